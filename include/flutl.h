@@ -1,0 +1,194 @@
+/*
+ * flutl.h -- C-ABI of the MI355X-native ttmlrender compositor ("fluttml-hip").
+ *
+ * This is the drop-in boundary UNDER the reference's GStreamer element
+ * (plugins/ttml/gstttmlrender.c).  The reference element's per-buffer work,
+ * gst_ttmlrender_gen_buffer (gstttmlrender.c:1427-1478), is split in two:
+ *
+ *   host  (C, Pango for shaping, Cairo only as A8 mask rasteriser)
+ *         builds a DISPLAY LIST: an ordered list of pixel primitives with the
+ *         region scissor, z-order and colour quantisation already baked in;
+ *   device (hand-written HIP, gfx950) composites that list into the
+ *         premultiplied B,G,R,A frame, every pixel stored exactly once.
+ *
+ * Each entry point below names the reference call site(s) it replaces.
+ * Plain pointers and sizes only; no GStreamer, torch or HIP types.
+ *
+ * All functions return 0 on success or a negative FLUTL_E* code.  There is no
+ * CPU fallback: without a usable HIP device every compute entry point returns
+ * FLUTL_ENODEV.
+ */
+#ifndef FLUTL_H
+#define FLUTL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLUTL_ABI_VERSION 1
+
+/* ---- error codes --------------------------------------------------------- */
+#define FLUTL_OK       0
+#define FLUTL_EINVAL  -22 /* bad argument / malformed display list          */
+#define FLUTL_ENOMEM  -12 /* hipMalloc / malloc failed                       */
+#define FLUTL_ENODEV  -19 /* no HIP device, or HIP runtime error             */
+#define FLUTL_ERANGE  -34 /* primitive references bytes outside the atlas    */
+
+/* ---- display-list IR ------------------------------------------------------
+ *
+ * Pixel format everywhere: premultiplied a8r8g8b8 in a little-endian uint32,
+ * i.e. memory order B,G,R,A == Cairo CAIRO_FORMAT_ARGB32 == what the
+ * reference pushes downstream (gstttmlrender.c:1446-1448; caps say "BGRA").
+ *
+ * Primitive ops.  "coverage" is an 8-bit value per destination pixel.
+ */
+#define FLUTL_OP_RECT        1u /* coverage from a 24.8 fixed-point box: replaces
+                                 * cairo_rectangle+cairo_fill at gstttmlrender.c
+                                 * :1265-1267 (region bg, pixel aligned), :1025-1027
+                                 * (span bg), :1053-1092 (under/over/strike lines).
+                                 * a,b,c,d = x1,y1,x2,y2 in 1/256 px.             */
+#define FLUTL_OP_MASK        2u /* coverage from an A8 mask in the atlas: replaces
+                                 * pango_cairo_show_glyph_string (:1150, one glyph)
+                                 * and cairo_stroke of the outline path (:1212).
+                                 * a = atlas byte offset, b = row stride (bytes),
+                                 * c,d = destination x,y of mask pixel (0,0).     */
+#define FLUTL_OP_IMAGE       3u /* premultiplied ARGB32 image in the atlas, OVER:
+                                 * replaces set_source_surface+paint (:1272-1275)
+                                 * and the blurred-outline blit (:1219-1224).
+                                 * a,b,c,d as for MASK (stride in bytes).         */
+#define FLUTL_OP_GROUP_BEGIN 4u /* region opacity group opens: the temp surface of
+                                 * :1250-1255.  Following prims paint into the
+                                 * group buffer, which starts transparent.        */
+#define FLUTL_OP_GROUP_END   5u /* cairo_paint_with_alpha (:1378-1380):
+                                 * dst = (group IN param) OVER dst.               */
+
+/* Blend rules (which third-party arithmetic the reference reaches). */
+#define FLUTL_RULE_PIXMAN 0u /* pixman: d = s*m + d*(255 - sa*m), MUL_UN8 rounding
+                              * (t = a*b + 0x80; (t + (t >> 8)) >> 8), saturating add */
+#define FLUTL_RULE_LERP   1u /* cairo in-place span renderer for OPAQUE solid
+                              * sources (fill/stroke with partial coverage):
+                              * d = mul(s,m) + mul(d,255-m) with 0x7f rounding       */
+
+typedef struct flutl_prim {
+  uint8_t  op;     /* FLUTL_OP_*                                              */
+  uint8_t  rule;   /* FLUTL_RULE_*                                            */
+  uint16_t param;  /* GROUP_END: 8-bit group alpha; else 0                    */
+  int16_t  cx0, cy0, cx1, cy1; /* destination bbox [cx0,cx1) x [cy0,cy1) in px,
+                                * already intersected with clip, group surface
+                                * and frame; nothing is touched outside it     */
+  uint32_t color;  /* premultiplied a8r8g8b8 source (RECT, MASK)              */
+  int32_t  a, b, c, d; /* op-specific, see FLUTL_OP_*                         */
+} flutl_prim; /* 32 bytes */
+
+/* One binning group == the primitives of one TTML region, in paint order.
+ * Regions are stored in paint (z) order: gstttmlrender.c:659-660, :1466-1467. */
+typedef struct flutl_region {
+  int16_t  x0, y0, x1, y1; /* union of the prim bboxes (for tile culling)     */
+  uint32_t first;          /* index of first prim                             */
+  uint32_t count;          /* number of prims                                 */
+} flutl_region; /* 16 bytes */
+
+/* Output tile of the compositor kernel: one workgroup per tile. */
+#define FLUTL_TILE_W 64
+#define FLUTL_TILE_H 8
+
+/* ---- host-side validation (no device needed) ----------------------------- */
+
+/* Checks a display list for structural validity against a W x H frame and an
+ * atlas of atlas_bytes: ops/rules known, bboxes inside the frame, mask/image
+ * reads inside the atlas, groups balanced per region.  Launching an invalid
+ * list is refused by every render entry point (a stray read would fault the
+ * GPU). */
+int flutl_list_validate (uint32_t width, uint32_t height,
+    const flutl_region *regions, uint32_t n_regions,
+    const flutl_prim *prims, uint32_t n_prims, size_t atlas_bytes);
+
+/* ---- stateless launches on caller-owned device memory --------------------
+ * For callers that manage HBM themselves (a device-memory GstAllocator, the
+ * test-suite, bench.py).  All pointers are DEVICE pointers; `stream` is a
+ * hipStream_t (NULL = default stream).  The list must have been validated on
+ * the host with flutl_list_validate(). */
+
+/* One frame: the device side of gst_ttmlrender_gen_buffer
+ * (gstttmlrender.c:1446-1467: CLEAR + region loop), one launch. */
+int flutl_launch_frame (void *stream, uint32_t width, uint32_t height,
+    void *dst, size_t dst_stride_bytes,
+    const flutl_region *regions, uint32_t n_regions,
+    const flutl_prim *prims, const uint8_t *atlas);
+
+/* A batch of independent frames (different scene states / streams) in ONE
+ * launch: frame i uses regions[region_first[i] .. +region_count[i]) and is
+ * written to dst + i*dst_frame_bytes.  Prim indices inside regions are
+ * absolute into `prims`. */
+typedef struct flutl_frame_desc {
+  uint32_t region_first;
+  uint32_t region_count;
+  uint64_t dst_offset;   /* byte offset of this frame from `dst`             */
+} flutl_frame_desc;
+
+int flutl_launch_batch (void *stream, uint32_t width, uint32_t height,
+    void *dst, size_t dst_stride_bytes,
+    const flutl_frame_desc *frames /* device */, uint32_t n_frames,
+    const flutl_region *regions, const flutl_prim *prims,
+    const uint8_t *atlas);
+
+/* Gaussian blur of a premultiplied ARGB32 image with pixman's convolution
+ * semantics: replaces gst_ttml_blur_image_surface (gstttmlblur.c:71-110).
+ * `kernel_fixed` = (2r+1)^2 pixman 16.16 weights (device), as produced by
+ * flutl_blur_kernel(). src/dst are w x h, stride in bytes; taps outside the
+ * source read transparent (PIXMAN_REPEAT_NONE). */
+int flutl_launch_blur (void *stream, const void *src, void *dst,
+    uint32_t w, uint32_t h, size_t stride_bytes,
+    const int32_t *kernel_fixed, int radius);
+
+/* Host helper: replaces gst_ttml_blur_create_gaussian_kernel
+ * (gstttmlblur.c:27-67).  Writes (2r+1)^2 16.16 weights to out. */
+int flutl_blur_kernel (int radius, double sigma, int32_t *out);
+
+/* ---- context API (library-owned HBM; what the GStreamer element uses) ---- */
+
+typedef struct flutl_ctx flutl_ctx;     /* one per element instance / thread  */
+typedef struct flutl_list flutl_list;   /* a display list resident in HBM     */
+
+/* Create a context on HIP device `device` with its own stream.  Replaces the
+ * per-instance Cairo state set up in gst_ttmlrender_init (gstttmlrender.c
+ * :1723-1750).  Re-entrant: several contexts may be used from different
+ * threads concurrently. */
+int  flutl_ctx_create (int device, flutl_ctx **out);
+void flutl_ctx_destroy (flutl_ctx *ctx);
+
+/* Atlas: one growing device buffer of A8 masks / ARGB32 images per context.
+ * flutl_atlas_put appends `bytes` (16-byte aligned) and returns its offset.
+ * flutl_atlas_reset drops all entries: gst_ttmlrender_reset (:1610-1621). */
+int  flutl_atlas_put (flutl_ctx *ctx, const void *src, size_t bytes,
+    uint32_t *offset_out);
+void flutl_atlas_reset (flutl_ctx *ctx);
+size_t flutl_atlas_size (const flutl_ctx *ctx);
+
+/* Upload (validate + H2D) a display list for a W x H frame. */
+int  flutl_list_create (flutl_ctx *ctx, uint32_t width, uint32_t height,
+    const flutl_region *regions, uint32_t n_regions,
+    const flutl_prim *prims, uint32_t n_prims, flutl_list **out);
+void flutl_list_destroy (flutl_ctx *ctx, flutl_list *list);
+
+/* Render into a device buffer (asynchronous on the context's stream). */
+int  flutl_render (flutl_ctx *ctx, const flutl_list *list,
+    void *dst_dev, size_t dst_stride_bytes);
+/* Render and copy to host memory (synchronous): what gen_buffer needs to fill
+ * a system-memory GstBuffer (gstttmlrender.c:1442-1444, :1474-1477). */
+int  flutl_render_to_host (flutl_ctx *ctx, const flutl_list *list,
+    void *dst_host, size_t dst_stride_bytes);
+int  flutl_ctx_sync (flutl_ctx *ctx);
+
+/* Library / device info (never fails; device_count 0 without a GPU). */
+int         flutl_abi_version (void);
+int         flutl_device_count (void);
+const char *flutl_strerror (int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUTL_H */
