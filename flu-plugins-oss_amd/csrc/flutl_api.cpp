@@ -1,0 +1,372 @@
+// flutl_api.cpp -- host half of the extern "C" shim (include/flutl.h): display
+// list validation, the per-element context (stream, atlas and list memory in
+// HBM) and the render entry points used by the GStreamer element.  Kernels and
+// the stateless launches live in flutl_kernels.hip.
+//
+// There is deliberately no CPU rendering path here: if HIP is unusable every
+// compute entry point fails with FLUTL_ENODEV.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <new>
+#include "flutl.h"
+
+namespace {
+
+constexpr size_t kAtlasSlack = 16;   // readable bytes before/after any entry
+constexpr size_t kAtlasAlign = 16;
+
+inline bool hip_ok (hipError_t e) { return e == hipSuccess; }
+
+}  // namespace
+
+struct flutl_list {
+  uint32_t width, height;
+  uint32_t n_regions, n_prims;
+  flutl_region *regions;  // device
+  flutl_prim *prims;      // device (same allocation)
+  void *mem;
+};
+
+struct flutl_ctx {
+  int device;
+  hipStream_t stream;
+  uint8_t *atlas;      // device
+  size_t atlas_cap;    // allocated bytes
+  size_t atlas_used;   // bytes in use (incl. leading slack)
+  void *frame;         // device staging frame for render_to_host
+  size_t frame_cap;
+};
+
+extern "C" int flutl_abi_version (void) { return FLUTL_ABI_VERSION; }
+
+extern "C" int flutl_device_count (void)
+{
+  int n = 0;
+  if (!hip_ok (hipGetDeviceCount (&n)))
+    return 0;
+  return n;
+}
+
+extern "C" const char *flutl_strerror (int code)
+{
+  switch (code) {
+    case FLUTL_OK: return "ok";
+    case FLUTL_EINVAL: return "invalid argument or malformed display list";
+    case FLUTL_ENOMEM: return "out of memory";
+    case FLUTL_ENODEV: return "no usable HIP device / HIP runtime error";
+    case FLUTL_ERANGE: return "primitive reads outside the atlas";
+    default: return "unknown error";
+  }
+}
+
+extern "C" int flutl_list_validate (uint32_t width, uint32_t height,
+    const flutl_region *regions, uint32_t n_regions, const flutl_prim *prims,
+    uint32_t n_prims, size_t atlas_bytes)
+{
+  if (width == 0 || height == 0 || width > 32767 || height > 32767)
+    return FLUTL_EINVAL;
+  if ((n_regions && !regions) || (n_prims && !prims))
+    return FLUTL_EINVAL;
+  for (uint32_t r = 0; r < n_regions; r++) {
+    const flutl_region &rg = regions[r];
+    if ((uint64_t) rg.first + rg.count > n_prims)
+      return FLUTL_EINVAL;
+    if (rg.x0 < 0 || rg.y0 < 0 || rg.x1 > (int) width || rg.y1 > (int) height ||
+        rg.x0 > rg.x1 || rg.y0 > rg.y1)
+      return FLUTL_EINVAL;
+    int depth = 0;
+    for (uint32_t i = rg.first; i < rg.first + rg.count; i++) {
+      const flutl_prim &p = prims[i];
+      if (p.cx0 > p.cx1 || p.cy0 > p.cy1 || p.cx0 < rg.x0 || p.cy0 < rg.y0 ||
+          p.cx1 > rg.x1 || p.cy1 > rg.y1)
+        return FLUTL_EINVAL;
+      if (p.rule != FLUTL_RULE_PIXMAN && p.rule != FLUTL_RULE_LERP)
+        return FLUTL_EINVAL;
+      switch (p.op) {
+        case FLUTL_OP_RECT:
+          if (p.a > p.c || p.b > p.d)
+            return FLUTL_EINVAL;
+          break;
+        case FLUTL_OP_MASK:
+        case FLUTL_OP_IMAGE: {
+          const int64_t bpp = p.op == FLUTL_OP_IMAGE ? 4 : 1;
+          if (p.a < 0 || p.b <= 0)
+            return FLUTL_EINVAL;
+          if (p.op == FLUTL_OP_IMAGE && ((p.a & 3) || (p.b & 3)))
+            return FLUTL_EINVAL;
+          if (p.cx0 == p.cx1 || p.cy0 == p.cy1)
+            break;
+          if (p.cx0 < p.c || p.cy0 < p.d)
+            return FLUTL_ERANGE;
+          if ((int64_t) (p.cx1 - p.c) * bpp > p.b)
+            return FLUTL_ERANGE;
+          const int64_t lo = (int64_t) p.a + (int64_t) (p.cy0 - p.d) * p.b +
+              (int64_t) (p.cx0 - p.c) * bpp;
+          const int64_t hi = (int64_t) p.a + (int64_t) (p.cy1 - 1 - p.d) * p.b +
+              (int64_t) (p.cx1 - p.c) * bpp;
+          // the kernel reads 4-byte windows that may start up to 3 bytes
+          // before / end 3 bytes after the bbox: keep them inside the atlas
+          if (lo < (int64_t) kAtlasSlack ||
+              hi + (int64_t) kAtlasSlack > (int64_t) atlas_bytes)
+            return FLUTL_ERANGE;
+          break;
+        }
+        case FLUTL_OP_GROUP_BEGIN:
+          if (depth != 0)
+            return FLUTL_EINVAL;
+          depth = 1;
+          break;
+        case FLUTL_OP_GROUP_END:
+          if (depth != 1 || p.param > 255)
+            return FLUTL_EINVAL;
+          depth = 0;
+          break;
+        default:
+          return FLUTL_EINVAL;
+      }
+    }
+    if (depth != 0)
+      return FLUTL_EINVAL;
+  }
+  return FLUTL_OK;
+}
+
+extern "C" int flutl_blur_kernel (int radius, double sigma, int32_t *out)
+{
+  if (radius < 0 || radius > 16 || !out || !(sigma > 0.0))
+    return FLUTL_EINVAL;
+  const double scale2 = 2.0 * sigma * sigma;
+  const double scale1 = 1.0 / (M_PI * scale2);
+  const int size = 2 * radius + 1;
+  double acc[33 * 33];
+  double sum = 0.0;
+  int i = 0;
+  for (int x = -radius; x <= radius; ++x)
+    for (int y = -radius; y <= radius; ++y, ++i) {
+      acc[i] = scale1 * exp (-((double) (x * x) + (double) (y * y)) / scale2);
+      sum += acc[i];
+    }
+  for (i = 0; i < size * size; ++i)
+    out[i] = (int32_t) ((acc[i] / sum) * 65536.0);  // pixman_double_to_fixed
+  return FLUTL_OK;
+}
+
+// ---- context -------------------------------------------------------------
+
+extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
+{
+  if (!out)
+    return FLUTL_EINVAL;
+  *out = nullptr;
+  int n = 0;
+  if (!hip_ok (hipGetDeviceCount (&n)) || device < 0 || device >= n)
+    return FLUTL_ENODEV;
+  if (!hip_ok (hipSetDevice (device)))
+    return FLUTL_ENODEV;
+  flutl_ctx *c = new (std::nothrow) flutl_ctx ();
+  if (!c)
+    return FLUTL_ENOMEM;
+  c->device = device;
+  if (!hip_ok (hipStreamCreateWithFlags (&c->stream, hipStreamNonBlocking))) {
+    delete c;
+    return FLUTL_ENODEV;
+  }
+  c->atlas = nullptr;
+  c->atlas_cap = 0;
+  c->atlas_used = kAtlasSlack;
+  c->frame = nullptr;
+  c->frame_cap = 0;
+  *out = c;
+  return FLUTL_OK;
+}
+
+extern "C" void flutl_ctx_destroy (flutl_ctx *c)
+{
+  if (!c)
+    return;
+  (void) hipSetDevice (c->device);
+  (void) hipStreamSynchronize (c->stream);
+  if (c->atlas)
+    (void) hipFree (c->atlas);
+  if (c->frame)
+    (void) hipFree (c->frame);
+  (void) hipStreamDestroy (c->stream);
+  delete c;
+}
+
+extern "C" int flutl_ctx_sync (flutl_ctx *c)
+{
+  if (!c)
+    return FLUTL_EINVAL;
+  return hip_ok (hipStreamSynchronize (c->stream)) ? FLUTL_OK : FLUTL_ENODEV;
+}
+
+static int atlas_reserve (flutl_ctx *c, size_t need)
+{
+  if (need <= c->atlas_cap)
+    return FLUTL_OK;
+  size_t cap = c->atlas_cap ? c->atlas_cap : (size_t) 1 << 20;
+  while (cap < need)
+    cap *= 2;
+  uint8_t *n = nullptr;
+  if (!hip_ok (hipMalloc (reinterpret_cast<void **> (&n), cap)))
+    return FLUTL_ENOMEM;
+  if (!hip_ok (hipMemsetAsync (n, 0, cap, c->stream))) {
+    (void) hipFree (n);
+    return FLUTL_ENODEV;
+  }
+  if (c->atlas) {
+    // lists in flight may still read the old buffer: drain first
+    if (!hip_ok (hipMemcpyAsync (n, c->atlas, c->atlas_used, hipMemcpyDeviceToDevice,
+            c->stream)) ||
+        !hip_ok (hipStreamSynchronize (c->stream))) {
+      (void) hipFree (n);
+      return FLUTL_ENODEV;
+    }
+    (void) hipFree (c->atlas);
+  }
+  c->atlas = n;
+  c->atlas_cap = cap;
+  return FLUTL_OK;
+}
+
+extern "C" int flutl_atlas_put (flutl_ctx *c, const void *src, size_t bytes,
+    uint32_t *offset_out)
+{
+  if (!c || !src || !offset_out || bytes == 0)
+    return FLUTL_EINVAL;
+  (void) hipSetDevice (c->device);
+  const size_t off = (c->atlas_used + kAtlasAlign - 1) & ~(kAtlasAlign - 1);
+  const size_t end = off + bytes;
+  if (end + kAtlasSlack > 0x7fffffffu)
+    return FLUTL_ERANGE;
+  int rc = atlas_reserve (c, end + kAtlasSlack);
+  if (rc)
+    return rc;
+  if (!hip_ok (hipMemcpyAsync (c->atlas + off, src, bytes, hipMemcpyHostToDevice,
+          c->stream)))
+    return FLUTL_ENODEV;
+  // src may be freed by the caller right after return
+  if (!hip_ok (hipStreamSynchronize (c->stream)))
+    return FLUTL_ENODEV;
+  c->atlas_used = end;
+  *offset_out = (uint32_t) off;
+  return FLUTL_OK;
+}
+
+extern "C" void flutl_atlas_reset (flutl_ctx *c)
+{
+  if (c)
+    c->atlas_used = kAtlasSlack;
+}
+
+extern "C" size_t flutl_atlas_size (const flutl_ctx *c)
+{
+  return c ? c->atlas_used + kAtlasSlack : 0;
+}
+
+extern "C" int flutl_list_create (flutl_ctx *c, uint32_t width, uint32_t height,
+    const flutl_region *regions, uint32_t n_regions, const flutl_prim *prims,
+    uint32_t n_prims, flutl_list **out)
+{
+  if (!c || !out)
+    return FLUTL_EINVAL;
+  *out = nullptr;
+  int rc = flutl_list_validate (width, height, regions, n_regions, prims, n_prims,
+      c->atlas_used + kAtlasSlack);
+  if (rc)
+    return rc;
+  (void) hipSetDevice (c->device);
+  flutl_list *l = new (std::nothrow) flutl_list ();
+  if (!l)
+    return FLUTL_ENOMEM;
+  const size_t rb = ((size_t) n_regions * sizeof (flutl_region) + 31) & ~(size_t) 31;
+  const size_t pb = (size_t) n_prims * sizeof (flutl_prim);
+  l->width = width;
+  l->height = height;
+  l->n_regions = n_regions;
+  l->n_prims = n_prims;
+  l->mem = nullptr;
+  if (!hip_ok (hipMalloc (&l->mem, rb + pb + 32))) {
+    delete l;
+    return FLUTL_ENOMEM;
+  }
+  l->regions = static_cast<flutl_region *> (l->mem);
+  l->prims = reinterpret_cast<flutl_prim *> (static_cast<uint8_t *> (l->mem) + rb);
+  bool ok = true;
+  if (n_regions)
+    ok = ok && hip_ok (hipMemcpyAsync (l->regions, regions,
+        (size_t) n_regions * sizeof (flutl_region), hipMemcpyHostToDevice, c->stream));
+  if (n_prims)
+    ok = ok && hip_ok (hipMemcpyAsync (l->prims, prims, pb, hipMemcpyHostToDevice,
+        c->stream));
+  ok = ok && hip_ok (hipStreamSynchronize (c->stream));
+  if (!ok) {
+    (void) hipFree (l->mem);
+    delete l;
+    return FLUTL_ENODEV;
+  }
+  *out = l;
+  return FLUTL_OK;
+}
+
+extern "C" void flutl_list_destroy (flutl_ctx *c, flutl_list *l)
+{
+  if (!l)
+    return;
+  if (c) {
+    (void) hipSetDevice (c->device);
+    (void) hipStreamSynchronize (c->stream);
+  }
+  if (l->mem)
+    (void) hipFree (l->mem);
+  delete l;
+}
+
+extern "C" int flutl_render (flutl_ctx *c, const flutl_list *l, void *dst_dev,
+    size_t dst_stride_bytes)
+{
+  if (!c || !l || !dst_dev)
+    return FLUTL_EINVAL;
+  (void) hipSetDevice (c->device);
+  return flutl_launch_frame (c->stream, l->width, l->height, dst_dev,
+      dst_stride_bytes, l->regions, l->n_regions, l->prims, c->atlas);
+}
+
+extern "C" int flutl_render_to_host (flutl_ctx *c, const flutl_list *l,
+    void *dst_host, size_t dst_stride_bytes)
+{
+  if (!c || !l || !dst_host || dst_stride_bytes < (size_t) l->width * 4)
+    return FLUTL_EINVAL;
+  (void) hipSetDevice (c->device);
+  const size_t tight = (size_t) l->width * 4;
+  const size_t need = tight * l->height;
+  if (need > c->frame_cap) {
+    if (c->frame) {
+      (void) hipStreamSynchronize (c->stream);
+      (void) hipFree (c->frame);
+      c->frame = nullptr;
+      c->frame_cap = 0;
+    }
+    if (!hip_ok (hipMalloc (&c->frame, need)))
+      return FLUTL_ENOMEM;
+    c->frame_cap = need;
+  }
+  int rc = flutl_launch_frame (c->stream, l->width, l->height, c->frame, tight,
+      l->regions, l->n_regions, l->prims, c->atlas);
+  if (rc)
+    return rc;
+  hipError_t e;
+  if (dst_stride_bytes == tight)
+    e = hipMemcpyAsync (dst_host, c->frame, need, hipMemcpyDeviceToHost, c->stream);
+  else
+    e = hipMemcpy2DAsync (dst_host, dst_stride_bytes, c->frame, tight, tight,
+        l->height, hipMemcpyDeviceToHost, c->stream);
+  if (!hip_ok (e) || !hip_ok (hipStreamSynchronize (c->stream)))
+    return FLUTL_ENODEV;
+  return FLUTL_OK;
+}

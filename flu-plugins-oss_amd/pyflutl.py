@@ -1,0 +1,206 @@
+"""ctypes binding of the fluttml-hip C-ABI (include/flutl.h).
+
+Plumbing for tests and bench.py only: the product is the C library
+(lib/libflutl.so) and the GStreamer element in host/.  PyTorch is used by the
+callers of this module for device memory and streams; nothing here computes.
+
+The library must have been built (``python -c 'import __graft_entry__ as g;
+g.build()'`` or ``make -C flu-plugins-oss_amd``); there is no fallback.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libflutl.so")
+
+# ---- IR mirrors (include/flutl.h) -----------------------------------------
+OP_RECT, OP_MASK, OP_IMAGE, OP_GROUP_BEGIN, OP_GROUP_END = 1, 2, 3, 4, 5
+RULE_PIXMAN, RULE_LERP = 0, 1
+TILE_W, TILE_H = 64, 8
+ATLAS_SLACK = 16
+
+PRIM_DTYPE = np.dtype([
+    ("op", "u1"), ("rule", "u1"), ("param", "<u2"),
+    ("cx0", "<i2"), ("cy0", "<i2"), ("cx1", "<i2"), ("cy1", "<i2"),
+    ("color", "<u4"),
+    ("a", "<i4"), ("b", "<i4"), ("c", "<i4"), ("d", "<i4"),
+])
+REGION_DTYPE = np.dtype([
+    ("x0", "<i2"), ("y0", "<i2"), ("x1", "<i2"), ("y1", "<i2"),
+    ("first", "<u4"), ("count", "<u4"),
+])
+FRAME_DTYPE = np.dtype([
+    ("region_first", "<u4"), ("region_count", "<u4"), ("dst_offset", "<u8"),
+])
+assert PRIM_DTYPE.itemsize == 32 and REGION_DTYPE.itemsize == 16
+assert FRAME_DTYPE.itemsize == 16
+
+EXPORTS = [
+    "flutl_abi_version", "flutl_device_count", "flutl_strerror",
+    "flutl_list_validate", "flutl_launch_frame", "flutl_launch_batch",
+    "flutl_launch_blur", "flutl_blur_kernel",
+    "flutl_ctx_create", "flutl_ctx_destroy", "flutl_ctx_sync",
+    "flutl_atlas_put", "flutl_atlas_reset", "flutl_atlas_size",
+    "flutl_list_create", "flutl_list_destroy",
+    "flutl_render", "flutl_render_to_host",
+]
+
+
+class FlutlError(RuntimeError):
+    def __init__(self, code, what):
+        self.code = code
+        super().__init__(f"{what}: {code} ({strerror(code)})")
+
+
+_lib = None
+
+
+def lib():
+    """Load lib/libflutl.so; raises loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                f"{LIB_PATH} missing: build it with __graft_entry__.build() "
+                "(there is no CPU fallback for the HIP path)")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, u32, sz = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_size_t
+        L.flutl_strerror.restype = ctypes.c_char_p
+        L.flutl_strerror.argtypes = [ctypes.c_int]
+        L.flutl_list_validate.argtypes = [u32, u32, vp, u32, vp, u32, sz]
+        L.flutl_launch_frame.argtypes = [vp, u32, u32, vp, sz, vp, u32, vp, vp]
+        L.flutl_launch_batch.argtypes = [vp, u32, u32, vp, sz, vp, u32, vp, vp, vp]
+        L.flutl_launch_blur.argtypes = [vp, vp, vp, u32, u32, sz, vp, ctypes.c_int]
+        L.flutl_blur_kernel.argtypes = [ctypes.c_int, ctypes.c_double, vp]
+        L.flutl_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+        L.flutl_ctx_destroy.argtypes = [vp]
+        L.flutl_ctx_destroy.restype = None
+        L.flutl_ctx_sync.argtypes = [vp]
+        L.flutl_atlas_put.argtypes = [vp, vp, sz, ctypes.POINTER(u32)]
+        L.flutl_atlas_reset.argtypes = [vp]
+        L.flutl_atlas_reset.restype = None
+        L.flutl_atlas_size.argtypes = [vp]
+        L.flutl_atlas_size.restype = sz
+        L.flutl_list_create.argtypes = [vp, u32, u32, vp, u32, vp, u32,
+                                        ctypes.POINTER(vp)]
+        L.flutl_list_destroy.argtypes = [vp, vp]
+        L.flutl_list_destroy.restype = None
+        L.flutl_render.argtypes = [vp, vp, vp, sz]
+        L.flutl_render_to_host.argtypes = [vp, vp, vp, sz]
+        _lib = L
+    return _lib
+
+
+def strerror(code):
+    return lib().flutl_strerror(int(code)).decode()
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise FlutlError(rc, what)
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def validate(width, height, regions, prims, atlas_bytes):
+    regions = np.ascontiguousarray(regions, REGION_DTYPE)
+    prims = np.ascontiguousarray(prims, PRIM_DTYPE)
+    return lib().flutl_list_validate(width, height, _np_ptr(regions), len(regions),
+                                     _np_ptr(prims), len(prims), atlas_bytes)
+
+
+def blur_kernel(radius, sigma):
+    out = np.empty((2 * radius + 1) ** 2, np.int32)
+    _check(lib().flutl_blur_kernel(radius, float(sigma), _np_ptr(out)),
+           "flutl_blur_kernel")
+    return out
+
+
+# ---- stateless launches on torch-owned device memory ----------------------
+
+def launch_frame(stream, width, height, dst, regions_dev, n_regions, prims_dev,
+                 atlas_dev, stride=None):
+    """dst / *_dev: torch CUDA tensors (or raw int device pointers)."""
+    p = lambda t: ctypes.c_void_p(t if isinstance(t, int) else t.data_ptr())
+    _check(lib().flutl_launch_frame(ctypes.c_void_p(stream), width, height, p(dst),
+                                    stride or width * 4, p(regions_dev), n_regions,
+                                    p(prims_dev), p(atlas_dev)),
+           "flutl_launch_frame")
+
+
+def launch_batch(stream, width, height, dst, frames_dev, n_frames, regions_dev,
+                 prims_dev, atlas_dev, stride=None):
+    p = lambda t: ctypes.c_void_p(t if isinstance(t, int) else t.data_ptr())
+    _check(lib().flutl_launch_batch(ctypes.c_void_p(stream), width, height, p(dst),
+                                    stride or width * 4, p(frames_dev), n_frames,
+                                    p(regions_dev), p(prims_dev), p(atlas_dev)),
+           "flutl_launch_batch")
+
+
+def launch_blur(stream, src, dst, w, h, kernel_dev, radius, stride=None):
+    p = lambda t: ctypes.c_void_p(t if isinstance(t, int) else t.data_ptr())
+    _check(lib().flutl_launch_blur(ctypes.c_void_p(stream), p(src), p(dst), w, h,
+                                   stride or w * 4, p(kernel_dev), radius),
+           "flutl_launch_blur")
+
+
+# ---- context API (library-owned HBM), as the GStreamer element uses it ----
+
+class Context:
+    def __init__(self, device=0):
+        h = ctypes.c_void_p()
+        _check(lib().flutl_ctx_create(device, ctypes.byref(h)), "flutl_ctx_create")
+        self._h = h
+
+    def close(self):
+        if self._h:
+            lib().flutl_ctx_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def atlas_put(self, data):
+        data = np.ascontiguousarray(data)
+        off = ctypes.c_uint32()
+        _check(lib().flutl_atlas_put(self._h, _np_ptr(data), data.nbytes,
+                                     ctypes.byref(off)), "flutl_atlas_put")
+        return off.value
+
+    def atlas_reset(self):
+        lib().flutl_atlas_reset(self._h)
+
+    def atlas_size(self):
+        return lib().flutl_atlas_size(self._h)
+
+    def list_create(self, width, height, regions, prims):
+        regions = np.ascontiguousarray(regions, REGION_DTYPE)
+        prims = np.ascontiguousarray(prims, PRIM_DTYPE)
+        h = ctypes.c_void_p()
+        _check(lib().flutl_list_create(self._h, width, height, _np_ptr(regions),
+                                       len(regions), _np_ptr(prims), len(prims),
+                                       ctypes.byref(h)), "flutl_list_create")
+        return h
+
+    def list_destroy(self, lst):
+        lib().flutl_list_destroy(self._h, lst)
+
+    def render_to_host(self, lst, width, height):
+        out = np.empty((height, width), np.uint32)
+        _check(lib().flutl_render_to_host(self._h, lst, _np_ptr(out), width * 4),
+               "flutl_render_to_host")
+        return out
+
+    def render(self, lst, dst_ptr, stride):
+        _check(lib().flutl_render(self._h, lst, ctypes.c_void_p(dst_ptr), stride),
+               "flutl_render")
+
+    def sync(self):
+        _check(lib().flutl_ctx_sync(self._h), "flutl_ctx_sync")

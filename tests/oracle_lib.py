@@ -1,0 +1,110 @@
+"""ctypes binding of oracle/libflutl_oracle.so -- the CHECKER, never the
+product.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+import this."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "libflutl_oracle.so")
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src = os.path.join(ORACLE_DIR, "flutl_oracle.c")
+        if (not os.path.exists(LIB_PATH) or
+                os.path.getmtime(LIB_PATH) < os.path.getmtime(src)):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "libflutl_oracle.so"],
+                                  stdout=subprocess.DEVNULL)
+        L = ctypes.CDLL(LIB_PATH)
+        u32p = np.ctypeslib.ndpointer(np.uint32, flags="C")
+        i32p = np.ctypeslib.ndpointer(np.int32, flags="C")
+        vp, u32, sz = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_size_t
+        L.flutl_oracle_blend_n.argtypes = [u32, u32p, u32p, u32p, u32p, sz]
+        L.flutl_oracle_over_n.argtypes = [u32p, u32p, u32p, sz]
+        L.flutl_oracle_group_n.argtypes = [u32p, u32p, u32p, u32p, sz]
+        L.flutl_oracle_color_rgba8888_n.argtypes = [u32p, u32p, sz]
+        L.flutl_oracle_color_rgba8888.argtypes = [u32]
+        L.flutl_oracle_color_rgba8888.restype = u32
+        L.flutl_oracle_color.argtypes = [ctypes.c_double] * 4
+        L.flutl_oracle_color.restype = u32
+        L.flutl_oracle_opacity_to_alpha.argtypes = [ctypes.c_double]
+        L.flutl_oracle_opacity_to_alpha.restype = u32
+        L.flutl_oracle_fixed_from_double.argtypes = [ctypes.c_double]
+        L.flutl_oracle_fixed_from_double.restype = ctypes.c_int32
+        L.flutl_oracle_rect_coverage.argtypes = [ctypes.c_int] * 6
+        L.flutl_oracle_rect_coverage.restype = u32
+        L.flutl_oracle_render.argtypes = [u32, u32, vp, sz, vp, u32, vp, vp]
+        L.flutl_oracle_blur.argtypes = [u32p, u32p, u32, u32, sz, i32p, ctypes.c_int]
+        L.flutl_oracle_blur_kernel.argtypes = [ctypes.c_int, ctypes.c_double, i32p]
+        _lib = L
+    return _lib
+
+
+def color_rgba8888(c):
+    c = np.ascontiguousarray(c, np.uint32)
+    o = np.empty_like(c)
+    lib().flutl_oracle_color_rgba8888_n(c.ravel(), o.ravel(), c.size)
+    return o
+
+
+def blend(rule, s, m, d):
+    s, m, d = (np.ascontiguousarray(np.broadcast_to(a, np.shape(d)), np.uint32).ravel()
+               for a in (s, m, d))
+    o = np.empty_like(d)
+    lib().flutl_oracle_blend_n(rule, s, m, d, o, d.size)
+    return o
+
+
+def over(s, d):
+    s = np.ascontiguousarray(s, np.uint32).ravel()
+    d = np.ascontiguousarray(d, np.uint32).ravel()
+    o = np.empty_like(d)
+    lib().flutl_oracle_over_n(s, d, o, d.size)
+    return o
+
+
+def group(g, alpha, d):
+    g = np.ascontiguousarray(g, np.uint32).ravel()
+    d = np.ascontiguousarray(d, np.uint32).ravel()
+    alpha = np.ascontiguousarray(np.broadcast_to(alpha, d.shape), np.uint32).ravel()
+    o = np.empty_like(d)
+    lib().flutl_oracle_group_n(g, alpha, d, o, d.size)
+    return o
+
+
+def render(width, height, regions, prims, atlas):
+    """CPU oracle frame for a display list (numpy structured arrays)."""
+    regions = np.ascontiguousarray(regions)
+    prims = np.ascontiguousarray(prims)
+    atlas = np.ascontiguousarray(atlas, np.uint8)
+    out = np.empty((height, width), np.uint32)
+    rc = lib().flutl_oracle_render(
+        width, height, out.ctypes.data_as(ctypes.c_void_p), width * 4,
+        regions.ctypes.data_as(ctypes.c_void_p), len(regions),
+        prims.ctypes.data_as(ctypes.c_void_p),
+        atlas.ctypes.data_as(ctypes.c_void_p))
+    if rc != 0:
+        raise RuntimeError(f"flutl_oracle_render: {rc}")
+    return out
+
+
+def blur(src, kernel, radius):
+    src = np.ascontiguousarray(src, np.uint32)
+    h, w = src.shape
+    out = np.empty_like(src)
+    lib().flutl_oracle_blur(src.ravel(), out.ravel(), w, h, w * 4,
+                            np.ascontiguousarray(kernel, np.int32), radius)
+    return out
+
+
+def blur_kernel(radius, sigma):
+    out = np.empty((2 * radius + 1) ** 2, np.int32)
+    lib().flutl_oracle_blur_kernel(radius, float(sigma), out)
+    return out

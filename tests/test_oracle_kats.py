@@ -1,0 +1,63 @@
+"""CPU: holds oracle/flutl_oracle.c to the known answers of the REAL
+cairo 1.16.0 / pixman 0.40.0 (tests/golden/kats.npz from oracle/kat_gen.c).
+This is what pins the oracle's arithmetic; scene-level pinning against the
+reference plugin's own frames is in test_oracle_scenes.py."""
+import numpy as np
+import pytest
+
+import kat_scenes
+import oracle_lib as O
+import pyflutl as F
+
+
+def test_versions(kats):
+    assert str(kats["versions"]) == "cairo 1.16.0 pixman 0.40.0"
+
+
+def test_color_quantisation(kats):
+    t = kats["color"]
+    assert np.array_equal(O.color_rgba8888(t[:, 0]), t[:, 1])
+
+
+def test_solid_over(kats):
+    t = kats["fill"]
+    assert np.array_equal(O.over(O.color_rgba8888(t[:, 0]), t[:, 1]), t[:, 2])
+
+
+def test_solid_in_mask_over(kats):
+    t = kats["mask"]
+    got = O.blend(F.RULE_PIXMAN, O.color_rgba8888(t[:, 0]), t[:, 1], t[:, 2])
+    assert np.array_equal(got, t[:, 3])
+
+
+def test_group_paint_with_alpha(kats):
+    t, op = kats["group"], kats["group_opacity"]
+    al = np.array([O.lib().flutl_oracle_opacity_to_alpha(float(x)) for x in op],
+                  np.uint32)
+    assert np.array_equal(O.group(t[:, 0], al, t[:, 1]), t[:, 2])
+
+
+def test_image_over(kats):
+    t = kats["image"]
+    assert np.array_equal(O.over(t[:, 0], t[:, 1]), t[:, 2])
+
+
+def test_blur_kernel_and_convolution(kats):
+    for i in range(int(kats["blur_count"])):
+        r, sigma = kats[f"blur{i}_radius_sigma"]
+        r = int(r)
+        k = kats[f"blur{i}_kernel"]
+        assert np.array_equal(O.blur_kernel(r, sigma), k)
+        assert np.array_equal(F.blur_kernel(r, sigma), k)   # product host helper
+        assert np.array_equal(O.blur(kats[f"blur{i}_src"], k, r), kats[f"blur{i}_out"])
+
+
+@pytest.mark.parametrize("name", sorted(kat_scenes.ALL))
+def test_compositor_reproduces_kat(kats, name):
+    """The oracle's display-list compositor (not just its scalar helpers)
+    reproduces real cairo's output for every table, incl. the unaligned-box
+    coverage rule and the opaque-stroke lerp rule."""
+    W, H, (R, P, A), exp = kat_scenes.ALL[name](kats)
+    assert F.validate(W, H, R, P, A.size) == 0
+    got = O.render(W, H, R, P, A)
+    assert np.array_equal(got, exp), f"{name}: {(got != exp).sum()} px differ"
