@@ -45,6 +45,22 @@ def load_states(cfg, n_states, stream_seed):
     W, H, nreg, font, outl, lines = CONFIGS[cfg]
     R, P, A = scenes.subtitle_like_scene(stream_seed, W, H, n_regions=nreg,
                                          font_px=font, outline_px=outl, lines=lines)
+    variant = os.environ.get("FLUTL_BENCH_VARIANT", "full")   # diagnosis only
+    if variant != "full":
+        keep = {"empty": lambda p: np.zeros(len(p), bool),
+                "bg": lambda p: p["op"] != 2,
+                "nooutline": lambda p: ~((p["op"] == 2) & (p["rule"] == 1)),
+                "noglyph": lambda p: ~((p["op"] == 2) & (p["rule"] == 0))}[variant](P)
+        newidx = np.cumsum(keep) - keep
+        R = R.copy()
+        for r in R:
+            sel = keep[r["first"]:r["first"] + r["count"]]
+            r["first"] = newidx[r["first"]] if r["count"] else 0
+            r["count"] = int(sel.sum())
+        P = P[keep]
+        if variant == "empty":
+            R = R[:0]
+        source = "synthetic-generator:" + variant
     rng = np.random.default_rng(stream_seed)
     states = []
     for s in range(n_states):
@@ -53,7 +69,8 @@ def load_states(cfg, n_states, stream_seed):
         glyph = (Ps["op"] == 2) & (Ps["rule"] == 0)
         Ps["color"][glyph] = 0xff000000 | int(rng.integers(0x404040, 0xffffff))
         states.append((R, Ps))
-    return W, H, states, A, "synthetic-generator"
+    return W, H, states, A, ("synthetic-generator" if variant == "full"
+                             else "synthetic-generator:" + variant)
 
 
 def main():

@@ -16,11 +16,16 @@
 //     clear pass and no read of the destination);
 //   * tiles are dealt to XCDs in contiguous bands (blocks b and b+8 share an
 //     XCD's L2), so a band's glyph masks are fetched into one L2 only;
-//   * per tile, the regions are culled with scalar loads, a region's
-//     primitives are binned by the 128 lanes in parallel (ballot + prefix
-//     popcount -> ordered list in LDS), then replayed in paint order.
+//   * the grid is persistent (<= 16 workgroups per CU) and grid-strides over
+//     tiles: workgroup dispatch rate would otherwise bound a 16k-tile frame;
+//   * per tile, regions are culled 64 at a time (one per lane + ballot), a
+//     region's primitives are binned by the 128 lanes in parallel (ballot +
+//     prefix popcount -> ordered, compacted 32-byte prims in LDS), then
+//     replayed in paint order with the next primitive's mask bytes already
+//     in flight.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "flutl.h"
 
 namespace {
@@ -130,8 +135,76 @@ struct FrameParams {
   uint64_t stride;                      // bytes
 };
 
-template <bool IN_GROUP>
-__device__ __forceinline__ void apply_cov (Px (&t)[4], const uint32_t (&cov)[4],
+// A primitive held wave-uniformly (SGPRs): read from the LDS bin list and
+// broadcast with v_readfirstlane so that all control flow on it is scalar.
+struct PrimU {
+  uint32_t op, rule, param;
+  int cx0, cy0, cx1, cy1;
+  uint32_t color;
+  int a, b, c, d;
+};
+
+__device__ __forceinline__ uint32_t rfl (uint32_t v)
+{
+  return (uint32_t) __builtin_amdgcn_readfirstlane ((int) v);
+}
+
+__device__ __forceinline__ PrimU prim_from_lds (const uint4 *s_prim, uint32_t i)
+{
+  const uint4 lo = s_prim[2 * i], hi = s_prim[2 * i + 1];
+  PrimU p;
+  const uint32_t w0 = rfl (lo.x), w1 = rfl (lo.y), w2 = rfl (lo.z);
+  p.op = w0 & 0xffu;
+  p.rule = (w0 >> 8) & 0xffu;
+  p.param = w0 >> 16;
+  p.cx0 = (int16_t) (w1 & 0xffffu);
+  p.cy0 = (int16_t) (w1 >> 16);
+  p.cx1 = (int16_t) (w2 & 0xffffu);
+  p.cy1 = (int16_t) (w2 >> 16);
+  p.color = rfl (lo.w);
+  p.a = (int) rfl (hi.x);
+  p.b = (int) rfl (hi.y);
+  p.c = (int) rfl (hi.z);
+  p.d = (int) rfl (hi.w);
+  return p;
+}
+
+// What a primitive needs from memory for this lane's 4 pixels.  Issued one
+// primitive ahead of its use so the load latency hides under the blend of the
+// previous primitive (OVER is order dependent, the loads are not).
+struct Fetched {
+  uint32_t v[4];
+};
+
+__device__ __forceinline__ Fetched prim_fetch (const PrimU &p,
+    const uint8_t *__restrict__ atlas, int x, int y)
+{
+  Fetched f = { { 0u, 0u, 0u, 0u } };
+  const bool any = y >= p.cy0 && y < p.cy1 && x < p.cx1 && x + 4 > p.cx0;
+  if (p.op == FLUTL_OP_MASK) {
+    if (any) {
+      // 4 consecutive A8 bytes at an arbitrary byte address.  The validated
+      // list keeps this window inside the atlas allocation (16 bytes of slack
+      // on both sides); bytes outside the bbox are masked off below.
+      const uint8_t *ptr = atlas + (uint32_t) p.a +
+          (size_t) (y - p.d) * (uint32_t) p.b + (x - p.c);
+      __builtin_memcpy (&f.v[0], ptr, 4);
+    }
+  } else if (p.op == FLUTL_OP_IMAGE) {
+    if (any) {
+      const uint8_t *row = atlas + (uint32_t) p.a +
+          (size_t) (y - p.d) * (uint32_t) p.b;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (x + k >= p.cx0 && x + k < p.cx1)
+          f.v[k] = *reinterpret_cast<const uint32_t *> (
+              row + (size_t) (x + k - p.c) * 4);
+    }
+  }
+  return f;
+}
+
+__device__ __forceinline__ void blend4 (Px (&t)[4], const uint32_t (&cov)[4],
     Px s, uint32_t rule)
 {
   if (rule == FLUTL_RULE_LERP) {
@@ -145,186 +218,198 @@ __device__ __forceinline__ void apply_cov (Px (&t)[4], const uint32_t (&cov)[4],
   }
 }
 
+__device__ __forceinline__ void prim_apply (const PrimU &p, const Fetched &f,
+    Px (&d)[4], Px (&g)[4], bool &in_group, int x, int y)
+{
+  if (p.op == FLUTL_OP_GROUP_BEGIN) {
+    in_group = true;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      g[k] = unpack (0);
+    return;
+  }
+  const bool rowin = y >= p.cy0 && y < p.cy1;
+  if (p.op == FLUTL_OP_GROUP_END) {
+    in_group = false;
+    const u16x2 al = splat (p.param);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const bool in = rowin && x + k >= p.cx0 && x + k < p.cx1;
+      if (in && (as_u32 (g[k].rb) | as_u32 (g[k].ag)) != 0) {
+        Px s;
+        s.rb = mul_un8 (g[k].rb, al);
+        s.ag = mul_un8 (g[k].ag, al);
+        over (d[k], s);
+      }
+    }
+    return;
+  }
+  if (p.op == FLUTL_OP_IMAGE) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      // pixels outside the bbox were fetched as 0: 0 OVER d == d
+      if (f.v[k] != 0) {
+        if (in_group)
+          over (g[k], unpack (f.v[k]));
+        else
+          over (d[k], unpack (f.v[k]));
+      }
+    }
+    return;
+  }
+  // RECT / MASK: 8-bit coverage for the lane's 4 pixels
+  uint32_t cov[4];
+  if (p.op == FLUTL_OP_RECT) {
+    const int oy = rowin ? overlap256 (p.b, p.d, y) : 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const bool in = x + k >= p.cx0 && x + k < p.cx1;
+      const uint32_t area = (uint32_t) (overlap256 (p.a, p.c, x + k) * oy) >> 8;
+      cov[k] = in ? min (area, 255u) : 0u;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const bool in = x + k >= p.cx0 && x + k < p.cx1;
+      cov[k] = in ? ((f.v[0] >> (8 * k)) & 0xffu) : 0u;
+    }
+  }
+  // wave-level early out: nothing of this prim lands in this wave's pixels
+  if (__ballot ((cov[0] | cov[1] | cov[2] | cov[3]) != 0) == 0)
+    return;
+  const Px s = unpack (p.color);
+  if (in_group)
+    blend4 (g, cov, s, p.rule);
+  else
+    blend4 (d, cov, s, p.rule);
+}
+
 __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
     FrameParams fp, uint8_t *__restrict__ dst,
     const flutl_frame_desc *__restrict__ frames,
     const flutl_region *__restrict__ regions,
     const flutl_prim *__restrict__ prims, const uint8_t *__restrict__ atlas)
 {
-  __shared__ uint32_t s_list[kChunk];
+  __shared__ uint4 s_prim[kChunk * 2];   // binned prims of the current chunk
   __shared__ uint32_t s_cnt[2];
-
-  // ---- XCD-aware block -> tile mapping (speed only) ----------------------
-  const uint32_t tiles_per_frame = fp.tiles_x * fp.tiles_y;
-  const uint32_t total = tiles_per_frame * fp.n_frames;
-  const uint32_t b = blockIdx.x;
-  const uint32_t logical = (b & 7u) * fp.per_xcd + (b >> 3);
-  if (logical >= total)
-    return;
-  const uint32_t frame = logical / tiles_per_frame;
-  const uint32_t tile = logical - frame * tiles_per_frame;
-  const uint32_t ty = tile / fp.tiles_x;
-  const uint32_t tx = tile - ty * fp.tiles_x;
-
-  uint32_t rfirst = fp.region_first, rcount = fp.region_count;
-  uint64_t dst_off = 0;
-  if (frames) {
-    rfirst = frames[frame].region_first;
-    rcount = frames[frame].region_count;
-    dst_off = frames[frame].dst_offset;
-  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int tx0 = (int) tx * FLUTL_TILE_W, ty0 = (int) ty * FLUTL_TILE_H;
-  const int x = tx0 + (tid & 15) * 4;
-  const int y = ty0 + (tid >> 4);
+  const uint32_t tiles_per_frame = fp.tiles_x * fp.tiles_y;
+  const uint32_t total = tiles_per_frame * fp.n_frames;
 
-  Px d[4], g[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    d[k] = unpack (0);
-    g[k] = unpack (0);
-  }
+  // Persistent grid-stride loop.  Blocks b and b+8 share an XCD (and its L2):
+  // XCD k walks the k-th contiguous band of tiles, so the glyph masks and
+  // display-list entries of a band are fetched into one L2 only.
+  const uint32_t xcd = blockIdx.x & 7u;
+  const uint32_t jstride = gridDim.x >> 3;
+  for (uint32_t j = blockIdx.x >> 3; j < fp.per_xcd; j += jstride) {
+    const uint32_t logical = xcd * fp.per_xcd + j;
+    if (logical >= total)
+      break;
+    const uint32_t frame = logical / tiles_per_frame;
+    const uint32_t tile = logical - frame * tiles_per_frame;
+    const uint32_t ty = tile / fp.tiles_x;
+    const uint32_t tx = tile - ty * fp.tiles_x;
 
-  for (uint32_t r = rfirst; r < rfirst + rcount; r++) {
-    // region bbox: wave-uniform -> scalar loads
-    const flutl_region rg = regions[r];
-    if (rg.x0 >= tx0 + FLUTL_TILE_W || rg.x1 <= tx0 ||
-        rg.y0 >= ty0 + FLUTL_TILE_H || rg.y1 <= ty0)
-      continue;
-    bool in_group = false;
-
-    for (uint32_t base = 0; base < rg.count; base += kChunk) {
-      // ---- bin: lane t tests prim base+t against the tile ----------------
-      const uint32_t pi = base + (uint32_t) tid;
-      bool hit = false;
-      if (pi < rg.count) {
-        const flutl_prim *p = &prims[rg.first + pi];
-        // cx0,cy0,cx1,cy1 are the 8 bytes at offset 4
-        const uint2 bb = *reinterpret_cast<const uint2 *> (
-            reinterpret_cast<const uint8_t *> (p) + 4);
-        const int cx0 = (int16_t) (bb.x & 0xffff), cy0 = (int16_t) (bb.x >> 16);
-        const int cx1 = (int16_t) (bb.y & 0xffff), cy1 = (int16_t) (bb.y >> 16);
-        hit = cx0 < tx0 + FLUTL_TILE_W && cx1 > tx0 &&
-            cy0 < ty0 + FLUTL_TILE_H && cy1 > ty0;
-      }
-      const unsigned long long bal = __ballot (hit);
-      if (lane == 0)
-        s_cnt[wave] = (uint32_t) __popcll (bal);
-      __syncthreads ();
-      const uint32_t pos = (wave ? s_cnt[0] : 0u) +
-          (uint32_t) __popcll (bal & ((1ull << lane) - 1ull));
-      const uint32_t n_hit = s_cnt[0] + s_cnt[1];
-      if (hit)
-        s_list[pos] = rg.first + pi;
-      __syncthreads ();
-
-      // ---- replay the tile's prims in paint order ------------------------
-      for (uint32_t i = 0; i < n_hit; i++) {
-        const uint32_t idx = __builtin_amdgcn_readfirstlane (s_list[i]);
-        const flutl_prim *pp = &prims[idx];
-        const uint32_t op = pp->op, rule = pp->rule;
-        const int cx0 = pp->cx0, cy0 = pp->cy0, cx1 = pp->cx1, cy1 = pp->cy1;
-
-        if (op == FLUTL_OP_GROUP_BEGIN) {
-          in_group = true;
-#pragma unroll
-          for (int k = 0; k < 4; k++)
-            g[k] = unpack (0);
-          continue;
-        }
-        if (op == FLUTL_OP_GROUP_END) {
-          in_group = false;
-          const u16x2 al = splat (pp->param);
-          const bool rowin = y >= cy0 && y < cy1;
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const bool in = rowin && x + k >= cx0 && x + k < cx1;
-            if (in && (as_u32 (g[k].rb) | as_u32 (g[k].ag)) != 0) {
-              Px s;
-              s.rb = mul_un8 (g[k].rb, al);
-              s.ag = mul_un8 (g[k].ag, al);
-              over (d[k], s);
-            }
-          }
-          continue;
-        }
-
-        const bool rowin = y >= cy0 && y < cy1;
-        const bool any = rowin && x < cx1 && x + 4 > cx0;
-
-        if (op == FLUTL_OP_IMAGE) {
-          if (any) {
-            const uint8_t *row = atlas + (uint32_t) pp->a +
-                (size_t) (y - pp->d) * (uint32_t) pp->b;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-              if (x + k >= cx0 && x + k < cx1) {
-                const uint32_t s = *reinterpret_cast<const uint32_t *> (
-                    row + (size_t) (x + k - pp->c) * 4);
-                if (in_group)
-                  over (g[k], unpack (s));
-                else
-                  over (d[k], unpack (s));
-              }
-            }
-          }
-          continue;
-        }
-
-        // RECT / MASK: 8-bit coverage for the lane's 4 pixels
-        uint32_t cov[4] = { 0, 0, 0, 0 };
-        if (op == FLUTL_OP_RECT) {
-          if (any) {
-            const int oy = overlap256 (pp->b, pp->d, y);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-              const bool in = x + k >= cx0 && x + k < cx1;
-              const uint32_t area =
-                  (uint32_t) (overlap256 (pp->a, pp->c, x + k) * oy) >> 8;
-              cov[k] = in ? min (area, 255u) : 0u;
-            }
-          }
-        } else {  // MASK
-          if (any) {
-            // 4 consecutive A8 bytes at an arbitrary byte address.  The
-            // validated list guarantees the window is inside the atlas
-            // allocation (16 bytes of slack on both sides).
-            const uint8_t *ptr = atlas + (uint32_t) pp->a +
-                (size_t) (y - pp->d) * (uint32_t) pp->b + (x - pp->c);
-            uint32_t w;
-            __builtin_memcpy (&w, ptr, 4);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-              const bool in = x + k >= cx0 && x + k < cx1;
-              cov[k] = in ? ((w >> (8 * k)) & 0xffu) : 0u;
-            }
-          }
-        }
-        // wave-level early out: nothing of this prim lands in this wave
-        if (__ballot ((cov[0] | cov[1] | cov[2] | cov[3]) != 0) == 0)
-          continue;
-        const Px s = unpack (pp->color);
-        if (in_group)
-          apply_cov<true> (g, cov, s, rule);
-        else
-          apply_cov<false> (d, cov, s, rule);
-      }
-      __syncthreads ();  // s_list / s_cnt are reused by the next chunk
+    uint32_t rfirst = fp.region_first, rcount = fp.region_count;
+    uint64_t dst_off = 0;
+    if (frames) {
+      rfirst = frames[frame].region_first;
+      rcount = frames[frame].region_count;
+      dst_off = frames[frame].dst_offset;
     }
-  }
 
-  // ---- store: every pixel exactly once -----------------------------------
-  if (y < (int) fp.height && x < (int) fp.width) {
-    uint8_t *out = dst + dst_off + (size_t) y * fp.stride + (size_t) x * 4;
-    const uint4 v = make_uint4 (pack (d[0]), pack (d[1]), pack (d[2]), pack (d[3]));
-    if (x + 4 <= (int) fp.width && ((reinterpret_cast<uintptr_t> (out) & 15) == 0)) {
-      *reinterpret_cast<uint4 *> (out) = v;
-    } else {
-      const uint32_t vv[4] = { v.x, v.y, v.z, v.w };
-      for (int k = 0; k < 4 && x + k < (int) fp.width; k++)
-        reinterpret_cast<uint32_t *> (out)[k] = vv[k];
+    const int tx0 = (int) tx * FLUTL_TILE_W, ty0 = (int) ty * FLUTL_TILE_H;
+    const int x = tx0 + (tid & 15) * 4;
+    const int y = ty0 + (tid >> 4);
+
+    Px d[4], g[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      d[k] = unpack (0);
+      g[k] = unpack (0);
+    }
+
+    // ---- cull regions: 64 at a time, one per lane, ballot -----------------
+    for (uint32_t rbase = 0; rbase < rcount; rbase += 64) {
+      uint4 rv = make_uint4 (0, 0, 0, 0);
+      bool rhit = false;
+      if (rbase + lane < rcount) {
+        rv = *reinterpret_cast<const uint4 *> (&regions[rfirst + rbase + lane]);
+        const int rx0 = (int16_t) (rv.x & 0xffffu), ry0 = (int16_t) (rv.x >> 16);
+        const int rx1 = (int16_t) (rv.y & 0xffffu), ry1 = (int16_t) (rv.y >> 16);
+        rhit = rx0 < tx0 + FLUTL_TILE_W && rx1 > tx0 &&
+            ry0 < ty0 + FLUTL_TILE_H && ry1 > ty0 && rv.w != 0;
+      }
+      unsigned long long rmask = __ballot (rhit);
+      while (rmask) {
+        const int rl = __builtin_ctzll (rmask);
+        rmask &= rmask - 1;
+        const uint32_t pfirst = (uint32_t) __builtin_amdgcn_readlane ((int) rv.z, rl);
+        const uint32_t pcount = (uint32_t) __builtin_amdgcn_readlane ((int) rv.w, rl);
+        bool in_group = false;
+
+        for (uint32_t base = 0; base < pcount; base += kChunk) {
+          // ---- bin: lane t tests prim base+t, hits are compacted (in paint
+          // order) into LDS as whole 32-byte primitives --------------------
+          const uint32_t pi = base + (uint32_t) tid;
+          bool hit = false;
+          uint4 lo = make_uint4 (0, 0, 0, 0), hi = lo;
+          if (pi < pcount) {
+            const uint4 *pp = reinterpret_cast<const uint4 *> (&prims[pfirst + pi]);
+            lo = pp[0];
+            hi = pp[1];
+            const int cx0 = (int16_t) (lo.y & 0xffffu), cy0 = (int16_t) (lo.y >> 16);
+            const int cx1 = (int16_t) (lo.z & 0xffffu), cy1 = (int16_t) (lo.z >> 16);
+            hit = cx0 < tx0 + FLUTL_TILE_W && cx1 > tx0 &&
+                cy0 < ty0 + FLUTL_TILE_H && cy1 > ty0;
+          }
+          const unsigned long long bal = __ballot (hit);
+          if (lane == 0)
+            s_cnt[wave] = (uint32_t) __popcll (bal);
+          __syncthreads ();
+          const uint32_t pos = (wave ? s_cnt[0] : 0u) +
+              (uint32_t) __popcll (bal & ((1ull << lane) - 1ull));
+          const uint32_t n_hit = s_cnt[0] + s_cnt[1];
+          if (hit) {
+            s_prim[2 * pos] = lo;
+            s_prim[2 * pos + 1] = hi;
+          }
+          __syncthreads ();
+
+          // ---- replay in paint order, fetching one primitive ahead -------
+          if (n_hit) {
+            PrimU cur = prim_from_lds (s_prim, 0);
+            Fetched fcur = prim_fetch (cur, atlas, x, y);
+            for (uint32_t i = 0; i < n_hit; i++) {
+              PrimU nxt = cur;
+              Fetched fnxt = fcur;
+              if (i + 1 < n_hit) {
+                nxt = prim_from_lds (s_prim, i + 1);
+                fnxt = prim_fetch (nxt, atlas, x, y);
+              }
+              prim_apply (cur, fcur, d, g, in_group, x, y);
+              cur = nxt;
+              fcur = fnxt;
+            }
+          }
+          __syncthreads ();  // s_prim / s_cnt are reused
+        }
+      }
+    }
+
+    // ---- store: every pixel exactly once ----------------------------------
+    if (y < (int) fp.height && x < (int) fp.width) {
+      uint8_t *out = dst + dst_off + (size_t) y * fp.stride + (size_t) x * 4;
+      const uint4 v = make_uint4 (pack (d[0]), pack (d[1]), pack (d[2]), pack (d[3]));
+      if (x + 4 <= (int) fp.width && ((reinterpret_cast<uintptr_t> (out) & 15) == 0)) {
+        *reinterpret_cast<uint4 *> (out) = v;
+      } else {
+        const uint32_t vv[4] = { v.x, v.y, v.z, v.w };
+        for (int k = 0; k < 4 && x + k < (int) fp.width; k++)
+          reinterpret_cast<uint32_t *> (out)[k] = vv[k];
+      }
     }
   }
 }
@@ -373,11 +458,28 @@ __global__ __launch_bounds__ (256) void flutl_blur_kernel_dev (
       a2 += (int32_t) ((p >> 16) & 0xff) * f;
       a3 += (int32_t) (p >> 24) * f;
     }
-  const uint32_t o0 = (uint32_t) min (max ((a0 + 0x8000) >> 16, 0), 255);
-  const uint32_t o1 = (uint32_t) min (max ((a1 + 0x8000) >> 16, 0), 255);
-  const uint32_t o2 = (uint32_t) min (max ((a2 + 0x8000) >> 16, 0), 255);
-  const uint32_t o3 = (uint32_t) min (max ((a3 + 0x8000) >> 16, 0), 255);
+  uint32_t o0 = (uint32_t) min (max ((a0 + 0x8000) >> 16, 0), 255);
+  uint32_t o1 = (uint32_t) min (max ((a1 + 0x8000) >> 16, 0), 255);
+  uint32_t o2 = (uint32_t) min (max ((a2 + 0x8000) >> 16, 0), 255);
+  uint32_t o3 = (uint32_t) min (max ((a3 + 0x8000) >> 16, 0), 255);
+  // hipcc (ROCm 7.2) fuses two of these clamps into gfx950's
+  // v_ashr_pk_u8_i32 and then ORs the other channels into the result as if
+  // its upper 16 bits were zero; on MI355X they are not (observed: R |= B).
+  // Keep the four clamps opaque so that the plain med3 form is emitted.
+  asm volatile ("" : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));
   dst[(size_t) y * stride_px + x] = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
+}
+
+// Workgroups per CU of the persistent grid (16 = the 32-wave CU limit for
+// 2-wave workgroups).  FLUTL_WG_PER_CU overrides it for tuning runs.
+uint32_t wg_per_cu ()
+{
+  static const uint32_t v = [] {
+    const char *e = getenv ("FLUTL_WG_PER_CU");
+    const long n = e ? strtol (e, nullptr, 10) : 0;
+    return (uint32_t) (n >= 1 && n <= 64 ? n : 16);
+  }();
+  return v;
 }
 
 int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst,
@@ -401,7 +503,12 @@ int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst
     return FLUTL_EINVAL;
   fp.per_xcd = (uint32_t) ((total + 7) / 8);
   fp.stride = stride;
-  hipLaunchKernelGGL (flutl_composite_kernel, dim3 (fp.per_xcd * 8), dim3 (kThreads),
+  // persistent grid: at most kWgPerCu workgroups per CU, a multiple of 8 (XCDs)
+  uint32_t grid = fp.per_xcd * 8u;
+  const uint32_t cap = 256u * wg_per_cu ();
+  if (grid > cap)
+    grid = cap;
+  hipLaunchKernelGGL (flutl_composite_kernel, dim3 (grid), dim3 (kThreads),
       0, stream, fp, static_cast<uint8_t *> (dst), frames, regions, prims, atlas);
   return hipGetLastError () == hipSuccess ? FLUTL_OK : FLUTL_ENODEV;
 }

@@ -122,10 +122,14 @@ def blur_kernel(radius, sigma):
 
 # ---- stateless launches on torch-owned device memory ----------------------
 
+def _dev_ptr(t):
+    return ctypes.c_void_p(t.data_ptr() if hasattr(t, "data_ptr") else int(t))
+
+
 def launch_frame(stream, width, height, dst, regions_dev, n_regions, prims_dev,
                  atlas_dev, stride=None):
     """dst / *_dev: torch CUDA tensors (or raw int device pointers)."""
-    p = lambda t: ctypes.c_void_p(t if isinstance(t, int) else t.data_ptr())
+    p = _dev_ptr
     _check(lib().flutl_launch_frame(ctypes.c_void_p(stream), width, height, p(dst),
                                     stride or width * 4, p(regions_dev), n_regions,
                                     p(prims_dev), p(atlas_dev)),
@@ -134,7 +138,7 @@ def launch_frame(stream, width, height, dst, regions_dev, n_regions, prims_dev,
 
 def launch_batch(stream, width, height, dst, frames_dev, n_frames, regions_dev,
                  prims_dev, atlas_dev, stride=None):
-    p = lambda t: ctypes.c_void_p(t if isinstance(t, int) else t.data_ptr())
+    p = _dev_ptr
     _check(lib().flutl_launch_batch(ctypes.c_void_p(stream), width, height, p(dst),
                                     stride or width * 4, p(frames_dev), n_frames,
                                     p(regions_dev), p(prims_dev), p(atlas_dev)),
@@ -142,7 +146,7 @@ def launch_batch(stream, width, height, dst, frames_dev, n_frames, regions_dev,
 
 
 def launch_blur(stream, src, dst, w, h, kernel_dev, radius, stride=None):
-    p = lambda t: ctypes.c_void_p(t if isinstance(t, int) else t.data_ptr())
+    p = _dev_ptr
     _check(lib().flutl_launch_blur(ctypes.c_void_p(stream), p(src), p(dst), w, h,
                                    stride or w * 4, p(kernel_dev), radius),
            "flutl_launch_blur")

@@ -130,7 +130,10 @@ def test_blur_matches_pixman_kats(gpu, kats):
                       w, h, gpu.to_dev(k), r)
         torch.cuda.synchronize()
         got = d.cpu().numpy().view(np.uint32).reshape(h, w)
-        assert np.array_equal(got, kats[f"blur{i}_out"]), i
+        exp = kats[f"blur{i}_out"]
+        bad = np.argwhere(got != exp)
+        assert len(bad) == 0, (i, r, len(bad), [(int(y), int(x), hex(got[y, x]), hex(exp[y, x]))
+                                             for y, x in bad[:6]])
 
 
 def test_blur_matches_oracle_large(gpu):
