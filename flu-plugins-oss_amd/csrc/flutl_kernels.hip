@@ -8,21 +8,23 @@
 // scan converter) -- bit exact, integer only.  No MFMA: this is byte-wise
 // blending bound by HBM stores.
 //
-// Work decomposition
-//   * one workgroup (2 wavefronts = 128 lanes) per 64x8 output tile;
-//     lane l owns the 4 horizontally adjacent pixels (16 bytes) at
-//     row l/16, column 4*(l%16): a wave stores four 256-byte row segments;
+// Work decomposition (see DESIGN.md for the measurements behind it)
+//   * the blend granule is the 64x8 output tile: a wave instruction covers a
+//     64x4 strip, lane l owning the 4 adjacent pixels (16 bytes) at column
+//     4*(l%16), row l/16, so a wave store writes four 256-byte row segments;
+//   * one workgroup (2 wavefronts) owns a 64x32 "supertile" = 4 stacked tiles:
+//     region culling and primitive binning are done once per supertile and
+//     each lane carries 4 row groups, which amortises the dependent
+//     round trips (region table -> primitives -> mask bytes) that bound a
+//     one-tile-per-workgroup kernel (v1: 41 us/4K frame, latency bound);
 //   * every output pixel is written exactly once, from registers (there is no
 //     clear pass and no read of the destination);
-//   * tiles are dealt to XCDs in contiguous bands (blocks b and b+8 share an
-//     XCD's L2), so a band's glyph masks are fetched into one L2 only;
-//   * the grid is persistent (<= 16 workgroups per CU) and grid-strides over
-//     tiles: workgroup dispatch rate would otherwise bound a 16k-tile frame;
-//   * per tile, regions are culled 64 at a time (one per lane + ballot), a
-//     region's primitives are binned by the 128 lanes in parallel (ballot +
-//     prefix popcount -> ordered, compacted 32-byte prims in LDS), then
-//     replayed in paint order with the next primitive's mask bytes already
-//     in flight.
+//   * supertiles are dealt to XCDs in contiguous bands (blocks b and b+8 share
+//     an XCD's L2), so a band's glyph masks are fetched into one L2 only;
+//   * regions are culled 64 at a time (one per lane + ballot), a region's
+//     primitives are binned by the 128 lanes in parallel (ballot + prefix
+//     popcount -> ordered, compacted 32-byte prims in LDS), then replayed in
+//     paint order with the next primitive's mask bytes already in flight.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -94,10 +96,10 @@ __device__ __forceinline__ void over (Px &d, Px s)
 }
 
 // d = (s IN m) OVER d   -- pixman over_n_8_8888 / glyph compositing
+// Branch free: m == 0 gives sm = 0 and 0 OVER d == d exactly (MUL_UN8 (x, 255)
+// == x), so lanes without coverage need no early-out.
 __device__ __forceinline__ void blend_pixman (Px &d, Px s, uint32_t m)
 {
-  if (m == 0)
-    return;
   u16x2 mm = splat (m);
   Px sm;
   sm.rb = mul_un8 (s.rb, mm);
@@ -106,14 +108,10 @@ __device__ __forceinline__ void blend_pixman (Px &d, Px s, uint32_t m)
 }
 
 // cairo in-place lerp for opaque solid sources (0x7f rounding)
+// Branch free as well: mul_7f (x, 255) == x and mul_7f (x, 0) == 0, so m == 0
+// leaves d and m == 255 yields s exactly, as cairo's special cases do.
 __device__ __forceinline__ void blend_lerp (Px &d, Px s, uint32_t m)
 {
-  if (m == 0)
-    return;
-  if (m == 255) {
-    d = s;
-    return;
-  }
   u16x2 mm = splat (m), im = splat (255u - m);
   d.rb = add_sat (mul_7f (s.rb, mm), mul_7f (d.rb, im));
   d.ag = add_sat (mul_7f (s.ag, mm), mul_7f (d.ag, im));
@@ -128,15 +126,25 @@ __device__ __forceinline__ int overlap256 (int lo, int hi, int p)
 
 struct FrameParams {
   uint32_t width, height;
-  uint32_t tiles_x, tiles_y;
+  uint32_t st_x, st_y;                  // supertiles per row / column
   uint32_t n_frames;
   uint32_t region_first, region_count;  // used when frames == nullptr
-  uint32_t per_xcd;                     // ceil(total_tiles / 8)
+  uint32_t per_xcd;                     // ceil(total_supertiles / 8)
   uint64_t stride;                      // bytes
 };
 
-// A primitive held wave-uniformly (SGPRs): read from the LDS bin list and
-// broadcast with v_readfirstlane so that all control flow on it is scalar.
+// Workgroup footprint: a 64 x 32 "supertile" = four stacked 64x8 output tiles.
+// Wave w owns rows [16w, 16w+16); lane l owns, in each of the wave's 4 row
+// groups r, the 4 pixels at column 4*(l%16), row 4*r + l/16 -- so one store
+// instruction of a wave writes four 256-byte row segments.
+constexpr int kSuperW = FLUTL_TILE_W;        // 64
+constexpr int kRG = 4;                       // row groups per wave
+constexpr int kSuperH = 2 * 4 * kRG;         // 2 waves x kRG x 4 rows
+constexpr int kWaveH = 4 * kRG;              // 16 rows per wave
+
+// A primitive held wave-uniformly in SGPRs.  The bin list in LDS holds prim
+// INDICES; the 32-byte primitive itself is fetched with scalar loads (the
+// index is wave-uniform), two primitives ahead of its use.
 struct PrimU {
   uint32_t op, rule, param;
   int cx0, cy0, cx1, cy1;
@@ -144,145 +152,74 @@ struct PrimU {
   int a, b, c, d;
 };
 
+typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
+typedef const __attribute__ ((address_space (4))) u32x4 *const_u32x4_ptr;
+
 __device__ __forceinline__ uint32_t rfl (uint32_t v)
 {
   return (uint32_t) __builtin_amdgcn_readfirstlane ((int) v);
 }
 
-__device__ __forceinline__ PrimU prim_from_lds (const uint4 *s_prim, uint32_t i)
+__device__ __forceinline__ PrimU prim_load (const flutl_prim *prims, uint32_t idx)
 {
-  const uint4 lo = s_prim[2 * i], hi = s_prim[2 * i + 1];
+  // constant address space + uniform address => s_load_dwordx4 x2
+  const_u32x4_ptr q = (const_u32x4_ptr) (uintptr_t) (prims + idx);
+  const u32x4 lo = q[0], hi = q[1];
   PrimU p;
-  const uint32_t w0 = rfl (lo.x), w1 = rfl (lo.y), w2 = rfl (lo.z);
-  p.op = w0 & 0xffu;
-  p.rule = (w0 >> 8) & 0xffu;
-  p.param = w0 >> 16;
-  p.cx0 = (int16_t) (w1 & 0xffffu);
-  p.cy0 = (int16_t) (w1 >> 16);
-  p.cx1 = (int16_t) (w2 & 0xffffu);
-  p.cy1 = (int16_t) (w2 >> 16);
-  p.color = rfl (lo.w);
-  p.a = (int) rfl (hi.x);
-  p.b = (int) rfl (hi.y);
-  p.c = (int) rfl (hi.z);
-  p.d = (int) rfl (hi.w);
+  p.op = lo.x & 0xffu;
+  p.rule = (lo.x >> 8) & 0xffu;
+  p.param = lo.x >> 16;
+  p.cx0 = (int16_t) (lo.y & 0xffffu);
+  p.cy0 = (int16_t) (lo.y >> 16);
+  p.cx1 = (int16_t) (lo.z & 0xffffu);
+  p.cy1 = (int16_t) (lo.z >> 16);
+  p.color = lo.w;
+  p.a = (int) hi.x;
+  p.b = (int) hi.y;
+  p.c = (int) hi.z;
+  p.d = (int) hi.w;
   return p;
 }
 
-// What a primitive needs from memory for this lane's 4 pixels.  Issued one
-// primitive ahead of its use so the load latency hides under the blend of the
-// previous primitive (OVER is order dependent, the loads are not).
-struct Fetched {
-  uint32_t v[4];
-};
+// Pixel state is kept packed (one a8r8g8b8 dword per pixel); blends unpack to
+// 2 x (2 x u16).
+template <bool LERP>
+__device__ __forceinline__ void px_blend (uint32_t &t, Px s, uint32_t m)
+{
+  Px v = unpack (t);
+  if (LERP)
+    blend_lerp (v, s, m);
+  else
+    blend_pixman (v, s, m);
+  t = pack (v);
+}
 
-__device__ __forceinline__ Fetched prim_fetch (const PrimU &p,
+__device__ __forceinline__ void px_over (uint32_t &t, Px s)
+{
+  Px v = unpack (t);
+  over (v, s);
+  t = pack (v);
+}
+
+// The 4 A8 coverage bytes of a MASK primitive for this lane's 4 pixels on row
+// y.  Issued one primitive ahead of use: OVER is order dependent, the loads
+// are not.
+__device__ __forceinline__ uint32_t mask_fetch (const PrimU &p,
     const uint8_t *__restrict__ atlas, int x, int y)
 {
-  Fetched f = { { 0u, 0u, 0u, 0u } };
-  const bool any = y >= p.cy0 && y < p.cy1 && x < p.cx1 && x + 4 > p.cx0;
-  if (p.op == FLUTL_OP_MASK) {
-    if (any) {
-      // 4 consecutive A8 bytes at an arbitrary byte address.  The validated
-      // list keeps this window inside the atlas allocation (16 bytes of slack
-      // on both sides); bytes outside the bbox are masked off below.
-      const uint8_t *ptr = atlas + (uint32_t) p.a +
-          (size_t) (y - p.d) * (uint32_t) p.b + (x - p.c);
-      __builtin_memcpy (&f.v[0], ptr, 4);
-    }
-  } else if (p.op == FLUTL_OP_IMAGE) {
-    if (any) {
-      const uint8_t *row = atlas + (uint32_t) p.a +
-          (size_t) (y - p.d) * (uint32_t) p.b;
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-        if (x + k >= p.cx0 && x + k < p.cx1)
-          f.v[k] = *reinterpret_cast<const uint32_t *> (
-              row + (size_t) (x + k - p.c) * 4);
-    }
+  uint32_t w = 0;
+  if (p.op == FLUTL_OP_MASK && x < p.cx1 && x + 4 > p.cx0 && y >= p.cy0 && y < p.cy1) {
+    // 4 consecutive A8 bytes at an arbitrary byte address.  The validated list
+    // keeps this window inside the atlas allocation (16 bytes of slack on both
+    // sides); bytes outside the bbox are masked off by the caller.
+    const uint32_t off = (uint32_t) p.a + (uint32_t) (y - p.d) * (uint32_t) p.b +
+        (uint32_t) (x - p.c);
+    __builtin_memcpy (&w, atlas + off, 4);
   }
-  return f;
+  return w;
 }
 
-__device__ __forceinline__ void blend4 (Px (&t)[4], const uint32_t (&cov)[4],
-    Px s, uint32_t rule)
-{
-  if (rule == FLUTL_RULE_LERP) {
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      blend_lerp (t[k], s, cov[k]);
-  } else {
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      blend_pixman (t[k], s, cov[k]);
-  }
-}
-
-__device__ __forceinline__ void prim_apply (const PrimU &p, const Fetched &f,
-    Px (&d)[4], Px (&g)[4], bool &in_group, int x, int y)
-{
-  if (p.op == FLUTL_OP_GROUP_BEGIN) {
-    in_group = true;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      g[k] = unpack (0);
-    return;
-  }
-  const bool rowin = y >= p.cy0 && y < p.cy1;
-  if (p.op == FLUTL_OP_GROUP_END) {
-    in_group = false;
-    const u16x2 al = splat (p.param);
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const bool in = rowin && x + k >= p.cx0 && x + k < p.cx1;
-      if (in && (as_u32 (g[k].rb) | as_u32 (g[k].ag)) != 0) {
-        Px s;
-        s.rb = mul_un8 (g[k].rb, al);
-        s.ag = mul_un8 (g[k].ag, al);
-        over (d[k], s);
-      }
-    }
-    return;
-  }
-  if (p.op == FLUTL_OP_IMAGE) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      // pixels outside the bbox were fetched as 0: 0 OVER d == d
-      if (f.v[k] != 0) {
-        if (in_group)
-          over (g[k], unpack (f.v[k]));
-        else
-          over (d[k], unpack (f.v[k]));
-      }
-    }
-    return;
-  }
-  // RECT / MASK: 8-bit coverage for the lane's 4 pixels
-  uint32_t cov[4];
-  if (p.op == FLUTL_OP_RECT) {
-    const int oy = rowin ? overlap256 (p.b, p.d, y) : 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const bool in = x + k >= p.cx0 && x + k < p.cx1;
-      const uint32_t area = (uint32_t) (overlap256 (p.a, p.c, x + k) * oy) >> 8;
-      cov[k] = in ? min (area, 255u) : 0u;
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const bool in = x + k >= p.cx0 && x + k < p.cx1;
-      cov[k] = in ? ((f.v[0] >> (8 * k)) & 0xffu) : 0u;
-    }
-  }
-  // wave-level early out: nothing of this prim lands in this wave's pixels
-  if (__ballot ((cov[0] | cov[1] | cov[2] | cov[3]) != 0) == 0)
-    return;
-  const Px s = unpack (p.color);
-  if (in_group)
-    blend4 (g, cov, s, p.rule);
-  else
-    blend4 (d, cov, s, p.rule);
-}
+constexpr uint32_t kListCap = 512;     // prim indices per replay round (2 KiB)
 
 __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
     FrameParams fp, uint8_t *__restrict__ dst,
@@ -290,125 +227,252 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
     const flutl_region *__restrict__ regions,
     const flutl_prim *__restrict__ prims, const uint8_t *__restrict__ atlas)
 {
-  __shared__ uint4 s_prim[kChunk * 2];   // binned prims of the current chunk
-  __shared__ uint32_t s_cnt[2];
+  __shared__ uint32_t s_list[kListCap];    // binned prim indices, paint order
+  __shared__ uint4 s_park[kThreads];       // frame pixels parked during a group
+  __shared__ uint32_t s_cnt[2][2];         // [chunk parity][wave] hit counts
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const uint32_t tiles_per_frame = fp.tiles_x * fp.tiles_y;
-  const uint32_t total = tiles_per_frame * fp.n_frames;
 
-  // Persistent grid-stride loop.  Blocks b and b+8 share an XCD (and its L2):
-  // XCD k walks the k-th contiguous band of tiles, so the glyph masks and
-  // display-list entries of a band are fetched into one L2 only.
-  const uint32_t xcd = blockIdx.x & 7u;
-  const uint32_t jstride = gridDim.x >> 3;
-  for (uint32_t j = blockIdx.x >> 3; j < fp.per_xcd; j += jstride) {
-    const uint32_t logical = xcd * fp.per_xcd + j;
-    if (logical >= total)
-      break;
-    const uint32_t frame = logical / tiles_per_frame;
-    const uint32_t tile = logical - frame * tiles_per_frame;
-    const uint32_t ty = tile / fp.tiles_x;
-    const uint32_t tx = tile - ty * fp.tiles_x;
+  // Blocks b and b+8 share an XCD (and its L2): XCD k gets the k-th contiguous
+  // band of supertiles, so the glyph masks and display-list entries of a band
+  // are fetched into one L2 only.  Speed only; any placement is correct.
+  const uint32_t st_per_frame = fp.st_x * fp.st_y;
+  const uint32_t total = st_per_frame * fp.n_frames;
+  const uint32_t logical = (blockIdx.x & 7u) * fp.per_xcd + (blockIdx.x >> 3);
+  if (logical >= total)
+    return;
+  const uint32_t frame = logical / st_per_frame;
+  const uint32_t st = logical - frame * st_per_frame;
+  const uint32_t sty = st / fp.st_x;
+  const uint32_t stx = st - sty * fp.st_x;
 
-    uint32_t rfirst = fp.region_first, rcount = fp.region_count;
-    uint64_t dst_off = 0;
-    if (frames) {
-      rfirst = frames[frame].region_first;
-      rcount = frames[frame].region_count;
-      dst_off = frames[frame].dst_offset;
-    }
+  uint32_t rfirst = fp.region_first, rcount = fp.region_count;
+  uint64_t dst_off = 0;
+  if (frames) {
+    rfirst = frames[frame].region_first;
+    rcount = frames[frame].region_count;
+    dst_off = frames[frame].dst_offset;
+  }
 
-    const int tx0 = (int) tx * FLUTL_TILE_W, ty0 = (int) ty * FLUTL_TILE_H;
-    const int x = tx0 + (tid & 15) * 4;
-    const int y = ty0 + (tid >> 4);
+  const int sx0 = (int) stx * kSuperW, sy0 = (int) sty * kSuperH;
+  const int wy0 = sy0 + wave * kWaveH;          // this wave's first row
+  const int x = sx0 + (lane & 15) * 4;
+  const int y_lane = wy0 + (lane >> 4);         // row in row group 0
 
-    Px d[4], g[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      d[k] = unpack (0);
-      g[k] = unpack (0);
-    }
+  // Binning state.  The common case bins ONCE per supertile (everything fits
+  // s_list) and replays the list for each of the wave's row groups.  Only if a
+  // supertile overlaps more primitives than s_list holds does each row group
+  // re-bin in rounds (correct, slower; pathological lists only).
+  uint32_t n_list = 0;
+  bool single_round = true, first_fill = true;
+  uint32_t parity = 0;
 
-    // ---- cull regions: 64 at a time, one per lane, ballot -----------------
-    for (uint32_t rbase = 0; rbase < rcount; rbase += 64) {
-      uint4 rv = make_uint4 (0, 0, 0, 0);
-      bool rhit = false;
-      if (rbase + lane < rcount) {
-        rv = *reinterpret_cast<const uint4 *> (&regions[rfirst + rbase + lane]);
-        const int rx0 = (int16_t) (rv.x & 0xffffu), ry0 = (int16_t) (rv.x >> 16);
-        const int rx1 = (int16_t) (rv.y & 0xffffu), ry1 = (int16_t) (rv.y >> 16);
-        rhit = rx0 < tx0 + FLUTL_TILE_W && rx1 > tx0 &&
-            ry0 < ty0 + FLUTL_TILE_H && ry1 > ty0 && rv.w != 0;
-      }
-      unsigned long long rmask = __ballot (rhit);
-      while (rmask) {
-        const int rl = __builtin_ctzll (rmask);
-        rmask &= rmask - 1;
-        const uint32_t pfirst = (uint32_t) __builtin_amdgcn_readlane ((int) rv.z, rl);
-        const uint32_t pcount = (uint32_t) __builtin_amdgcn_readlane ((int) rv.w, rl);
-        bool in_group = false;
+#pragma unroll 1
+  for (int r = 0; r < kRG; r++) {
+    const int ry0 = wy0 + 4 * r;                // scalar: rows [ry0, ry0+4)
+    const int y = y_lane + 4 * r;
+    // t = the surface being painted: the frame, or -- between GROUP_BEGIN and
+    // GROUP_END -- the region's group surface, while the frame pixels are
+    // parked in a lane-private LDS slot (no barrier: a lane reads its own).
+    uint32_t t[4] = { 0u, 0u, 0u, 0u };
 
-        for (uint32_t base = 0; base < pcount; base += kChunk) {
-          // ---- bin: lane t tests prim base+t, hits are compacted (in paint
-          // order) into LDS as whole 32-byte primitives --------------------
-          const uint32_t pi = base + (uint32_t) tid;
-          bool hit = false;
-          uint4 lo = make_uint4 (0, 0, 0, 0), hi = lo;
-          if (pi < pcount) {
-            const uint4 *pp = reinterpret_cast<const uint4 *> (&prims[pfirst + pi]);
-            lo = pp[0];
-            hi = pp[1];
-            const int cx0 = (int16_t) (lo.y & 0xffffu), cy0 = (int16_t) (lo.y >> 16);
-            const int cx1 = (int16_t) (lo.z & 0xffffu), cy1 = (int16_t) (lo.z >> 16);
-            hit = cx0 < tx0 + FLUTL_TILE_W && cx1 > tx0 &&
-                cy0 < ty0 + FLUTL_TILE_H && cy1 > ty0;
+    const bool refill = r == 0 || !single_round;
+    // cursor over (hit regions) x (128-prim chunks)
+    uint32_t rbase = 0;                  // next batch of 64 regions to cull
+    unsigned long long rmask = 0;        // hit regions of the current batch
+    uint32_t rv_first = 0, rv_count = 0; // per lane: prim range of "my" region
+    uint32_t pfirst = 0, pcount = 0, pbase = 0;
+    bool done = !refill;
+
+    do {
+      if (refill) {
+        // ======== fill: bin chunks into s_list until it could overflow ======
+        if (r != 0 || n_list != 0)
+          __syncthreads ();              // the other wave may still replay
+        n_list = 0;
+        for (;;) {
+          if (pbase >= pcount) {         // current region exhausted
+            if (rmask == 0) {            // current batch exhausted
+              if (rbase >= rcount) {
+                done = true;
+                break;
+              }
+              // cull 64 regions against the supertile, one per lane.  Lanes
+              // past the end re-read the last region and are masked out.
+              const uint32_t ridx = min (rbase + (uint32_t) lane, rcount - 1u);
+              const uint4 rv = *reinterpret_cast<const uint4 *> (&regions[rfirst + ridx]);
+              const int rx0 = (int16_t) (rv.x & 0xffffu), ry0r = (int16_t) (rv.x >> 16);
+              const int rx1 = (int16_t) (rv.y & 0xffffu), ry1r = (int16_t) (rv.y >> 16);
+              const bool rhit = rbase + lane < rcount && rx0 < sx0 + kSuperW &&
+                  rx1 > sx0 && ry0r < sy0 + kSuperH && ry1r > sy0 && rv.w != 0;
+              rmask = __ballot (rhit);
+              rv_first = rv.z;
+              rv_count = rv.w;
+              rbase += 64;
+              continue;
+            }
+            const int rl = __builtin_ctzll (rmask);
+            rmask &= rmask - 1;
+            pfirst = (uint32_t) __builtin_amdgcn_readlane ((int) rv_first, rl);
+            pcount = (uint32_t) __builtin_amdgcn_readlane ((int) rv_count, rl);
+            pbase = 0;
+            continue;
           }
+          if (n_list + kChunk > kListCap)
+            break;                       // replay what we have first
+
+          // bin: lane t tests prim pbase+t against the supertile; hits are
+          // appended, in paint order, as prim indices
+          const uint32_t pi = pbase + (uint32_t) tid;
+          const uint32_t pidx = pfirst + min (pi, pcount - 1u);
+          const uint2 bb = *reinterpret_cast<const uint2 *> (
+              reinterpret_cast<const uint8_t *> (&prims[pidx]) + 4);
+          const int cx0 = (int16_t) (bb.x & 0xffffu), cy0 = (int16_t) (bb.x >> 16);
+          const int cx1 = (int16_t) (bb.y & 0xffffu), cy1 = (int16_t) (bb.y >> 16);
+          const bool hit = pi < pcount && cx0 < sx0 + kSuperW && cx1 > sx0 &&
+              cy0 < sy0 + kSuperH && cy1 > sy0;
           const unsigned long long bal = __ballot (hit);
           if (lane == 0)
-            s_cnt[wave] = (uint32_t) __popcll (bal);
+            s_cnt[parity][wave] = (uint32_t) __popcll (bal);
           __syncthreads ();
-          const uint32_t pos = (wave ? s_cnt[0] : 0u) +
+          const uint32_t c0 = s_cnt[parity][0], c1 = s_cnt[parity][1];
+          const uint32_t pos = n_list + (wave ? c0 : 0u) +
               (uint32_t) __popcll (bal & ((1ull << lane) - 1ull));
-          const uint32_t n_hit = s_cnt[0] + s_cnt[1];
-          if (hit) {
-            s_prim[2 * pos] = lo;
-            s_prim[2 * pos + 1] = hi;
-          }
-          __syncthreads ();
+          if (hit)
+            s_list[pos] = pidx;
+          n_list += c0 + c1;
+          parity ^= 1u;
+          pbase += kChunk;
+        }
+        __syncthreads ();                // s_list complete
+        if (r == 0 && first_fill)
+          single_round = done;           // everything fitted in one round?
+        first_fill = false;
+      }
 
-          // ---- replay in paint order, fetching one primitive ahead -------
-          if (n_hit) {
-            PrimU cur = prim_from_lds (s_prim, 0);
-            Fetched fcur = prim_fetch (cur, atlas, x, y);
-            for (uint32_t i = 0; i < n_hit; i++) {
-              PrimU nxt = cur;
-              Fetched fnxt = fcur;
-              if (i + 1 < n_hit) {
-                nxt = prim_from_lds (s_prim, i + 1);
-                fnxt = prim_fetch (nxt, atlas, x, y);
+      // ======== replay s_list for row group r, in paint order ==============
+      // 3-stage software pipeline: scalar-load prim i+2 | fetch the mask
+      // bytes of prim i+1 | blend prim i.
+      if (n_list) {
+        PrimU q0 = prim_load (prims, rfl (s_list[0]));
+        PrimU q1 = prim_load (prims, rfl (s_list[min (1u, n_list - 1u)]));
+        uint32_t f0 = mask_fetch (q0, atlas, x, y);
+        for (uint32_t i = 0; i < n_list; i++) {
+          const PrimU q2 = prim_load (prims, rfl (s_list[min (i + 2u, n_list - 1u)]));
+          const uint32_t f1 = mask_fetch (q1, atlas, x, y);
+          const PrimU p = q0;
+          const uint32_t f = f0;
+          q0 = q1;
+          q1 = q2;
+          f0 = f1;
+
+          // rows of this row group untouched by the prim: scalar skip.  A
+          // group's BEGIN/END carry the same bbox, so they skip together.
+          if (p.cy1 <= ry0 || p.cy0 >= ry0 + 4)
+            continue;
+
+          if (p.op == FLUTL_OP_GROUP_BEGIN) {
+            s_park[tid] = make_uint4 (t[0], t[1], t[2], t[3]);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+              t[k] = 0;
+            continue;
+          }
+
+          const bool rowin = y >= p.cy0 && y < p.cy1;
+          // per-lane pixel predicates, as a byte mask over the 4 pixels
+          uint32_t pmask = 0;
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            pmask |= (rowin && x + k >= p.cx0 && x + k < p.cx1) ? (0xffu << (8 * k)) : 0u;
+
+          if (p.op == FLUTL_OP_RECT || p.op == FLUTL_OP_MASK) {
+            // ---- solid colour through an 8-bit coverage --------------------
+            uint32_t w = f;
+            if (p.op == FLUTL_OP_RECT) {
+              // is the whole 64x4 strip inside the rectangle's full-coverage
+              // interior?  (scalar test)
+              const bool full = ((p.a + 255) >> 8) <= sx0 && (p.c >> 8) >= sx0 + kSuperW &&
+                  p.cx0 <= sx0 && p.cx1 >= sx0 + kSuperW && ((p.b + 255) >> 8) <= ry0 &&
+                  (p.d >> 8) >= ry0 + 4 && p.cy0 <= ry0 && p.cy1 >= ry0 + 4;
+              if (full && (p.color >> 24) == 255u) {
+                // opaque, coverage 255 everywhere: d = s under both rules
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                  t[k] = p.color;
+                continue;
               }
-              prim_apply (cur, fcur, d, g, in_group, x, y);
-              cur = nxt;
-              fcur = fnxt;
+              // cairo rectangular scan converter coverage
+              const int oy = overlap256 (p.b, p.d, y);
+              w = 0;
+#pragma unroll
+              for (int k = 0; k < 4; k++)
+                w |= min ((uint32_t) (overlap256 (p.a, p.c, x + k) * oy) >> 8, 255u) << (8 * k);
+            }
+            w &= pmask;
+            // wave-level early out: nothing lands in this strip
+            if (__ballot (w != 0) == 0)
+              continue;
+            const Px s = unpack (p.color);
+            if (p.rule == FLUTL_RULE_LERP) {
+#pragma unroll
+              for (int k = 0; k < 4; k++)
+                px_blend<true> (t[k], s, (w >> (8 * k)) & 0xffu);
+            } else {
+#pragma unroll
+              for (int k = 0; k < 4; k++)
+                px_blend<false> (t[k], s, (w >> (8 * k)) & 0xffu);
+            }
+          } else {
+            // ---- per-pixel premultiplied source, OVER: IMAGE / GROUP_END ----
+            const bool is_end = p.op == FLUTL_OP_GROUP_END;
+            uint32_t sv[4] = { 0u, 0u, 0u, 0u };
+            if (is_end) {
+              // the group surface is what was painted since GROUP_BEGIN; swap
+              // the parked frame pixels back in
+              const uint4 dd = s_park[tid];
+#pragma unroll
+              for (int k = 0; k < 4; k++)
+                sv[k] = ((pmask >> (8 * k)) & 1u) ? t[k] : 0u;
+              t[0] = dd.x;
+              t[1] = dd.y;
+              t[2] = dd.z;
+              t[3] = dd.w;
+            } else if (rowin) {
+              const uint32_t rowoff = (uint32_t) p.a +
+                  (uint32_t) (y - p.d) * (uint32_t) p.b + (uint32_t) (x - p.c) * 4u;
+#pragma unroll
+              for (int k = 0; k < 4; k++)
+                if ((pmask >> (8 * k)) & 1u)
+                  sv[k] = *reinterpret_cast<const uint32_t *> (
+                      atlas + (rowoff + 4u * (uint32_t) k));
+            }
+            if (__ballot ((sv[0] | sv[1] | sv[2] | sv[3]) != 0) == 0)
+              continue;   // 0 OVER d == d
+            const u16x2 al = splat (p.param);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              Px sp = unpack (sv[k]);
+              if (is_end) {   // (group IN alpha)
+                sp.rb = mul_un8 (sp.rb, al);
+                sp.ag = mul_un8 (sp.ag, al);
+              }
+              px_over (t[k], sp);
             }
           }
-          __syncthreads ();  // s_prim / s_cnt are reused
         }
       }
-    }
+    } while (!done);
 
     // ---- store: every pixel exactly once ----------------------------------
-    if (y < (int) fp.height && x < (int) fp.width) {
+    if (x < (int) fp.width && y < (int) fp.height) {
       uint8_t *out = dst + dst_off + (size_t) y * fp.stride + (size_t) x * 4;
-      const uint4 v = make_uint4 (pack (d[0]), pack (d[1]), pack (d[2]), pack (d[3]));
       if (x + 4 <= (int) fp.width && ((reinterpret_cast<uintptr_t> (out) & 15) == 0)) {
-        *reinterpret_cast<uint4 *> (out) = v;
+        *reinterpret_cast<uint4 *> (out) = make_uint4 (t[0], t[1], t[2], t[3]);
       } else {
-        const uint32_t vv[4] = { v.x, v.y, v.z, v.w };
         for (int k = 0; k < 4 && x + k < (int) fp.width; k++)
-          reinterpret_cast<uint32_t *> (out)[k] = vv[k];
+          reinterpret_cast<uint32_t *> (out)[k] = t[k];
       }
     }
   }
@@ -470,18 +534,6 @@ __global__ __launch_bounds__ (256) void flutl_blur_kernel_dev (
   dst[(size_t) y * stride_px + x] = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
 }
 
-// Workgroups per CU of the persistent grid (16 = the 32-wave CU limit for
-// 2-wave workgroups).  FLUTL_WG_PER_CU overrides it for tuning runs.
-uint32_t wg_per_cu ()
-{
-  static const uint32_t v = [] {
-    const char *e = getenv ("FLUTL_WG_PER_CU");
-    const long n = e ? strtol (e, nullptr, 10) : 0;
-    return (uint32_t) (n >= 1 && n <= 64 ? n : 16);
-  }();
-  return v;
-}
-
 int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst,
     size_t stride, const flutl_frame_desc *frames, uint32_t n_frames,
     uint32_t region_first, uint32_t region_count, const flutl_region *regions,
@@ -493,21 +545,17 @@ int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst
   FrameParams fp;
   fp.width = width;
   fp.height = height;
-  fp.tiles_x = (width + FLUTL_TILE_W - 1) / FLUTL_TILE_W;
-  fp.tiles_y = (height + FLUTL_TILE_H - 1) / FLUTL_TILE_H;
+  fp.st_x = (width + kSuperW - 1) / kSuperW;
+  fp.st_y = (height + kSuperH - 1) / kSuperH;
   fp.n_frames = n_frames;
   fp.region_first = region_first;
   fp.region_count = region_count;
-  const uint64_t total = (uint64_t) fp.tiles_x * fp.tiles_y * n_frames;
+  const uint64_t total = (uint64_t) fp.st_x * fp.st_y * n_frames;
   if (total > 0x7fffffffull)
     return FLUTL_EINVAL;
   fp.per_xcd = (uint32_t) ((total + 7) / 8);
   fp.stride = stride;
-  // persistent grid: at most kWgPerCu workgroups per CU, a multiple of 8 (XCDs)
-  uint32_t grid = fp.per_xcd * 8u;
-  const uint32_t cap = 256u * wg_per_cu ();
-  if (grid > cap)
-    grid = cap;
+  const uint32_t grid = fp.per_xcd * 8u;   // one workgroup per supertile
   hipLaunchKernelGGL (flutl_composite_kernel, dim3 (grid), dim3 (kThreads),
       0, stream, fp, static_cast<uint8_t *> (dst), frames, regions, prims, atlas);
   return hipGetLastError () == hipSuccess ? FLUTL_OK : FLUTL_ENODEV;
