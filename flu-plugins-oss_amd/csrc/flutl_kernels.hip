@@ -380,12 +380,15 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
             continue;
           }
 
-          const bool rowin = y >= p.cy0 && y < p.cy1;
-          // per-lane pixel predicates, as a byte mask over the 4 pixels
-          uint32_t pmask = 0;
-#pragma unroll
-          for (int k = 0; k < 4; k++)
-            pmask |= (rowin && x + k >= p.cx0 && x + k < p.cx1) ? (0xffu << (8 * k)) : 0u;
+          // per-lane pixel predicates as a byte mask over the lane's 4 pixels,
+          // by unsigned range checks and shifts (VALU only: compare + s_and
+          // chains on 64-bit lane masks would load the scalar unit instead)
+          const bool rowin = (uint32_t) (y - p.cy0) < (uint32_t) (p.cy1 - p.cy0);
+          const int klo = min (max (p.cx0 - x, 0), 4);   // first pixel inside
+          const int khi = min (max (p.cx1 - x, 0), 4);   // one past the last
+          const uint32_t mlo = (uint32_t) ((1ull << (8 * klo)) - 1ull);
+          const uint32_t mhi = (uint32_t) ((1ull << (8 * khi)) - 1ull);
+          const uint32_t pmask = rowin ? (mhi & ~mlo) : 0u;
 
           if (p.op == FLUTL_OP_RECT || p.op == FLUTL_OP_MASK) {
             // ---- solid colour through an 8-bit coverage --------------------
@@ -396,11 +399,21 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
               const bool full = ((p.a + 255) >> 8) <= sx0 && (p.c >> 8) >= sx0 + kSuperW &&
                   p.cx0 <= sx0 && p.cx1 >= sx0 + kSuperW && ((p.b + 255) >> 8) <= ry0 &&
                   (p.d >> 8) >= ry0 + 4 && p.cy0 <= ry0 && p.cy1 >= ry0 + 4;
-              if (full && (p.color >> 24) == 255u) {
-                // opaque, coverage 255 everywhere: d = s under both rules
+              if (full) {
+                // coverage 255 on the whole strip: t = s OVER t with a uniform
+                // s.  Opaque s, or nothing painted yet: t = s exactly
+                // (MUL_UN8 (t, 0) == 0, MUL_UN8 (0, ia) == 0) under both rules.
+                if ((p.color >> 24) == 255u || p.rule == FLUTL_RULE_LERP ||
+                    __ballot ((t[0] | t[1] | t[2] | t[3]) != 0) == 0) {
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                  t[k] = p.color;
+                  for (int k = 0; k < 4; k++)
+                    t[k] = p.color;
+                } else {
+                  const Px sc = unpack (p.color);
+#pragma unroll
+                  for (int k = 0; k < 4; k++)
+                    px_over (t[k], sc);
+                }
                 continue;
               }
               // cairo rectangular scan converter coverage
