@@ -1,0 +1,52 @@
+#!/bin/bash
+# Builds the MI355X-native GStreamer plugin: our render element
+# (gstttmlrender_hip.c + recorder) compiled TOGETHER WITH the reference's
+# untouched base class, parser, data model, typefinder and plugin entry, which
+# are compiled from where they lie under $REF (never copied into this repo).
+# This is exactly what a maintainer gets by replacing plugins/ttml/
+# gstttmlrender.c + gstttmlblur.c with host/*.c in the reference tree.
+#
+# Output: ../lib/gstreamer-1.0/libgstfluttml.so (git-ignored; travels to the
+# GPU box as a prebuilt file).  Needs the GStreamer/Pango/Cairo dev files of
+# this image (/opt/conda) and /root/reference; otherwise keeps the prebuilt.
+set -euo pipefail
+REF=${REF:-/root/reference}
+C=${CONDA:-/opt/conda}
+HERE="$(cd "$(dirname "$0")" && pwd)"
+PKG="$(dirname "$HERE")"
+OUT="$PKG/lib/gstreamer-1.0"
+if [ ! -d "$REF/plugins/ttml" ] || [ ! -f "$C/include/gstreamer-1.0/gst/gst.h" ]; then
+  echo "build_plugin: reference tree or GStreamer dev stack absent -- keeping prebuilt $OUT" >&2
+  exit 0
+fi
+mkdir -p "$OUT"
+T="$REF/plugins/ttml"
+REF_SRCS="$T/gstfluttml.c $T/gstttmlbase.c $T/gstttmltype.c $T/gstttmlattribute.c
+ $T/gstttmlstate.c $T/gstttmlevent.c $T/gstttmlspan.c $T/gstttmlutils.c
+ $T/gstttmlnamespace.c $T/gstttmlstyle.c $T/gstttmlparse.c
+ $T/gstttmlsegmentedparse.c
+ $REF/libs/flu/downloader/lib/fludownloader.c
+ $REF/libs/flu/downloader/lib/fludownloaderhelper.c
+ $REF/libs/fluc/flu-codec-sdk/fluc/bwmeter/fluc_bwmeter.c
+ $REF/libs/fluc/flu-codec-sdk/fluc/bwmeter/fluc_bwmeter_base.c
+ $REF/libs/fluc/flu-codec-sdk/fluc/bwmeter/fluc_bwmeter_sock.c
+ $REF/libs/fluc/flu-codec-sdk/fluc/threads/fluc_barrier.c
+ $REF/libs/fluc/flu-codec-sdk/fluc/threads/fluc_monitor.c
+ $REF/libs/fluc/flu-codec-sdk/fluc/threads/fluc_mutex.c"
+OUR_SRCS="$HERE/gstttmlrender_hip.c $HERE/flutl_recorder.c $HERE/flutl_pack.c"
+INC="-I$HERE -I$PKG/../include -I$T -I$REF/libs/common -I$REF/libs/flu/downloader/lib
+ -I$REF/libs/fluc/flu-codec-sdk -I$REF/libs/fluc/flu-codec-sdk/fluc
+ -I$C/include/gstreamer-1.0 -I$C/include/glib-2.0 -I$C/lib/glib-2.0/include
+ -I$C/lib/gstreamer-1.0/include -I$C/include/libxml2 -I$C/include/pango-1.0
+ -I$C/include/cairo -I$C/include/pixman-1 -I$C/include/harfbuzz
+ -I$C/include/freetype2 -I$C/include/fribidi -I$C/include"
+DEFS="-DVERSION=\"fluttml-hip\" -DPACKAGE=\"flu-plugins-oss\" -DPACKAGE_NAME=\"flu-plugins-oss\"
+ -DBUILD_TTMLPARSE=1 -DBUILD_TTMLRENDER=1 -DFLUC_USE_THREADS=1 -D_FLUC_H_
+ -include fluc/threads/fluc_threads.h -include fluc/bwmeter/fluc_bwmeter.h"
+# shellcheck disable=SC2086
+gcc -shared -fPIC -O2 -w $DEFS $INC $REF_SRCS -Wall -Wno-deprecated-declarations $OUR_SRCS \
+  -L"$PKG/lib" -lflutl -Wl,-rpath,'$ORIGIN/..' \
+  -L$C/lib -Wl,-rpath,$C/lib -lgstreamer-1.0 -lgstbase-1.0 -lgstvideo-1.0 \
+  -lgobject-2.0 -lglib-2.0 -lxml2 -lpangocairo-1.0 -lpango-1.0 -lcairo \
+  -lcurl -lm -o "$OUT/libgstfluttml.so"
+echo "build_plugin: built $OUT/libgstfluttml.so"

@@ -1,0 +1,811 @@
+/*
+ * flutl_recorder.c -- see flutl_recorder.h.
+ *
+ * Every rule below that turns a drawing verb into a primitive restates what
+ * Cairo 1.16.0 does for the corresponding call of the reference and is pinned
+ * by tests against the real library and against frames of the reference plugin
+ * (tests/test_oracle_kats.py, tests/test_scenes_vs_reference.py):
+ *   - colour: premultiply in double, (c * 65535 + 0.5) -> 16 bit, keep the high
+ *     byte (cairo-color.c);
+ *   - path -> fixed point: round to nearest 1/256, relative segments are
+ *     converted on their own and added (cairo-path-fixed.c);
+ *   - a filled box that is not pixel aligned, and any stroke, goes through the
+ *     span renderer: opaque colours -- or ANY colour while the target surface
+ *     is still clear -- take Cairo's in-place lerp (FLUTL_RULE_LERP), all
+ *     other cases go to pixman (cairo-image-compositor.c);
+ *   - glyphs land at floor (device position + 0.5) and always go to pixman.
+ */
+#include "flutl_recorder.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ATLAS_SLACK 16u
+#define ATLAS_ALIGN 16u
+
+typedef struct
+{
+  void *font;      /* cairo_scaled_font_t *, referenced */
+  uint32_t glyph;
+  uint32_t used;
+  uint32_t offset; /* atlas offset of the tight A8 bitmap */
+  int w, h;        /* tight bitmap size; 0 x 0 = blank glyph */
+  int bx, by;      /* bitmap top-left relative to the glyph origin */
+} GlyphEntry;
+
+typedef struct
+{
+  cairo_surface_t *surface;
+  uint32_t offset;
+  int w, h;
+} ImageEntry;
+
+struct FlutlRecorder
+{
+  int width, height;
+  cairo_surface_t *scratch;   /* A8, width x height */
+  cairo_t *cr;
+
+  flutl_prim *prims;
+  uint32_t n_prims, cap_prims;
+  flutl_region *regions;
+  uint32_t n_regions, cap_regions;
+  uint32_t region_first;
+  int in_region;
+
+  uint8_t *atlas;
+  size_t atlas_size, atlas_cap;
+  uint32_t *new_off, *new_size;
+  uint32_t n_new, cap_new;
+
+  GlyphEntry *glyphs;
+  uint32_t glyph_cap, glyph_count;
+  ImageEntry *images;
+  uint32_t n_images, cap_images;
+
+  int has_clip, clip[4];      /* x0,y0,x1,y1 */
+  int in_group, group[4];
+  int frame_clear, group_clear;
+
+  double rgba[4];
+  uint32_t pixel;             /* quantised premultiplied a8r8g8b8 */
+  int color_opaque, color_clear;
+
+  uint32_t unsupported;
+};
+
+/* ---- small helpers --------------------------------------------------------- */
+
+static void *
+xrealloc (void *p, size_t n)
+{
+  void *q = realloc (p, n);
+  if (!q)
+    abort ();
+  return q;
+}
+
+static uint32_t
+atlas_put (FlutlRecorder *rec, const void *src, size_t bytes)
+{
+  size_t off = (rec->atlas_size + ATLAS_ALIGN - 1) & ~(size_t) (ATLAS_ALIGN - 1);
+  size_t end = off + bytes;
+  if (end + ATLAS_SLACK > rec->atlas_cap) {
+    size_t cap = rec->atlas_cap ? rec->atlas_cap : 1 << 16;
+    while (cap < end + ATLAS_SLACK)
+      cap *= 2;
+    rec->atlas = xrealloc (rec->atlas, cap);
+    memset (rec->atlas + rec->atlas_cap, 0, cap - rec->atlas_cap);
+    rec->atlas_cap = cap;
+  }
+  memset (rec->atlas + rec->atlas_size, 0, off - rec->atlas_size);
+  memcpy (rec->atlas + off, src, bytes);
+  rec->atlas_size = end;
+  if (rec->n_new == rec->cap_new) {
+    rec->cap_new = rec->cap_new ? rec->cap_new * 2 : 64;
+    rec->new_off = xrealloc (rec->new_off, rec->cap_new * sizeof (uint32_t));
+    rec->new_size = xrealloc (rec->new_size, rec->cap_new * sizeof (uint32_t));
+  }
+  rec->new_off[rec->n_new] = (uint32_t) off;
+  rec->new_size[rec->n_new] = (uint32_t) bytes;
+  rec->n_new++;
+  return (uint32_t) off;
+}
+
+static uint16_t
+color_double_to_short (double d)
+{
+  return (uint16_t) (d * 65535.0 + 0.5);
+}
+
+static double
+clamp01 (double v)
+{
+  return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+}
+
+static int32_t
+fixed_from_double (double d)
+{
+  /* _cairo_fixed_from_double: nearest 1/256, ties to even */
+  return (int32_t) nearbyint (d * 256.0);
+}
+
+static int
+imax (int a, int b)
+{
+  return a > b ? a : b;
+}
+
+static int
+imin (int a, int b)
+{
+  return a < b ? a : b;
+}
+
+/* Intersect a device box with clip, group surface and frame.  Returns 0 if
+ * nothing is left. */
+static int
+clip_box (FlutlRecorder *rec, int *x0, int *y0, int *x1, int *y1)
+{
+  *x0 = imax (*x0, 0);
+  *y0 = imax (*y0, 0);
+  *x1 = imin (*x1, rec->width);
+  *y1 = imin (*y1, rec->height);
+  if (rec->has_clip) {
+    *x0 = imax (*x0, rec->clip[0]);
+    *y0 = imax (*y0, rec->clip[1]);
+    *x1 = imin (*x1, rec->clip[2]);
+    *y1 = imin (*y1, rec->clip[3]);
+  }
+  if (rec->in_group) {
+    *x0 = imax (*x0, rec->group[0]);
+    *y0 = imax (*y0, rec->group[1]);
+    *x1 = imin (*x1, rec->group[2]);
+    *y1 = imin (*y1, rec->group[3]);
+  }
+  return *x1 > *x0 && *y1 > *y0;
+}
+
+static flutl_prim *
+push_prim (FlutlRecorder *rec)
+{
+  if (rec->n_prims == rec->cap_prims) {
+    rec->cap_prims = rec->cap_prims ? rec->cap_prims * 2 : 256;
+    rec->prims = xrealloc (rec->prims, rec->cap_prims * sizeof (flutl_prim));
+  }
+  flutl_prim *p = &rec->prims[rec->n_prims++];
+  memset (p, 0, sizeof *p);
+  return p;
+}
+
+static int
+target_is_clear (FlutlRecorder *rec)
+{
+  return rec->in_group ? rec->group_clear : rec->frame_clear;
+}
+
+static void
+target_touched (FlutlRecorder *rec)
+{
+  if (rec->in_group)
+    rec->group_clear = 0;
+  else
+    rec->frame_clear = 0;
+}
+
+/* ---- life cycle ------------------------------------------------------------ */
+
+FlutlRecorder *
+flutl_recorder_new (void)
+{
+  FlutlRecorder *rec = calloc (1, sizeof *rec);
+  if (!rec)
+    abort ();
+  rec->atlas_size = ATLAS_SLACK;
+  return rec;
+}
+
+static void
+drop_caches (FlutlRecorder *rec)
+{
+  for (uint32_t i = 0; i < rec->glyph_cap; i++)
+    if (rec->glyphs[i].used)
+      cairo_scaled_font_destroy (rec->glyphs[i].font);
+  free (rec->glyphs);
+  rec->glyphs = NULL;
+  rec->glyph_cap = rec->glyph_count = 0;
+  for (uint32_t i = 0; i < rec->n_images; i++)
+    cairo_surface_destroy (rec->images[i].surface);
+  rec->n_images = 0;
+  rec->atlas_size = ATLAS_SLACK;
+  if (rec->atlas)
+    memset (rec->atlas, 0, rec->atlas_cap);
+  rec->n_new = 0;
+}
+
+void
+flutl_recorder_reset (FlutlRecorder *rec)
+{
+  drop_caches (rec);
+}
+
+void
+flutl_recorder_free (FlutlRecorder *rec)
+{
+  if (!rec)
+    return;
+  drop_caches (rec);
+  if (rec->cr)
+    cairo_destroy (rec->cr);
+  if (rec->scratch)
+    cairo_surface_destroy (rec->scratch);
+  free (rec->prims);
+  free (rec->regions);
+  free (rec->atlas);
+  free (rec->new_off);
+  free (rec->new_size);
+  free (rec->images);
+  free (rec);
+}
+
+void
+flutl_recorder_begin_frame (FlutlRecorder *rec, int width, int height)
+{
+  if (!rec->scratch || rec->width != width || rec->height != height) {
+    if (rec->cr)
+      cairo_destroy (rec->cr);
+    if (rec->scratch)
+      cairo_surface_destroy (rec->scratch);
+    rec->scratch = cairo_image_surface_create (CAIRO_FORMAT_A8, width, height);
+    rec->cr = NULL;
+    rec->width = width;
+    rec->height = height;
+  }
+  if (rec->cr)
+    cairo_destroy (rec->cr);
+  rec->cr = cairo_create (rec->scratch);
+  cairo_set_source_rgba (rec->cr, 1, 1, 1, 1);
+  rec->n_prims = 0;
+  rec->n_regions = 0;
+  rec->in_region = 0;
+  rec->has_clip = 0;
+  rec->in_group = 0;
+  rec->frame_clear = 1;
+  rec->group_clear = 1;
+  rec->unsupported = 0;
+  flutl_recorder_set_color (rec, 0, 0, 0, 1);
+}
+
+cairo_t *
+flutl_recorder_cairo (FlutlRecorder *rec)
+{
+  return rec->cr;
+}
+
+/* ---- regions, groups, clip, colour ----------------------------------------- */
+
+void
+flutl_recorder_region_begin (FlutlRecorder *rec)
+{
+  rec->region_first = rec->n_prims;
+  rec->in_region = 1;
+}
+
+void
+flutl_recorder_region_end (FlutlRecorder *rec)
+{
+  uint32_t n = rec->n_prims - rec->region_first;
+  rec->in_region = 0;
+  if (n == 0)
+    return;
+  int x0 = 32767, y0 = 32767, x1 = 0, y1 = 0;
+  for (uint32_t i = rec->region_first; i < rec->n_prims; i++) {
+    const flutl_prim *p = &rec->prims[i];
+    if (p->cx1 <= p->cx0 || p->cy1 <= p->cy0)
+      continue;
+    x0 = imin (x0, p->cx0);
+    y0 = imin (y0, p->cy0);
+    x1 = imax (x1, p->cx1);
+    y1 = imax (y1, p->cy1);
+  }
+  if (x1 <= x0 || y1 <= y0) {   /* nothing visible */
+    rec->n_prims = rec->region_first;
+    return;
+  }
+  /* empty-bbox prims (group markers of an off-frame region) must still lie
+   * inside the region box */
+  for (uint32_t i = rec->region_first; i < rec->n_prims; i++) {
+    flutl_prim *p = &rec->prims[i];
+    if (p->cx1 <= p->cx0 || p->cy1 <= p->cy0) {
+      p->cx0 = p->cx1 = (int16_t) x0;
+      p->cy0 = p->cy1 = (int16_t) y0;
+    }
+  }
+  if (rec->n_regions == rec->cap_regions) {
+    rec->cap_regions = rec->cap_regions ? rec->cap_regions * 2 : 32;
+    rec->regions = xrealloc (rec->regions, rec->cap_regions * sizeof (flutl_region));
+  }
+  flutl_region *r = &rec->regions[rec->n_regions++];
+  r->x0 = (int16_t) x0;
+  r->y0 = (int16_t) y0;
+  r->x1 = (int16_t) x1;
+  r->y1 = (int16_t) y1;
+  r->first = rec->region_first;
+  r->count = n;
+}
+
+void
+flutl_recorder_group_begin (FlutlRecorder *rec, int x, int y, int w, int h)
+{
+  rec->group[0] = x;
+  rec->group[1] = y;
+  rec->group[2] = x + imax (w, 0);
+  rec->group[3] = y + imax (h, 0);
+  int x0 = x, y0 = y, x1 = rec->group[2], y1 = rec->group[3];
+  /* the group marker itself is not subject to the region clip */
+  int saved = rec->has_clip;
+  rec->has_clip = 0;
+  rec->in_group = 0;
+  if (!clip_box (rec, &x0, &y0, &x1, &y1))
+    x0 = y0 = x1 = y1 = 0;
+  rec->has_clip = saved;
+  flutl_prim *p = push_prim (rec);
+  p->op = FLUTL_OP_GROUP_BEGIN;
+  p->cx0 = (int16_t) x0;
+  p->cy0 = (int16_t) y0;
+  p->cx1 = (int16_t) x1;
+  p->cy1 = (int16_t) y1;
+  rec->in_group = 1;
+  rec->group_clear = 1;
+}
+
+void
+flutl_recorder_group_end (FlutlRecorder *rec, double opacity)
+{
+  int x0 = rec->group[0], y0 = rec->group[1], x1 = rec->group[2], y1 = rec->group[3];
+  int saved = rec->has_clip;
+  rec->has_clip = 0;
+  rec->in_group = 0;
+  if (!clip_box (rec, &x0, &y0, &x1, &y1))
+    x0 = y0 = x1 = y1 = 0;
+  rec->has_clip = saved;
+  flutl_prim *p = push_prim (rec);
+  p->op = FLUTL_OP_GROUP_END;
+  /* solid mask pattern of cairo_paint_with_alpha: alpha_short >> 8 */
+  p->param = (uint16_t) (color_double_to_short (clamp01 (opacity)) >> 8);
+  p->cx0 = (int16_t) x0;
+  p->cy0 = (int16_t) y0;
+  p->cx1 = (int16_t) x1;
+  p->cy1 = (int16_t) y1;
+  rec->frame_clear = 0;
+}
+
+void
+flutl_recorder_clip (FlutlRecorder *rec, int x, int y, int w, int h)
+{
+  int c[4] = { x, y, x + imax (w, 0), y + imax (h, 0) };
+  if (rec->has_clip) {
+    c[0] = imax (c[0], rec->clip[0]);
+    c[1] = imax (c[1], rec->clip[1]);
+    c[2] = imin (c[2], rec->clip[2]);
+    c[3] = imin (c[3], rec->clip[3]);
+  }
+  memcpy (rec->clip, c, sizeof c);
+  rec->has_clip = 1;
+}
+
+void
+flutl_recorder_clip_reset (FlutlRecorder *rec)
+{
+  rec->has_clip = 0;
+}
+
+void
+flutl_recorder_set_color (FlutlRecorder *rec, double r, double g, double b, double a)
+{
+  r = clamp01 (r);
+  g = clamp01 (g);
+  b = clamp01 (b);
+  a = clamp01 (a);
+  rec->rgba[0] = r;
+  rec->rgba[1] = g;
+  rec->rgba[2] = b;
+  rec->rgba[3] = a;
+  uint16_t as = color_double_to_short (a);
+  uint16_t rs = color_double_to_short (r * a);
+  uint16_t gs = color_double_to_short (g * a);
+  uint16_t bs = color_double_to_short (b * a);
+  rec->pixel = ((uint32_t) (as >> 8) << 24) | ((uint32_t) (rs >> 8) << 16) |
+      ((uint32_t) (gs >> 8) << 8) | (uint32_t) (bs >> 8);
+  rec->color_opaque = as >= 0xff00;   /* CAIRO_COLOR_IS_OPAQUE */
+  rec->color_clear = as <= 0x00ff;    /* CAIRO_COLOR_IS_CLEAR  */
+}
+
+void
+flutl_recorder_get_color (FlutlRecorder *rec, double rgba[4])
+{
+  memcpy (rgba, rec->rgba, sizeof rec->rgba);
+}
+
+/* ---- rectangles ------------------------------------------------------------ */
+
+static int
+ctm_is_translation (cairo_t *cr, cairo_matrix_t *m)
+{
+  cairo_get_matrix (cr, m);
+  return m->xx == 1.0 && m->yy == 1.0 && m->xy == 0.0 && m->yx == 0.0;
+}
+
+void
+flutl_recorder_fill_rect (FlutlRecorder *rec, double x, double y, double w, double h)
+{
+  cairo_matrix_t m;
+  if (!ctm_is_translation (rec->cr, &m)) {
+    rec->unsupported++;   /* rotated writing modes: not implemented yet */
+    return;
+  }
+  if (rec->color_clear)
+    return;               /* OVER with a clear source is a no-op in cairo */
+  /* cairo_rectangle: move_to (x, y) then relative segments */
+  double dx = x, dy = y;
+  cairo_matrix_transform_point (&m, &dx, &dy);
+  int32_t fx1 = fixed_from_double (dx), fy1 = fixed_from_double (dy);
+  int32_t fx2 = fx1 + fixed_from_double (w), fy2 = fy1 + fixed_from_double (h);
+  if (fx2 < fx1) { int32_t t = fx1; fx1 = fx2; fx2 = t; }
+  if (fy2 < fy1) { int32_t t = fy1; fy1 = fy2; fy2 = t; }
+  if (fx1 == fx2 || fy1 == fy2)
+    return;
+  int x0 = fx1 >> 8, y0 = fy1 >> 8, x1 = (fx2 + 255) >> 8, y1 = (fy2 + 255) >> 8;
+  if (!clip_box (rec, &x0, &y0, &x1, &y1))
+    return;
+  int aligned = ((fx1 | fy1 | fx2 | fy2) & 255) == 0;
+  flutl_prim *p = push_prim (rec);
+  p->op = FLUTL_OP_RECT;
+  p->rule = (!aligned && (rec->color_opaque || target_is_clear (rec)))
+      ? FLUTL_RULE_LERP : FLUTL_RULE_PIXMAN;
+  p->cx0 = (int16_t) x0;
+  p->cy0 = (int16_t) y0;
+  p->cx1 = (int16_t) x1;
+  p->cy1 = (int16_t) y1;
+  p->color = rec->pixel;
+  p->a = fx1;
+  p->b = fy1;
+  p->c = fx2;
+  p->d = fy2;
+  target_touched (rec);
+}
+
+/* ---- glyphs ---------------------------------------------------------------- */
+
+static uint32_t
+glyph_hash (const void *font, uint32_t glyph)
+{
+  uint64_t h = (uint64_t) (uintptr_t) font * 0x9E3779B97F4A7C15ull;
+  h ^= (uint64_t) glyph * 0xC2B2AE3D27D4EB4Full;
+  return (uint32_t) (h >> 32);
+}
+
+static GlyphEntry *glyph_lookup (FlutlRecorder *rec, cairo_scaled_font_t *sf,
+    uint32_t glyph);
+
+static void
+glyph_grow (FlutlRecorder *rec)
+{
+  uint32_t old_cap = rec->glyph_cap;
+  GlyphEntry *old = rec->glyphs;
+  rec->glyph_cap = old_cap ? old_cap * 2 : 256;
+  rec->glyphs = calloc (rec->glyph_cap, sizeof (GlyphEntry));
+  if (!rec->glyphs)
+    abort ();
+  for (uint32_t i = 0; i < old_cap; i++) {
+    if (!old[i].used)
+      continue;
+    uint32_t j = glyph_hash (old[i].font, old[i].glyph) & (rec->glyph_cap - 1);
+    while (rec->glyphs[j].used)
+      j = (j + 1) & (rec->glyph_cap - 1);
+    rec->glyphs[j] = old[i];
+  }
+  free (old);
+}
+
+/* Rasterise one glyph exactly as the image backend will see it: through the
+ * scaled font's own glyph cache, at an integer origin, onto a cleared A8
+ * surface with an opaque white source (result byte == mask byte). */
+static void
+glyph_rasterise (FlutlRecorder *rec, cairo_scaled_font_t *sf, GlyphEntry *e)
+{
+  cairo_glyph_t g = { e->glyph, 0, 0 };
+  cairo_text_extents_t ext;
+  cairo_scaled_font_glyph_extents (sf, &g, 1, &ext);
+  e->w = e->h = 0;
+  if (!(ext.width > 0) || !(ext.height > 0))
+    return;
+  int x0 = (int) floor (ext.x_bearing) - 2, y0 = (int) floor (ext.y_bearing) - 2;
+  int w = (int) ceil (ext.width) + 6, h = (int) ceil (ext.height) + 6;
+  cairo_surface_t *s = cairo_image_surface_create (CAIRO_FORMAT_A8, w, h);
+  cairo_t *cr = cairo_create (s);
+  cairo_set_scaled_font (cr, sf);
+  cairo_set_source_rgba (cr, 1, 1, 1, 1);
+  g.x = -x0;
+  g.y = -y0;
+  cairo_show_glyphs (cr, &g, 1);
+  cairo_destroy (cr);
+  cairo_surface_flush (s);
+  const uint8_t *data = cairo_image_surface_get_data (s);
+  int stride = cairo_image_surface_get_stride (s);
+  int tx0 = w, ty0 = h, tx1 = -1, ty1 = -1;
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++)
+      if (data[y * stride + x]) {
+        if (x < tx0) tx0 = x;
+        if (x > tx1) tx1 = x;
+        if (y < ty0) ty0 = y;
+        if (y > ty1) ty1 = y;
+      }
+  if (tx1 >= tx0) {
+    int tw = tx1 - tx0 + 1, th = ty1 - ty0 + 1;
+    uint8_t *tight = malloc ((size_t) tw * th);
+    if (!tight)
+      abort ();
+    for (int y = 0; y < th; y++)
+      memcpy (tight + (size_t) y * tw, data + (size_t) (ty0 + y) * stride + tx0, tw);
+    e->offset = atlas_put (rec, tight, (size_t) tw * th);
+    free (tight);
+    e->w = tw;
+    e->h = th;
+    e->bx = x0 + tx0;
+    e->by = y0 + ty0;
+  }
+  cairo_surface_destroy (s);
+}
+
+static GlyphEntry *
+glyph_lookup (FlutlRecorder *rec, cairo_scaled_font_t *sf, uint32_t glyph)
+{
+  if (rec->glyph_count * 2 >= rec->glyph_cap)
+    glyph_grow (rec);
+  uint32_t j = glyph_hash (sf, glyph) & (rec->glyph_cap - 1);
+  while (rec->glyphs[j].used) {
+    if (rec->glyphs[j].font == sf && rec->glyphs[j].glyph == glyph)
+      return &rec->glyphs[j];
+    j = (j + 1) & (rec->glyph_cap - 1);
+  }
+  GlyphEntry *e = &rec->glyphs[j];
+  e->used = 1;
+  e->font = cairo_scaled_font_reference (sf);
+  e->glyph = glyph;
+  rec->glyph_count++;
+  glyph_rasterise (rec, sf, e);
+  return e;
+}
+
+void
+flutl_recorder_show_glyph (FlutlRecorder *rec, PangoFont *font,
+    const PangoGlyphInfo *gi)
+{
+  cairo_matrix_t m;
+  if (gi->glyph == PANGO_GLYPH_EMPTY)
+    return;
+  if (gi->glyph & PANGO_GLYPH_UNKNOWN_FLAG) {
+    rec->unsupported++;   /* hex-box rendering of unknown glyphs */
+    return;
+  }
+  if (!ctm_is_translation (rec->cr, &m)) {
+    rec->unsupported++;   /* sheared / rotated glyphs: not implemented yet */
+    return;
+  }
+  if (rec->color_clear)
+    return;
+  cairo_scaled_font_t *sf =
+      pango_cairo_font_get_scaled_font ((PangoCairoFont *) font);
+  if (!sf)
+    return;
+  /* pango_cairo_renderer: position = current point (none -> 0,0) + offsets;
+   * cairo then adds the CTM translation and rounds half up (_cairo_lround). */
+  double cx = (double) gi->geometry.x_offset / PANGO_SCALE;
+  double cy = gi->geometry.y_offset == 0
+      ? 0.0 : (double) gi->geometry.y_offset / PANGO_SCALE;
+  int ix = (int) floor (cx + m.x0 + 0.5), iy = (int) floor (cy + m.y0 + 0.5);
+  GlyphEntry *e = glyph_lookup (rec, sf, gi->glyph);
+  target_touched (rec);
+  if (e->w == 0)
+    return;
+  int ox = ix + e->bx, oy = iy + e->by;
+  int x0 = ox, y0 = oy, x1 = ox + e->w, y1 = oy + e->h;
+  if (!clip_box (rec, &x0, &y0, &x1, &y1))
+    return;
+  flutl_prim *p = push_prim (rec);
+  p->op = FLUTL_OP_MASK;
+  p->rule = FLUTL_RULE_PIXMAN;
+  p->cx0 = (int16_t) x0;
+  p->cy0 = (int16_t) y0;
+  p->cx1 = (int16_t) x1;
+  p->cy1 = (int16_t) y1;
+  p->color = rec->pixel;
+  p->a = (int32_t) e->offset;
+  p->b = e->w;
+  p->c = ox;
+  p->d = oy;
+}
+
+/* ---- strokes --------------------------------------------------------------- */
+
+void
+flutl_recorder_stroke (FlutlRecorder *rec)
+{
+  cairo_t *cr = rec->cr;
+  double ex1, ey1, ex2, ey2;
+  cairo_stroke_extents (cr, &ex1, &ey1, &ex2, &ey2);
+  cairo_user_to_device (cr, &ex1, &ey1);
+  cairo_user_to_device (cr, &ex2, &ey2);
+  if (ex2 < ex1) { double t = ex1; ex1 = ex2; ex2 = t; }
+  if (ey2 < ey1) { double t = ey1; ey1 = ey2; ey2 = t; }
+  int bx0 = imax ((int) floor (ex1) - 2, 0), by0 = imax ((int) floor (ey1) - 2, 0);
+  int bx1 = imin ((int) ceil (ex2) + 2, rec->width);
+  int by1 = imin ((int) ceil (ey2) + 2, rec->height);
+  if (rec->color_clear || bx1 <= bx0 || by1 <= by0) {
+    cairo_new_path (cr);
+    return;
+  }
+  /* coverage = what the stroker + scan converter hand to the span renderer */
+  cairo_save (cr);
+  cairo_set_source_rgba (cr, 1, 1, 1, 1);
+  cairo_stroke (cr);
+  cairo_restore (cr);
+  cairo_surface_flush (rec->scratch);
+  uint8_t *data = cairo_image_surface_get_data (rec->scratch);
+  int stride = cairo_image_surface_get_stride (rec->scratch);
+  int tx0 = bx1, ty0 = by1, tx1 = -1, ty1 = -1;
+  for (int y = by0; y < by1; y++) {
+    const uint8_t *row = data + (size_t) y * stride;
+    for (int x = bx0; x < bx1; x++)
+      if (row[x]) {
+        if (x < tx0) tx0 = x;
+        if (x > tx1) tx1 = x;
+        if (y < ty0) ty0 = y;
+        if (y > ty1) ty1 = y;
+      }
+  }
+  if (tx1 < tx0)
+    return;
+  int x0 = tx0, y0 = ty0, x1 = tx1 + 1, y1 = ty1 + 1;
+  int visible = clip_box (rec, &x0, &y0, &x1, &y1);
+  if (visible) {
+    int w = x1 - x0, h = y1 - y0;
+    uint8_t *tight = malloc ((size_t) w * h);
+    if (!tight)
+      abort ();
+    for (int y = 0; y < h; y++)
+      memcpy (tight + (size_t) y * w, data + (size_t) (y0 + y) * stride + x0, w);
+    uint32_t off = atlas_put (rec, tight, (size_t) w * h);
+    free (tight);
+    flutl_prim *p = push_prim (rec);
+    p->op = FLUTL_OP_MASK;
+    p->rule = (rec->color_opaque || target_is_clear (rec))
+        ? FLUTL_RULE_LERP : FLUTL_RULE_PIXMAN;
+    p->cx0 = (int16_t) x0;
+    p->cy0 = (int16_t) y0;
+    p->cx1 = (int16_t) x1;
+    p->cy1 = (int16_t) y1;
+    p->color = rec->pixel;
+    p->a = (int32_t) off;
+    p->b = w;
+    p->c = x0;
+    p->d = y0;
+  }
+  target_touched (rec);
+  /* clear what the stroke left in the scratch surface */
+  for (int y = ty0; y <= ty1; y++)
+    memset (data + (size_t) y * stride + tx0, 0, (size_t) (tx1 - tx0 + 1));
+  cairo_surface_mark_dirty_rectangle (rec->scratch, tx0, ty0, tx1 - tx0 + 1,
+      ty1 - ty0 + 1);
+}
+
+/* ---- images ---------------------------------------------------------------- */
+
+void
+flutl_recorder_paint_image (FlutlRecorder *rec, cairo_surface_t *img, int x, int y)
+{
+  if (cairo_surface_get_type (img) != CAIRO_SURFACE_TYPE_IMAGE) {
+    rec->unsupported++;
+    return;
+  }
+  cairo_format_t fmt = cairo_image_surface_get_format (img);
+  if (fmt != CAIRO_FORMAT_ARGB32 && fmt != CAIRO_FORMAT_RGB24) {
+    rec->unsupported++;
+    return;
+  }
+  ImageEntry *e = NULL;
+  for (uint32_t i = 0; i < rec->n_images; i++)
+    if (rec->images[i].surface == img)
+      e = &rec->images[i];
+  if (!e) {
+    int w = cairo_image_surface_get_width (img);
+    int h = cairo_image_surface_get_height (img);
+    int stride = cairo_image_surface_get_stride (img);
+    cairo_surface_flush (img);
+    const uint8_t *data = cairo_image_surface_get_data (img);
+    uint32_t *tight = malloc ((size_t) w * h * 4);
+    if (!tight)
+      abort ();
+    for (int r = 0; r < h; r++) {
+      memcpy (tight + (size_t) r * w, data + (size_t) r * stride, (size_t) w * 4);
+      if (fmt == CAIRO_FORMAT_RGB24)
+        for (int c = 0; c < w; c++)
+          tight[(size_t) r * w + c] |= 0xff000000u;
+    }
+    if (rec->n_images == rec->cap_images) {
+      rec->cap_images = rec->cap_images ? rec->cap_images * 2 : 8;
+      rec->images = xrealloc (rec->images, rec->cap_images * sizeof (ImageEntry));
+    }
+    e = &rec->images[rec->n_images++];
+    e->surface = cairo_surface_reference (img);
+    e->w = w;
+    e->h = h;
+    e->offset = atlas_put (rec, tight, (size_t) w * h * 4);
+    free (tight);
+  }
+  target_touched (rec);
+  int x0 = x, y0 = y, x1 = x + e->w, y1 = y + e->h;
+  if (!clip_box (rec, &x0, &y0, &x1, &y1))
+    return;
+  flutl_prim *p = push_prim (rec);
+  p->op = FLUTL_OP_IMAGE;
+  p->cx0 = (int16_t) x0;
+  p->cy0 = (int16_t) y0;
+  p->cx1 = (int16_t) x1;
+  p->cy1 = (int16_t) y1;
+  p->a = (int32_t) e->offset;
+  p->b = e->w * 4;
+  p->c = x;
+  p->d = y;
+}
+
+/* ---- results ---------------------------------------------------------------- */
+
+const flutl_region *
+flutl_recorder_regions (FlutlRecorder *rec, uint32_t *n)
+{
+  *n = rec->n_regions;
+  return rec->regions;
+}
+
+const flutl_prim *
+flutl_recorder_prims (FlutlRecorder *rec, uint32_t *n)
+{
+  *n = rec->n_prims;
+  return rec->prims;
+}
+
+const uint8_t *
+flutl_recorder_atlas (FlutlRecorder *rec, size_t *size)
+{
+  /* [0, atlas_size) is data, followed by ATLAS_SLACK readable zero bytes */
+  size_t need = rec->atlas_size + ATLAS_SLACK;
+  if (need > rec->atlas_cap) {
+    rec->atlas = xrealloc (rec->atlas, need);
+    memset (rec->atlas + rec->atlas_cap, 0, need - rec->atlas_cap);
+    rec->atlas_cap = need;
+  }
+  *size = need;
+  return rec->atlas;
+}
+
+uint32_t
+flutl_recorder_new_atlas_entries (FlutlRecorder *rec, const uint32_t **offsets,
+    const uint32_t **sizes)
+{
+  uint32_t n = rec->n_new;
+  *offsets = rec->new_off;
+  *sizes = rec->new_size;
+  rec->n_new = 0;
+  return n;
+}
+
+uint32_t
+flutl_recorder_unsupported (FlutlRecorder *rec)
+{
+  return rec->unsupported;
+}

@@ -1,0 +1,89 @@
+/*
+ * flutl_recorder.h -- host-side display-list recorder of the fluttml-hip
+ * render element.
+ *
+ * The reference draws every primitive straight into a Cairo image surface
+ * (plugins/ttml/gstttmlrender.c:1235-1385 show_regions, :941-1176 show_layout,
+ * :1180-1232 render_outline).  This recorder offers the same small set of
+ * drawing verbs, but RECORDS them as flutl_prim entries (include/flutl.h) with
+ * the clip, the group surface bounds, the colour quantisation and the blend
+ * rule already resolved, so that the device kernel only does pixel arithmetic.
+ *
+ * Cairo is used here for two things only, never for pixels of the frame:
+ *   - a scratch A8 surface + cairo_t that tracks the CTM with Cairo's own
+ *     matrix arithmetic and accumulates outline paths;
+ *   - rasterising A8 masks (glyphs through the scaled-font glyph cache,
+ *     strokes through the stroker + scan converter) into the atlas.
+ */
+#ifndef FLUTL_RECORDER_H
+#define FLUTL_RECORDER_H
+
+#include <cairo.h>
+#include <pango/pangocairo.h>
+#include <stdint.h>
+#include "flutl.h"
+
+typedef struct FlutlRecorder FlutlRecorder;
+
+FlutlRecorder *flutl_recorder_new (void);
+void flutl_recorder_free (FlutlRecorder *rec);
+
+/* Drop the atlas and the glyph cache (gst_ttmlrender_reset, :1610-1621). */
+void flutl_recorder_reset (FlutlRecorder *rec);
+
+/* Start a new frame of width x height; keeps atlas + glyph cache. */
+void flutl_recorder_begin_frame (FlutlRecorder *rec, int width, int height);
+
+/* The tracking context: callers issue cairo_save/translate/restore and path
+ * calls on it exactly as the reference does on render->cairo. */
+cairo_t *flutl_recorder_cairo (FlutlRecorder *rec);
+
+/* One TTML region == one binning group of the display list. */
+void flutl_recorder_region_begin (FlutlRecorder *rec);
+void flutl_recorder_region_end (FlutlRecorder *rec);
+
+/* Opacity group = the temporary region surface of :1250-1256 / :1375-1382.
+ * Primitives recorded in between are also clipped to the surface bounds. */
+void flutl_recorder_group_begin (FlutlRecorder *rec, int x, int y, int w, int h);
+void flutl_recorder_group_end (FlutlRecorder *rec, double opacity);
+
+/* cairo_rectangle + cairo_clip with integer device coordinates (:1279-1284);
+ * intersects with the current clip, like cairo_clip.  clip_reset drops it
+ * (cairo_restore at the end of show_regions). */
+void flutl_recorder_clip (FlutlRecorder *rec, int x, int y, int w, int h);
+void flutl_recorder_clip_reset (FlutlRecorder *rec);
+
+/* cairo_set_source_rgba. */
+void flutl_recorder_set_color (FlutlRecorder *rec, double r, double g, double b,
+    double a);
+void flutl_recorder_get_color (FlutlRecorder *rec, double rgba[4]);
+
+/* cairo_rectangle (x, y, w, h) + cairo_fill under the tracking context's CTM. */
+void flutl_recorder_fill_rect (FlutlRecorder *rec, double x, double y, double w,
+    double h);
+
+/* pango_cairo_show_glyph_string for ONE glyph at the CTM origin (:1149-1151). */
+void flutl_recorder_show_glyph (FlutlRecorder *rec, PangoFont *font,
+    const PangoGlyphInfo *gi);
+
+/* cairo_stroke of the tracking context's current path with its line width
+ * (:1212, and the intermediate strokes of show_layout in path mode). */
+void flutl_recorder_stroke (FlutlRecorder *rec);
+
+/* cairo_set_source_surface (img, x, y) + cairo_paint (:1271-1276). */
+void flutl_recorder_paint_image (FlutlRecorder *rec, cairo_surface_t *img, int x,
+    int y);
+
+/* ---- results of the frame -------------------------------------------------*/
+const flutl_region *flutl_recorder_regions (FlutlRecorder *rec, uint32_t *n);
+const flutl_prim *flutl_recorder_prims (FlutlRecorder *rec, uint32_t *n);
+/* host copy of the atlas: bytes [0, size), incl. the 16-byte leading slack */
+const uint8_t *flutl_recorder_atlas (FlutlRecorder *rec, size_t *size);
+/* atlas entries appended since the last call (for incremental upload);
+ * returns the number of entries; entry i spans [offsets[i], offsets[i]+sizes[i]) */
+uint32_t flutl_recorder_new_atlas_entries (FlutlRecorder *rec,
+    const uint32_t **offsets, const uint32_t **sizes);
+/* number of primitives dropped because a feature is not implemented yet */
+uint32_t flutl_recorder_unsupported (FlutlRecorder *rec);
+
+#endif /* FLUTL_RECORDER_H */

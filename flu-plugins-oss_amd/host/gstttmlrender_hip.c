@@ -1,0 +1,1201 @@
+/*
+ * gstttmlrender_hip.c -- MI355X-native `ttmlrender` element.
+ *
+ * Drop-in replacement for the reference's plugins/ttml/gstttmlrender.c +
+ * gstttmlblur.c: it provides the same GType (gst_ttmlrender_get_type, declared
+ * by the reference's own gstttmlrender.h, which plugins/ttml/gstfluttml.c:57-60
+ * registers as element "ttmlrender"), the same pad template, properties and
+ * GstTTMLBaseClass vfuncs (plugins/ttml/gstttmlbase.h:71-98), and is compiled
+ * together with the reference's UNTOUCHED base class / parser / data model.
+ *
+ * What differs is how a buffer is produced (gen_buffer, reference
+ * gstttmlrender.c:1427-1478): the layout work that is inherently host side
+ * (Pango markup -> PangoLayout -> glyph runs) stays here, but nothing is drawn
+ * on the host.  Every drawing call of the reference is RECORDED as a display
+ * list (flutl_recorder.c) and the frame is composited by the HIP kernel behind
+ * the C-ABI of include/flutl.h.  There is no CPU rendering fallback: if the
+ * HIP library cannot render, gen_buffer returns NULL (the base class's error
+ * convention, gstttmlbase.c:161-163) after logging an error.
+ *
+ * Reference behaviours that affect pixels are reproduced on purpose, including
+ * the odd ones; each is marked "reference:" below.
+ *
+ * Not implemented yet (counted and logged, never silently approximated):
+ * vertical writing modes (tbrl/tblr), anamorphic font sizes, reverseOblique,
+ * blurred outlines.
+ */
+#ifdef HAVE_CONFIG_H
+#include "config.h"
+#endif
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <gst/gst.h>
+#include <pango/pangocairo.h>
+
+#include "gstttmlbase.h"
+#include "gstttmlrender.h"
+#include "gstttmlstate.h"
+#include "gstttmlspan.h"
+#include "gstttmlstyle.h"
+#include "gstttmlattribute.h"
+#include "gstttmlutils.h"
+
+#include "flutl.h"
+#include "flutl_recorder.h"
+#include "flutl_pack.h"
+
+GST_DEBUG_CATEGORY_EXTERN (ttmlrender_debug);
+#define GST_CAT_DEFAULT ttmlrender_debug
+
+#define DEFAULT_WINDOW_WIDTH 720
+#define DEFAULT_WINDOW_HEIGHT 576
+
+enum
+{
+  PROP_0,
+  PROP_DEFAULT_FONT_FAMILY,
+  PROP_DEFAULT_FONT_SIZE,
+  PROP_DEFAULT_TEXT_ALIGN,
+  PROP_DEFAULT_DISPLAY_ALIGN,
+  PROP_WINDOW_WIDTH,
+  PROP_WINDOW_HEIGHT
+};
+
+/* Device-side state of one element instance. */
+typedef struct
+{
+  FlutlRecorder *rec;
+  flutl_ctx *ctx;            /* NULL until first use; stays NULL without a GPU */
+  gboolean ctx_failed;
+  FlutlPackWriter *dump;     /* FLUTL_DUMP_PACK=<file>: scene-pack dump */
+  gboolean dump_only;        /* FLUTL_DUMP_ONLY=1: record, do not render */
+  GHashTable *images;        /* id -> cairo_surface_t (decoded PNGs) */
+} GstTTMLRenderPrivate;
+
+static GstStaticPadTemplate ttmlrender_src_template =
+    GST_STATIC_PAD_TEMPLATE ("src", GST_PAD_SRC, GST_PAD_ALWAYS,
+        GST_STATIC_CAPS ("video/x-raw, format=BGRA, width=(int)[1,MAX], "
+            "height=(int)[1,MAX], framerate=(fraction)0/1, "
+            "pixel-aspect-ratio=(fraction)[0/1, MAX]"));
+
+G_DEFINE_TYPE_WITH_PRIVATE (GstTTMLRender, gst_ttmlrender, GST_TYPE_TTMLBASE);
+
+static inline GstTTMLRenderPrivate *
+get_priv (GstTTMLRender *render)
+{
+  return gst_ttmlrender_get_instance_private (render);
+}
+
+/* ---- styling that Pango markup cannot express ------------------------------
+ * Carried through Pango as integer attributes of four private types. */
+typedef enum
+{
+  HIP_ATTR_OVERLINE,
+  HIP_ATTR_INVISIBLE,
+  HIP_ATTR_REVERSE,
+  HIP_ATTR_REVERSE_OBLIQUE,
+  HIP_ATTR_LAST
+} HipAttrKind;
+
+static PangoAttribute *hip_attr_copy (const PangoAttribute *attr);
+static void hip_attr_destroy (PangoAttribute *attr);
+static gboolean hip_attr_equal (const PangoAttribute *a, const PangoAttribute *b);
+
+static PangoAttrClass hip_attr_klass[HIP_ATTR_LAST] = {
+  { PANGO_ATTR_INVALID, hip_attr_copy, hip_attr_destroy, hip_attr_equal },
+  { PANGO_ATTR_INVALID, hip_attr_copy, hip_attr_destroy, hip_attr_equal },
+  { PANGO_ATTR_INVALID, hip_attr_copy, hip_attr_destroy, hip_attr_equal },
+  { PANGO_ATTR_INVALID, hip_attr_copy, hip_attr_destroy, hip_attr_equal },
+};
+
+static PangoAttribute *
+hip_attr_new (const PangoAttrClass *klass, int value, guint start, guint end)
+{
+  PangoAttrInt *a = g_slice_new (PangoAttrInt);
+  pango_attribute_init (&a->attr, klass);
+  a->value = value;
+  a->attr.start_index = start;
+  a->attr.end_index = end;
+  return &a->attr;
+}
+
+static PangoAttribute *
+hip_attr_copy (const PangoAttribute *attr)
+{
+  return hip_attr_new (attr->klass, ((const PangoAttrInt *) attr)->value,
+      attr->start_index, attr->end_index);
+}
+
+static void
+hip_attr_destroy (PangoAttribute *attr)
+{
+  g_slice_free (PangoAttrInt, (PangoAttrInt *) attr);
+}
+
+static gboolean
+hip_attr_equal (const PangoAttribute *a, const PangoAttribute *b)
+{
+  return ((const PangoAttrInt *) a)->value == ((const PangoAttrInt *) b)->value;
+}
+
+/* ---- per-buffer region model ------------------------------------------------ */
+typedef struct
+{
+  gchar *id;
+  gint zindex;
+  gint ox, oy, ex, ey;       /* origin, extent: integers (reference :49-52) */
+  gint pox, poy, pex, pey;   /* after padding */
+  guint32 bg;                /* 0xRRGGBBAA */
+  gdouble opacity;
+  cairo_surface_t *image;
+  gint image_x, image_y;
+  GstTTMLDisplayAlign display_align;
+  gboolean overflow_visible;
+  GstTTMLWritingMode writing_mode;
+  GstTTMLTextOutline outline; /* reference: a region attribute, from the
+                               * first span that reaches the region (:62-64) */
+  GList *layouts;            /* PangoLayout */
+  GString *par;              /* markup of the paragraph being assembled */
+  GstTTMLStyle par_style;
+  PangoAttrList *par_attrs;
+  gint par_plain_len;
+} HipRegion;
+
+#define COMP(c, shift) ((((c) >> (shift)) & 255) / 255.0)
+
+static gint
+region_cmp_z (gconstpointer a, gconstpointer b)
+{
+  return ((const HipRegion *) a)->zindex - ((const HipRegion *) b)->zindex;
+}
+
+static gint
+region_cmp_id (gconstpointer a, gconstpointer id)
+{
+  return g_strcmp0 (((const HipRegion *) a)->id, (const gchar *) id);
+}
+
+static void
+region_free (gpointer data)
+{
+  HipRegion *r = data;
+  if (r->par)
+    g_string_free (r->par, TRUE);
+  if (r->par_attrs)
+    pango_attr_list_unref (r->par_attrs);
+  gst_ttml_style_reset (&r->par_style);
+  g_list_free_full (r->layouts, g_object_unref);
+  g_free (r->id);
+  g_free (r);
+}
+
+/* ---- images (smpte:backgroundImage) ----------------------------------------- */
+typedef struct
+{
+  const guint8 *p;
+  gint left;
+} MemReader;
+
+static cairo_status_t
+mem_read (void *closure, unsigned char *out, unsigned int len)
+{
+  MemReader *m = closure;
+  if ((gint) len > m->left)
+    return CAIRO_STATUS_READ_ERROR;
+  memcpy (out, m->p, len);
+  m->p += len;
+  m->left -= len;
+  return CAIRO_STATUS_SUCCESS;
+}
+
+static cairo_surface_t *
+image_lookup (GstTTMLRender *render, const gchar *id)
+{
+  GstTTMLRenderPrivate *priv = get_priv (render);
+  cairo_surface_t *s;
+  guint8 *data = NULL;
+  gint len = 0;
+  gboolean owned = FALSE;
+
+  if (!priv->images)
+    priv->images = g_hash_table_new_full (g_str_hash, g_str_equal, g_free,
+        (GDestroyNotify) cairo_surface_destroy);
+  s = g_hash_table_lookup (priv->images, id);
+  if (s)
+    return s;
+
+  if (id[0] == '#') {
+    gst_ttml_state_restore_data (&render->base.state, id + 1, &data, &len);
+    if (!data) {
+      GST_WARNING_OBJECT (render, "no embedded image '%s'", id + 1);
+      return NULL;
+    }
+  } else {
+    /* reference :375-407: URL as is, or relative to the document location */
+    gchar *scheme = g_uri_parse_scheme (id), *url;
+    if (scheme) {
+      url = g_strdup (id);
+      g_free (scheme);
+    } else {
+      gchar *base = gst_ttmlbase_uri_get (render->base.sinkpad);
+      gchar *dir = g_path_get_dirname (base);
+      url = strncmp (base, "file://", 7) == 0 ? g_build_filename (dir, id, NULL)
+                                             : g_strdup_printf ("%s/%s", dir, id);
+      g_free (base);
+      g_free (dir);
+    }
+    if (!fludownloader_helper_downloader_download_sync (render->downloader, url,
+            &data, &len, NULL)) {
+      GST_WARNING_OBJECT (render, "could not retrieve '%s'", id);
+      g_free (url);
+      return NULL;
+    }
+    owned = TRUE;
+    g_free (url);
+  }
+  MemReader rd = { data, len };
+  s = cairo_image_surface_create_from_png_stream (mem_read, &rd);
+  if (owned)
+    g_free (data);
+  if (!s || cairo_surface_status (s) != CAIRO_STATUS_SUCCESS) {
+    GST_WARNING_OBJECT (render, "could not decode image '%s'", id);
+    if (s)
+      cairo_surface_destroy (s);
+    return NULL;
+  }
+  g_hash_table_insert (priv->images, g_strdup (id), s);
+  return s;
+}
+
+/* ---- style -> region geometry (reference :434-561) --------------------------- */
+static gfloat
+norm_len (GstTTMLRender *render, GstTTMLAttribute *attr, int index, int dir)
+{
+  return gst_ttml_attribute_get_normalized_length (&render->base.state, NULL, attr,
+      index, dir, NULL);
+}
+
+static void
+region_configure (GstTTMLRender *render, HipRegion *r, GstTTMLStyle *style)
+{
+  GstTTMLAttribute *a;
+
+  a = gst_ttml_style_get_attr (style, GST_TTML_ATTR_ZINDEX);
+  r->zindex = a ? a->value.i : 0;
+  a = gst_ttml_style_get_attr (style, GST_TTML_ATTR_OPACITY);
+  r->opacity = a ? a->value.d : 1.0;
+
+  /* lengths are floats, stored into ints: truncation (reference :450-489) */
+  a = gst_ttml_style_get_attr (style, GST_TTML_ATTR_ORIGIN);
+  r->ox = a ? norm_len (render, a, 0, 0) : 0;
+  r->oy = a ? norm_len (render, a, 1, 1) : 0;
+  a = gst_ttml_style_get_attr (style, GST_TTML_ATTR_EXTENT);
+  if (a) {
+    r->ex = norm_len (render, a, 0, 0);
+    r->ey = norm_len (render, a, 1, 1);
+  } else {
+    r->ex = render->base.state.frame_width;
+    r->ey = render->base.state.frame_height;
+  }
+  r->pox = r->ox;
+  r->poy = r->oy;
+  r->pex = r->ex;
+  r->pey = r->ey;
+  a = gst_ttml_style_get_attr (style, GST_TTML_ATTR_PADDING);
+  if (a) {
+    /* reference: int += float, int -= float + float (each a float->int store) */
+    gfloat px = norm_len (render, a, 3, 0), py = norm_len (render, a, 0, 1);
+    r->pox += px;
+    r->poy += py;
+    r->pex -= px + norm_len (render, a, 1, 0);
+    r->pey -= py + norm_len (render, a, 2, 1);
+  }
+
+  a = gst_ttml_style_get_attr (style, GST_TTML_ATTR_BACKGROUND_REGION_COLOR);
+  r->bg = a ? a->value.color : 0;
+
+  a = gst_ttml_style_get_attr (style, GST_TTML_ATTR_SMPTE_BACKGROUND_IMAGE);
+  r->image = (a && a->value.string) ? image_lookup (render, a->value.string) : NULL;
+  if (r->image) {
+    gint iw = cairo_image_surface_get_width (r->image);
+    gint ih = cairo_image_surface_get_height (r->image);
+    a = gst_ttml_style_get_attr (style,
+        GST_TTML_ATTR_SMPTE_BACKGROUND_IMAGE_HORIZONTAL);
+    if (!a)
+      r->image_x = r->pox + (r->pex - iw) / 2;
+    else if (a->value.raw_length[0].unit == GST_TTML_LENGTH_UNIT_RELATIVE)
+      r->image_x = r->pox + (r->pex - iw) * a->value.raw_length[0].f;
+    else
+      r->image_x = r->pox + a->value.raw_length[0].f;
+    a = gst_ttml_style_get_attr (style,
+        GST_TTML_ATTR_SMPTE_BACKGROUND_IMAGE_VERTICAL);
+    if (!a)
+      r->image_y = r->poy + (r->pey - ih) / 2;
+    else if (a->value.raw_length[0].unit == GST_TTML_LENGTH_UNIT_RELATIVE)
+      r->image_y = r->poy + (r->pey - ih) * a->value.raw_length[0].f;
+    else
+      r->image_y = r->poy + a->value.raw_length[0].f;
+  }
+
+  a = gst_ttml_style_get_attr (style, GST_TTML_ATTR_DISPLAY_ALIGN);
+  r->display_align = a ? a->value.display_align : render->default_display_align;
+  a = gst_ttml_style_get_attr (style, GST_TTML_ATTR_TEXTOUTLINE);
+  if (a)
+    r->outline = a->value.text_outline;
+  else
+    r->outline.length[0].unit = GST_TTML_LENGTH_UNIT_NOT_PRESENT;
+  a = gst_ttml_style_get_attr (style, GST_TTML_ATTR_OVERFLOW);
+  r->overflow_visible = a ? a->value.b : FALSE;
+  a = gst_ttml_style_get_attr (style, GST_TTML_ATTR_WRITING_MODE);
+  r->writing_mode = a ? a->value.writing_mode : GST_TTML_WRITING_MODE_LRTB;
+}
+
+/* ---- active spans -> region paragraphs (reference :591-939) ------------------ */
+static void
+par_add_attr (HipRegion *r, PangoAttribute *attr)
+{
+  if (!r->par_attrs)
+    r->par_attrs = pango_attr_list_new ();
+  pango_attr_list_change (r->par_attrs, attr);
+}
+
+/* reference :861-898: Pango markup has no alpha, so a colour with alpha != 0
+ * travels as a Pango colour attribute with the alpha hidden in the LSB of red */
+static void
+smuggled_color (guint32 c, guint16 *r, guint16 *g, guint16 *b)
+{
+  *r = ((c >> 16) & 0xFF00) | (c & 0x00FF);
+  *g = (c >> 8) & 0xFF00;
+  *b = c & 0xFF00;
+}
+
+static void
+span_to_region (GstTTMLRender *render, GList **regions, GstTTMLSpan *span)
+{
+  GstTTMLBase *base = GST_TTMLBASE (render);
+  GstTTMLStyle merged;
+  GstTTMLAttribute *a;
+  const gchar *rid;
+  HipRegion *r;
+  GList *link;
+  gchar *head, *tail, *font_size;
+  guint start, end;
+
+  a = gst_ttml_style_get_attr (&span->style, GST_TTML_ATTR_DISPLAY);
+  if (a && !a->value.b)
+    return;
+
+  a = gst_ttml_style_get_attr (&span->style, GST_TTML_ATTR_REGION);
+  rid = a ? a->value.string : "anonymous";
+  if (a) {
+    /* span attributes override the region's own */
+    GstTTMLStyle region_style;
+    if (!g_hash_table_lookup_extended (base->state.saved_region_attr_stacks, rid,
+            NULL, (gpointer *) &region_style.attributes))
+      return;                   /* unknown region: the span is dropped */
+    gst_ttml_style_copy (&merged, &region_style, FALSE);
+    for (link = span->style.attributes; link; link = link->next)
+      gst_ttml_attribute_free (
+          gst_ttml_style_set_attr (&merged, (GstTTMLAttribute *) link->data));
+  } else {
+    gst_ttml_style_copy (&merged, &span->style, FALSE);
+  }
+
+  link = g_list_find_custom (*regions, rid, region_cmp_id);
+  if (link) {
+    r = link->data;
+    /* reference :647-654: only the first contributor configures the region */
+    if (!r->layouts && !r->par)
+      region_configure (render, r, &merged);
+  } else {
+    r = g_new0 (HipRegion, 1);
+    r->id = g_strdup (rid);
+    region_configure (render, r, &merged);
+    *regions = g_list_insert_sorted (*regions, r, region_cmp_z);
+  }
+
+  /* default font size: one cell row (reference :677-685) */
+  font_size = render->default_font_size
+      ? g_strdup (render->default_font_size)
+      : g_strdup_printf (" %dpx ",
+            base->state.frame_height / base->state.cell_resolution_y);
+  gst_ttml_style_gen_pango_markup (&base->state, &merged, &head, &tail,
+      render->default_font_family, font_size);
+  g_free (font_size);
+
+  if (span->length) {
+    if (!r->par)
+      r->par = g_string_new (NULL);
+    g_string_append (r->par, head);
+    g_string_append_len (r->par, span->chars, span->length);
+    g_string_append (r->par, tail);
+  }
+  g_free (head);
+  g_free (tail);
+
+  if (!r->par_style.attributes)
+    gst_ttml_style_copy (&r->par_style, &merged, FALSE);
+
+  start = r->par_plain_len;
+  end = start + span->length;
+
+  a = gst_ttml_style_get_attr (&span->style, GST_TTML_ATTR_TEXT_DECORATION);
+  if (a && (a->value.text_decoration & GST_TTML_TEXT_DECORATION_OVERLINE))
+    par_add_attr (r, hip_attr_new (&hip_attr_klass[HIP_ATTR_OVERLINE], 1, start, end));
+  a = gst_ttml_style_get_attr (&span->style, GST_TTML_ATTR_VISIBILITY);
+  if (a && !a->value.b)
+    par_add_attr (r, hip_attr_new (&hip_attr_klass[HIP_ATTR_INVISIBLE], 0, start, end));
+
+  a = gst_ttml_style_get_attr (&span->style, GST_TTML_ATTR_FONT_SIZE);
+  if (a && gst_ttml_attribute_is_length_present (a, 1)) {
+    /* anamorphic "w h" font size (reference :745-857): not implemented */
+    GST_FIXME_OBJECT (render, "anamorphic fontSize is not implemented");
+  }
+
+  a = gst_ttml_style_get_attr (&span->style, GST_TTML_ATTR_BACKGROUND_COLOR);
+  if (a && (a->value.color & 0xFF)) {
+    guint16 cr, cg, cb;
+    PangoAttribute *pa;
+    smuggled_color (a->value.color, &cr, &cg, &cb);
+    pa = pango_attr_background_new (cr, cg, cb);
+    pa->start_index = start;
+    pa->end_index = end;
+    par_add_attr (r, pa);
+  }
+  a = gst_ttml_style_get_attr (&span->style, GST_TTML_ATTR_COLOR);
+  if (a && (a->value.color & 0xFF)) {
+    guint16 cr, cg, cb;
+    PangoAttribute *pa;
+    smuggled_color (a->value.color, &cr, &cg, &cb);
+    pa = pango_attr_foreground_new (cr, cg, cb);
+    pa->start_index = start;
+    pa->end_index = end;
+    par_add_attr (r, pa);
+  }
+  a = gst_ttml_style_get_attr (&span->style, GST_TTML_ATTR_UNICODE_BIDI);
+  if (a && a->value.unicode_bidi == GST_TTML_UNICODE_BIDI_OVERRIDE) {
+    a = gst_ttml_style_get_attr (&span->style, GST_TTML_ATTR_DIRECTION);
+    if (a && a->value.direction == GST_TTML_DIRECTION_RTL)
+      par_add_attr (r, hip_attr_new (&hip_attr_klass[HIP_ATTR_REVERSE], 1, start, end));
+  }
+  a = gst_ttml_style_get_attr (&span->style, GST_TTML_ATTR_FONT_STYLE);
+  if (a && a->value.font_style == GST_TTML_FONT_STYLE_REVERSE_OBLIQUE)
+    par_add_attr (r,
+        hip_attr_new (&hip_attr_klass[HIP_ATTR_REVERSE_OBLIQUE], 1, start, end));
+
+  r->par_plain_len += span->length;
+  gst_ttml_style_reset (&merged);
+}
+
+/* Regions whose background shows even without text (reference :1400-1425). */
+static void
+background_region (gpointer key, gpointer value, gpointer user_data)
+{
+  gpointer *ctx = user_data;
+  GstTTMLRender *render = ctx[0];
+  GList **regions = ctx[1];
+  GstTTMLStyle style;
+  GstTTMLAttribute *a;
+
+  style.attributes = value;
+  a = gst_ttml_style_get_attr (&style, GST_TTML_ATTR_SHOW_BACKGROUND);
+  if (a && a->value.show_background != GST_TTML_SHOW_BACKGROUND_ALWAYS)
+    return;
+  if (!g_list_find_custom (*regions, key, region_cmp_id)) {
+    HipRegion *r = g_new0 (HipRegion, 1);
+    r->id = g_strdup (key);
+    region_configure (render, r, &style);
+    *regions = g_list_insert_sorted (*regions, r, region_cmp_z);
+  }
+}
+
+/* Paragraph -> PangoLayout (reference :199-289). */
+static void
+region_flush_paragraph (GstTTMLRender *render, HipRegion *r)
+{
+  PangoLayout *layout = pango_layout_new (render->pango_context);
+  GstTTMLAttribute *a;
+  gint w = r->pex, h = r->pey;
+  GstTTMLWrapOption wrap = GST_TTML_WRAP_OPTION_YES;
+  PangoAlignment align = PANGO_ALIGN_LEFT;
+
+  if (r->writing_mode > GST_TTML_WRITING_MODE_RLTB) {
+    w = r->pey;
+    h = r->pex;
+  }
+  a = gst_ttml_style_get_attr (&r->par_style, GST_TTML_ATTR_WRAP_OPTION);
+  if (a)
+    wrap = a->value.wrap_option;
+  if (wrap == GST_TTML_WRAP_OPTION_YES)
+    pango_layout_set_width (layout, w * PANGO_SCALE);
+  pango_layout_set_height (layout, h * PANGO_SCALE);
+
+  a = gst_ttml_style_get_attr (&r->par_style, GST_TTML_ATTR_TEXT_ALIGN);
+  switch (a ? a->value.text_align : render->default_text_align) {
+    case GST_TTML_TEXT_ALIGN_RIGHT:
+    case GST_TTML_TEXT_ALIGN_END:
+      align = PANGO_ALIGN_RIGHT;
+      break;
+    case GST_TTML_TEXT_ALIGN_CENTER:
+      align = PANGO_ALIGN_CENTER;
+      break;
+    default:
+      break;
+  }
+  pango_layout_set_alignment (layout, align);
+
+  /* reference: lineHeight is smuggled to the draw loop as the layout spacing;
+   * -1 means "use the line's own extents" */
+  a = gst_ttml_style_get_attr (&r->par_style, GST_TTML_ATTR_LINE_HEIGHT);
+  if (a && gst_ttml_attribute_is_length_present (a, 0))
+    pango_layout_set_spacing (layout, norm_len (render, a, 0, 1));
+  else
+    pango_layout_set_spacing (layout, -1);
+
+  pango_layout_set_markup (layout, r->par->str, -1);
+
+  if (r->par_attrs) {
+    PangoAttrList *dst = pango_layout_get_attributes (layout);
+    PangoAttrIterator *it = pango_attr_list_get_iterator (r->par_attrs);
+    do {
+      GSList *l, *attrs = pango_attr_iterator_get_attrs (it);
+      for (l = attrs; l; l = l->next)
+        pango_attr_list_change (dst, l->data);
+      g_slist_free (attrs);
+    } while (pango_attr_iterator_next (it));
+    pango_attr_iterator_destroy (it);
+    pango_layout_set_attributes (layout, dst);
+    pango_attr_list_unref (r->par_attrs);
+    r->par_attrs = NULL;
+  }
+
+  r->layouts = g_list_append (r->layouts, layout);
+  g_string_free (r->par, TRUE);
+  r->par = NULL;
+  r->par_plain_len = 0;
+  gst_ttml_style_reset (&r->par_style);
+}
+
+/* ---- layout -> primitives (reference :941-1176) ------------------------------
+ * fill == TRUE : glyphs and rectangles are recorded as primitives;
+ * fill == FALSE: glyph outlines and rectangles are appended to the recorder's
+ *                path; span backgrounds still fill (after flushing the pending
+ *                path with a stroke), exactly as the reference's "render"
+ *                flag does in the outline pass. */
+static void
+set_smuggled_source (FlutlRecorder *rec, const PangoColor *c)
+{
+  /* reference :1009-1012: red uses its high byte / 65280, green and blue the
+   * full 16 bits / 65535, alpha is the low byte of red / 255 */
+  flutl_recorder_set_color (rec, (c->red & 0xFF00) / 65280.0, c->green / 65535.0,
+      c->blue / 65535.0, (c->red & 0x00FF) / 255.0);
+}
+
+static void
+rect_or_path (FlutlRecorder *rec, gboolean fill, double x, double y, double w,
+    double h)
+{
+  if (fill) {
+    flutl_recorder_fill_rect (rec, x, y, w, h);
+  } else {
+    cairo_rectangle (flutl_recorder_cairo (rec), x, y, w, h);
+    flutl_recorder_stroke (rec);
+  }
+}
+
+static void
+walk_layout (GstTTMLRender *render, PangoLayout *layout, gboolean fill,
+    int right_edge, gboolean show_background, GstTTMLWritingMode writing_mode)
+{
+  FlutlRecorder *rec = get_priv (render)->rec;
+  cairo_t *cr = flutl_recorder_cairo (rec);
+  int n_lines = pango_layout_get_line_count (layout);
+  int spacing = pango_layout_get_spacing (layout);
+  int baseline = pango_layout_get_baseline (layout) / PANGO_SCALE;
+  int xoffset = 0, li;
+
+  if (pango_layout_get_width (layout) == -1) {
+    /* no wrapping: alignment is applied by hand against the region width */
+    PangoRectangle ext;
+    pango_layout_get_pixel_extents (layout, NULL, &ext);
+    if (pango_layout_get_alignment (layout) == PANGO_ALIGN_RIGHT)
+      xoffset = right_edge - ext.width;
+    if (pango_layout_get_alignment (layout) == PANGO_ALIGN_CENTER)
+      xoffset = (right_edge - ext.width) / 2;
+  }
+
+  for (li = 0; li < n_lines; li++) {
+    PangoLayoutLine *line = pango_layout_get_line_readonly (layout, li);
+    int pre, post, *ranges, n_ranges, line_dx;
+    GSList *rl;
+
+    pango_layout_line_get_x_ranges (line, line->start_index,
+        line->start_index + line->length, &ranges, &n_ranges);
+    if (spacing == -1) {
+      PangoRectangle ext;
+      pango_layout_line_get_pixel_extents (line, NULL, &ext);
+      pre = -ext.y;
+      post = ext.y + ext.height;
+    } else {
+      pre = baseline;
+      post = spacing - baseline;
+    }
+    line_dx = xoffset + ranges[0] / PANGO_SCALE;     /* integer division */
+    g_free (ranges);
+
+    cairo_translate (cr, line_dx,
+        writing_mode != GST_TTML_WRITING_MODE_TBLR ? pre : -post);
+    cairo_save (cr);
+    for (rl = line->runs; rl; rl = rl->next) {
+      PangoGlyphItem *run = rl->data;
+      PangoGlyphString *gs = run->glyphs;
+      GSList *al;
+      double width = 0.0;
+      gboolean skip = FALSE, oblique = FALSE;
+      gboolean reverse = writing_mode == GST_TTML_WRITING_MODE_RLTB;
+      int i;
+
+      for (i = 0; i < gs->num_glyphs; i++)
+        width += gs->glyphs[i].geometry.width;
+      width /= PANGO_SCALE;
+      cairo_save (cr);
+      double saved_color[4];
+      flutl_recorder_get_color (rec, saved_color);
+
+      /* pass 1: colours and span background */
+      for (al = run->item->analysis.extra_attrs; al; al = al->next) {
+        PangoAttribute *attr = al->data;
+        if (attr->klass->type == PANGO_ATTR_FOREGROUND) {
+          set_smuggled_source (rec, &((PangoAttrColor *) attr)->color);
+        } else if (attr->klass->type == PANGO_ATTR_BACKGROUND) {
+          double keep[4];
+          if (!show_background)
+            continue;
+          if (!fill)
+            flutl_recorder_stroke (rec);   /* flush the outline path so far */
+          flutl_recorder_get_color (rec, keep);
+          set_smuggled_source (rec, &((PangoAttrColor *) attr)->color);
+          flutl_recorder_fill_rect (rec, 0, -pre, width, pre + post);
+          flutl_recorder_set_color (rec, keep[0], keep[1], keep[2], keep[3]);
+        } else if (attr->klass == &hip_attr_klass[HIP_ATTR_REVERSE]) {
+          reverse = TRUE;
+        }
+      }
+
+      /* pass 2: decorations, visibility */
+      for (al = run->item->analysis.extra_attrs; al; al = al->next) {
+        PangoAttribute *attr = al->data;
+        PangoFontMetrics *fm;
+        double thick, pos;
+        switch (attr->klass->type) {
+          case PANGO_ATTR_UNDERLINE:
+            fm = pango_font_get_metrics (run->item->analysis.font, NULL);
+            thick = pango_font_metrics_get_underline_thickness (fm);
+            pos = pango_font_metrics_get_underline_position (fm);
+            pango_font_metrics_unref (fm);
+            rect_or_path (rec, fill, 0, -pos / PANGO_SCALE, width, thick / PANGO_SCALE);
+            break;
+          case PANGO_ATTR_STRIKETHROUGH:
+            fm = pango_font_get_metrics (run->item->analysis.font, NULL);
+            thick = pango_font_metrics_get_strikethrough_thickness (fm);
+            pos = pango_font_metrics_get_strikethrough_position (fm);
+            pango_font_metrics_unref (fm);
+            rect_or_path (rec, fill, 0, -pos / PANGO_SCALE, width, thick / PANGO_SCALE);
+            break;
+          default:
+            if (attr->klass == &hip_attr_klass[HIP_ATTR_OVERLINE]) {
+              fm = pango_font_get_metrics (run->item->analysis.font, NULL);
+              thick = pango_font_metrics_get_underline_thickness (fm);
+              pos = pango_font_metrics_get_ascent (fm);
+              pango_font_metrics_unref (fm);
+              rect_or_path (rec, fill, 0, -pos / PANGO_SCALE, width,
+                  thick / PANGO_SCALE);
+            } else if (attr->klass == &hip_attr_klass[HIP_ATTR_INVISIBLE]) {
+              skip = TRUE;
+            } else if (attr->klass == &hip_attr_klass[HIP_ATTR_REVERSE_OBLIQUE]) {
+              oblique = TRUE;
+            }
+            break;
+        }
+      }
+      if (oblique) {
+        GST_FIXME_OBJECT (render, "reverseOblique is not implemented");
+        skip = TRUE;
+      }
+
+      if (!skip) {
+        /* one glyph at a time, like the reference (:1138-1161) */
+        int n = gs->num_glyphs;
+        for (i = 0; i < n; i++) {
+          PangoGlyphInfo *gi = &gs->glyphs[reverse ? n - 1 - i : i];
+          cairo_save (cr);
+          /* reference: the glyph offsets are applied here AND again by Pango */
+          cairo_translate (cr, gi->geometry.x_offset / (double) PANGO_SCALE,
+              gi->geometry.y_offset / (double) PANGO_SCALE);
+          if (fill) {
+            flutl_recorder_show_glyph (rec, run->item->analysis.font, gi);
+          } else {
+            PangoGlyphString one = *gs;
+            one.num_glyphs = 1;
+            one.glyphs = gi;
+            pango_cairo_glyph_string_path (cr, run->item->analysis.font, &one);
+          }
+          cairo_restore (cr);
+          cairo_translate (cr, gi->geometry.width / (double) PANGO_SCALE, 0);
+        }
+      }
+      cairo_restore (cr);
+      /* cairo_restore also restores the source colour */
+      flutl_recorder_set_color (rec, saved_color[0], saved_color[1], saved_color[2],
+          saved_color[3]);
+      cairo_translate (cr, width, 0);
+    }
+    cairo_restore (cr);
+    cairo_translate (cr, -line_dx,
+        writing_mode != GST_TTML_WRITING_MODE_TBLR ? post : -pre);
+  }
+}
+
+/* Text outline (reference :1180-1232). */
+static void
+outline_layout (GstTTMLRender *render, HipRegion *r, PangoLayout *layout)
+{
+  FlutlRecorder *rec = get_priv (render)->rec;
+  cairo_t *cr = flutl_recorder_cairo (rec);
+  /* reference :1186: "current colour" is hard-wired to opaque white */
+  guint32 c = r->outline.use_current_color ? 0xFFFFFFFF : r->outline.color;
+  double keep[4];
+
+  if (r->outline.length[1].unit != GST_TTML_LENGTH_UNIT_NOT_PRESENT) {
+    GST_FIXME_OBJECT (render, "blurred textOutline is not implemented; "
+        "the outline of region '%s' is not drawn", r->id);
+    return;
+  }
+  flutl_recorder_get_color (rec, keep);
+  cairo_save (cr);
+  flutl_recorder_set_color (rec, COMP (c, 24), COMP (c, 16), COMP (c, 8), COMP (c, 0));
+  cairo_set_line_width (cr, r->outline.length[0].f * 2);
+  walk_layout (render, layout, FALSE, r->pex, TRUE, r->writing_mode);
+  flutl_recorder_stroke (rec);
+  cairo_restore (cr);
+  flutl_recorder_set_color (rec, keep[0], keep[1], keep[2], keep[3]);
+}
+
+/* One region -> one binning group (reference :1235-1385). */
+static void
+record_region (HipRegion *r, GstTTMLRender *render)
+{
+  FlutlRecorder *rec = get_priv (render)->rec;
+  cairo_t *cr = flutl_recorder_cairo (rec);
+  gboolean grouped = r->opacity < 1.0;
+  GList *l;
+
+  if (r->par)
+    region_flush_paragraph (render, r);
+
+  flutl_recorder_region_begin (rec);
+  cairo_save (cr);
+  if (grouped)
+    flutl_recorder_group_begin (rec, r->ox, r->oy, r->ex, r->ey);
+
+  if (r->bg != 0) {
+    flutl_recorder_set_color (rec, COMP (r->bg, 24), COMP (r->bg, 16),
+        COMP (r->bg, 8), COMP (r->bg, 0));
+    flutl_recorder_fill_rect (rec, r->ox, r->oy, r->ex, r->ey);
+  }
+  if (r->image)
+    flutl_recorder_paint_image (rec, r->image, r->image_x, r->image_y);
+  if (!r->overflow_visible)
+    flutl_recorder_clip (rec, r->pox, r->poy, r->pex, r->pey);
+
+  cairo_translate (cr, r->pox, r->poy);
+  if (r->display_align != GST_TTML_DISPLAY_ALIGN_BEFORE) {
+    double height = 0.0, posy;
+    for (l = r->layouts; l; l = l->next) {
+      PangoRectangle ext;
+      pango_layout_get_pixel_extents (l->data, NULL, &ext);
+      height += ext.height;
+    }
+    /* reference :1303: the UNPADDED extent is used */
+    posy = r->ey - height;
+    if (r->display_align == GST_TTML_DISPLAY_ALIGN_CENTER)
+      posy /= 2.0;
+    cairo_translate (cr, 0, posy);
+  }
+
+  if (r->writing_mode == GST_TTML_WRITING_MODE_TBRL ||
+      r->writing_mode == GST_TTML_WRITING_MODE_TBLR) {
+    GST_FIXME_OBJECT (render, "vertical writing modes are not implemented; "
+        "the text of region '%s' is not drawn", r->id);
+  } else {
+    for (l = r->layouts; l; l = l->next) {
+      gboolean outlined =
+          r->outline.length[0].unit != GST_TTML_LENGTH_UNIT_NOT_PRESENT;
+      if (outlined)
+        outline_layout (render, r, l->data);
+      /* reference :1360-1363: default text colour = inverse of the region
+       * background, opaque */
+      flutl_recorder_set_color (rec, 1.0 - COMP (r->bg, 24), 1.0 - COMP (r->bg, 16),
+          1.0 - COMP (r->bg, 8), 1.0);
+      walk_layout (render, l->data, TRUE, r->pex, !outlined, r->writing_mode);
+    }
+  }
+
+  if (grouped)
+    flutl_recorder_group_end (rec, r->opacity);
+  flutl_recorder_clip_reset (rec);
+  cairo_restore (cr);
+  flutl_recorder_region_end (rec);
+}
+
+/* ---- device side -------------------------------------------------------------- */
+static gboolean
+ensure_ctx (GstTTMLRender *render)
+{
+  GstTTMLRenderPrivate *priv = get_priv (render);
+  if (priv->ctx)
+    return TRUE;
+  if (priv->ctx_failed)
+    return FALSE;
+  const gchar *dev = g_getenv ("FLUTL_DEVICE");
+  int rc = flutl_ctx_create (dev ? atoi (dev) : 0, &priv->ctx);
+  if (rc != FLUTL_OK) {
+    priv->ctx_failed = TRUE;
+    GST_ELEMENT_ERROR (render, LIBRARY, INIT,
+        ("ttmlrender: no usable MI355X/HIP device"),
+        ("flutl_ctx_create: %s", flutl_strerror (rc)));
+    return FALSE;
+  }
+  return TRUE;
+}
+
+static GstBuffer *
+gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime duration)
+{
+  GstTTMLRender *render = GST_TTMLRENDER (base);
+  GstTTMLRenderPrivate *priv = get_priv (render);
+  FlutlRecorder *rec = priv->rec;
+  gint width = base->state.frame_width, height = base->state.frame_height;
+  GList *regions = NULL, *l;
+  const flutl_region *rg;
+  const flutl_prim *pr;
+  uint32_t n_rg, n_pr;
+  GstBuffer *buffer = NULL;
+
+  GST_DEBUG_OBJECT (render, "buffer %" GST_TIME_FORMAT " + %" GST_TIME_FORMAT
+      ", frame %dx%d", GST_TIME_ARGS (ts), GST_TIME_ARGS (duration), width, height);
+  if (width <= 0 || height <= 0 || width > 32767 || height > 32767)
+    return NULL;
+
+  /* ---- host: scene state -> display list -------------------------------- */
+  flutl_recorder_begin_frame (rec, width, height);
+  if (base->state.saved_region_attr_stacks) {
+    gpointer ctx[2] = { render, &regions };
+    g_hash_table_foreach (base->state.saved_region_attr_stacks, background_region,
+        ctx);
+  }
+  for (l = base->active_spans; l; l = l->next)
+    span_to_region (render, &regions, l->data);
+  for (l = regions; l; l = l->next)
+    record_region (l->data, render);
+  g_list_free_full (regions, region_free);
+
+  rg = flutl_recorder_regions (rec, &n_rg);
+  pr = flutl_recorder_prims (rec, &n_pr);
+  if (flutl_recorder_unsupported (rec))
+    GST_WARNING_OBJECT (render, "%u primitive(s) use features that are not "
+        "implemented and were left out", flutl_recorder_unsupported (rec));
+
+  if (priv->dump) {
+    size_t atlas_size;
+    const uint8_t *atlas = flutl_recorder_atlas (rec, &atlas_size);
+    flutl_pack_writer_add (priv->dump, width, height, rg, n_rg, pr, n_pr, atlas,
+        atlas_size);
+  }
+  if (priv->dump_only) {
+    /* record-only test facility (no GPU needed): the base class must see a
+     * buffer or its timeline bookkeeping diverges; the frame is left blank */
+    buffer = gst_buffer_new_and_alloc ((gsize) width * height * 4);
+    gst_buffer_memset (buffer, 0, 0, (gsize) width * height * 4);
+    return buffer;
+  }
+
+  /* ---- device: display list -> frame ------------------------------------- */
+  if (!ensure_ctx (render))
+    return NULL;
+  {
+    const uint32_t *off, *size;
+    size_t atlas_size;
+    const uint8_t *atlas = flutl_recorder_atlas (rec, &atlas_size);
+    uint32_t i, n = flutl_recorder_new_atlas_entries (rec, &off, &size);
+    for (i = 0; i < n; i++) {
+      uint32_t dev_off = 0;
+      int rc = flutl_atlas_put (priv->ctx, atlas + off[i], size[i], &dev_off);
+      if (rc != FLUTL_OK || dev_off != off[i]) {
+        GST_ELEMENT_ERROR (render, LIBRARY, FAILED, ("ttmlrender: atlas upload failed"),
+            ("flutl_atlas_put: %s (offset %u vs %u)", flutl_strerror (rc), dev_off,
+                off[i]));
+        return NULL;
+      }
+    }
+  }
+  {
+    flutl_list *list = NULL;
+    GstMapInfo map;
+    int rc = flutl_list_create (priv->ctx, width, height, rg, n_rg, pr, n_pr, &list);
+    if (rc != FLUTL_OK) {
+      GST_ELEMENT_ERROR (render, LIBRARY, FAILED, ("ttmlrender: invalid display list"),
+          ("flutl_list_create: %s", flutl_strerror (rc)));
+      return NULL;
+    }
+    buffer = gst_buffer_new_and_alloc ((gsize) width * height * 4);
+    gst_buffer_map (buffer, &map, GST_MAP_WRITE);
+    rc = flutl_render_to_host (priv->ctx, list, map.data, (size_t) width * 4);
+    gst_buffer_unmap (buffer, &map);
+    flutl_list_destroy (priv->ctx, list);
+    if (rc != FLUTL_OK) {
+      GST_ELEMENT_ERROR (render, LIBRARY, FAILED, ("ttmlrender: HIP render failed"),
+          ("flutl_render_to_host: %s", flutl_strerror (rc)));
+      gst_buffer_unref (buffer);
+      return NULL;
+    }
+  }
+  return buffer;
+}
+
+/* ---- caps (reference :1480-1531) ----------------------------------------------- */
+static void
+gst_ttmlrender_fixate_caps (GstTTMLBase *base, GstCaps *caps)
+{
+  GstTTMLRender *render = GST_TTMLRENDER (base);
+  GstStructure *s = gst_caps_get_structure (caps, 0);
+  while (gst_caps_get_size (caps) > 1)
+    gst_caps_remove_structure (caps, gst_caps_get_size (caps) - 1);
+  gst_structure_fixate_field_nearest_int (s, "width", render->window_width);
+  gst_structure_fixate_field_nearest_int (s, "height", render->window_height);
+}
+
+static void
+gst_ttmlrender_complete_caps (GstTTMLBase *base, GstCaps *caps)
+{
+  gst_structure_fixate_field_nearest_fraction (gst_caps_get_structure (caps, 0),
+      "pixel-aspect-ratio", base->state.par_num, base->state.par_den);
+}
+
+static void
+gst_ttmlrender_setcaps (GstTTMLBase *base, GstCaps *caps)
+{
+  GstStructure *s = gst_caps_get_structure (caps, 0);
+  gint w = base->state.frame_width, h = base->state.frame_height;
+  gst_structure_get_int (s, "width", &w);
+  gst_structure_get_int (s, "height", &h);
+  base->state.frame_width = w;
+  base->state.frame_height = h;
+}
+
+/* ---- properties (reference :1533-1608) ------------------------------------------ */
+static void
+gst_ttmlrender_get_property (GObject *object, guint id, GValue *value,
+    GParamSpec *pspec)
+{
+  GstTTMLRender *render = GST_TTMLRENDER (object);
+  switch (id) {
+    case PROP_DEFAULT_FONT_FAMILY:
+      g_value_set_string (value, render->default_font_family);
+      break;
+    case PROP_DEFAULT_FONT_SIZE:
+      g_value_set_string (value, render->default_font_size);
+      break;
+    case PROP_DEFAULT_TEXT_ALIGN:
+      g_value_set_enum (value, render->default_text_align);
+      break;
+    case PROP_DEFAULT_DISPLAY_ALIGN:
+      g_value_set_enum (value, render->default_display_align);
+      break;
+    case PROP_WINDOW_WIDTH:
+      g_value_set_uint (value, render->window_width);
+      break;
+    case PROP_WINDOW_HEIGHT:
+      g_value_set_uint (value, render->window_height);
+      break;
+    default:
+      G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec);
+      break;
+  }
+}
+
+static void
+gst_ttmlrender_set_property (GObject *object, guint id, const GValue *value,
+    GParamSpec *pspec)
+{
+  GstTTMLRender *render = GST_TTMLRENDER (object);
+  switch (id) {
+    case PROP_DEFAULT_FONT_FAMILY:
+      g_free (render->default_font_family);
+      render->default_font_family = g_value_dup_string (value);
+      break;
+    case PROP_DEFAULT_FONT_SIZE:
+      g_free (render->default_font_size);
+      render->default_font_size = g_value_dup_string (value);
+      break;
+    case PROP_DEFAULT_TEXT_ALIGN:
+      render->default_text_align = g_value_get_enum (value);
+      break;
+    case PROP_DEFAULT_DISPLAY_ALIGN:
+      render->default_display_align = g_value_get_enum (value);
+      break;
+    case PROP_WINDOW_WIDTH:
+      /* reference: the window size is also the frame size until caps say
+       * otherwise (:1590-1603) */
+      render->window_width = g_value_get_uint (value);
+      render->base.state.frame_width = render->window_width;
+      break;
+    case PROP_WINDOW_HEIGHT:
+      render->window_height = g_value_get_uint (value);
+      render->base.state.frame_height = render->window_height;
+      break;
+    default:
+      G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec);
+      break;
+  }
+}
+
+/* ---- reset / dispose / init (reference :1610-1750) ------------------------------- */
+static void
+gst_ttmlrender_reset (GstTTMLBase *base)
+{
+  GstTTMLRender *render = GST_TTMLRENDER (base);
+  GstTTMLRenderPrivate *priv = get_priv (render);
+  /* per-document caches: decoded images, glyph/outline atlas (host + HBM) */
+  if (priv->images) {
+    g_hash_table_unref (priv->images);
+    priv->images = NULL;
+  }
+  if (priv->rec)
+    flutl_recorder_reset (priv->rec);
+  if (priv->ctx) {
+    flutl_ctx_sync (priv->ctx);
+    flutl_atlas_reset (priv->ctx);
+  }
+  if (priv->dump)
+    flutl_pack_writer_flush (priv->dump);
+}
+
+static void
+gst_ttmlrender_dispose (GObject *object)
+{
+  GstTTMLRender *render = GST_TTMLRENDER (object);
+  GstTTMLRenderPrivate *priv = get_priv (render);
+
+  gst_ttmlrender_reset (GST_TTMLBASE (render));
+  if (priv->dump) {
+    flutl_pack_writer_free (priv->dump);
+    priv->dump = NULL;
+  }
+  if (priv->ctx) {
+    flutl_ctx_destroy (priv->ctx);
+    priv->ctx = NULL;
+  }
+  if (priv->rec) {
+    flutl_recorder_free (priv->rec);
+    priv->rec = NULL;
+  }
+  g_clear_pointer (&render->default_font_family, g_free);
+  g_clear_pointer (&render->default_font_size, g_free);
+  g_clear_object (&render->pango_context);
+  if (render->downloader) {
+    fludownloader_helper_downloader_free (render->downloader);
+    render->downloader = NULL;
+  }
+  G_OBJECT_CLASS (gst_ttmlrender_parent_class)->dispose (object);
+}
+
+static void
+gst_ttmlrender_class_init (GstTTMLRenderClass *klass)
+{
+  GObjectClass *gobject_class = G_OBJECT_CLASS (klass);
+  GstElementClass *element_class = GST_ELEMENT_CLASS (klass);
+  GstTTMLBaseClass *base_class = GST_TTMLBASE_CLASS (klass);
+
+  gobject_class->dispose = gst_ttmlrender_dispose;
+  gobject_class->set_property = gst_ttmlrender_set_property;
+  gobject_class->get_property = gst_ttmlrender_get_property;
+
+  g_object_class_install_property (gobject_class, PROP_DEFAULT_FONT_FAMILY,
+      g_param_spec_string ("default_font_family", "Default font family",
+          "Font family to use when the TTML file does not explicitly set one",
+          "Sans", G_PARAM_READWRITE));
+  g_object_class_install_property (gobject_class, PROP_DEFAULT_FONT_SIZE,
+      g_param_spec_string ("default_font_size", "Default font size",
+          "Font size to use when the TTML file does not explicitly set one",
+          "default", G_PARAM_READWRITE));
+  g_object_class_install_property (gobject_class, PROP_DEFAULT_TEXT_ALIGN,
+      g_param_spec_enum ("default_text_align", "Default text alignment",
+          "Text alignment to use when the TTML file does not explicitly set one",
+          GST_TTML_TEXT_ALIGN_SPEC, GST_TTML_TEXT_ALIGN_LEFT, G_PARAM_READWRITE));
+  g_object_class_install_property (gobject_class, PROP_DEFAULT_DISPLAY_ALIGN,
+      g_param_spec_enum ("default_display_align", "Default display alignment",
+          "Display alignment to use when the TTML file does not explicitly set one",
+          GST_TTML_DISPLAY_ALIGN_SPEC, GST_TTML_DISPLAY_ALIGN_BEFORE,
+          G_PARAM_READWRITE));
+  g_object_class_install_property (gobject_class, PROP_WINDOW_WIDTH,
+      g_param_spec_uint ("window-width", "Default window width",
+          "Default window width used when rendering", 0, 4096,
+          DEFAULT_WINDOW_WIDTH, G_PARAM_READWRITE));
+  g_object_class_install_property (gobject_class, PROP_WINDOW_HEIGHT,
+      g_param_spec_uint ("window-height", "Default window width",
+          "Default window height used when rendering", 0, 4096,
+          DEFAULT_WINDOW_HEIGHT, G_PARAM_READWRITE));
+
+  gst_element_class_add_pad_template (element_class,
+      gst_static_pad_template_get (&ttmlrender_src_template));
+  gst_element_class_set_details_simple (element_class, "TTML subtitle renderer",
+      "Codec/Decoder/Subtitle",
+      "Render TTML subtitle streams into a video stream (MI355X / HIP compositor)",
+      "fluttml-hip");
+
+  base_class->gen_buffer = gst_ttmlrender_gen_buffer;
+  base_class->fixate_caps = gst_ttmlrender_fixate_caps;
+  base_class->complete_caps = gst_ttmlrender_complete_caps;
+  base_class->src_setcaps = gst_ttmlrender_setcaps;
+  base_class->reset = gst_ttmlrender_reset;
+}
+
+static void
+gst_ttmlrender_init (GstTTMLRender *render)
+{
+  GstTTMLRenderPrivate *priv = get_priv (render);
+  static gsize registered = 0;
+  const gchar *dump;
+
+  if (g_once_init_enter (&registered)) {
+    hip_attr_klass[HIP_ATTR_OVERLINE].type = pango_attr_type_register ("Overline");
+    hip_attr_klass[HIP_ATTR_INVISIBLE].type =
+        pango_attr_type_register ("Invisibility");
+    hip_attr_klass[HIP_ATTR_REVERSE].type = pango_attr_type_register ("Reverse");
+    hip_attr_klass[HIP_ATTR_REVERSE_OBLIQUE].type =
+        pango_attr_type_register ("ReverseOblique");
+    g_once_init_leave (&registered, 1);
+  }
+
+  render->pango_context =
+      pango_font_map_create_context (pango_cairo_font_map_get_default ());
+  /* reference :1739: the instance default is "Serif" whatever the param spec says */
+  render->default_font_family = g_strdup ("Serif");
+  render->default_font_size = NULL;
+  render->window_width = DEFAULT_WINDOW_WIDTH;
+  render->window_height = DEFAULT_WINDOW_HEIGHT;
+  render->cached_images = NULL;
+  render->downloader = fludownloader_helper_downloader_new (NULL);
+
+  priv->rec = flutl_recorder_new ();
+  priv->ctx = NULL;
+  priv->ctx_failed = FALSE;
+  priv->images = NULL;
+  dump = g_getenv ("FLUTL_DUMP_PACK");
+  priv->dump = dump ? flutl_pack_writer_new (dump) : NULL;
+  priv->dump_only = g_getenv ("FLUTL_DUMP_ONLY") != NULL;
+}
