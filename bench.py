@@ -38,7 +38,9 @@ CONFIGS = {
 def load_states(cfg, n_states, stream_seed):
     """Returns list of (regions, prims) and one shared atlas for a stream."""
     import scene_pack
-    pack = scene_pack.find_pack(cfg, stream_seed)
+    pack = scene_pack.find_pack(cfg.split("_")[0], stream_seed)
+    if os.environ.get("FLUTL_BENCH_VARIANT"):
+        pack = None               # diagnosis variants use the synthetic generator
     if pack is not None:
         return pack.width, pack.height, pack.states(n_states), pack.atlas, pack.source
     import scenes

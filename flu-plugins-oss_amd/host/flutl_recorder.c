@@ -41,6 +41,14 @@ typedef struct
   int w, h;
 } ImageEntry;
 
+/* stroke masks are re-rasterised for every buffer (like the reference does),
+ * but an identical mask is stored in the atlas only once */
+typedef struct
+{
+  uint64_t hash;
+  uint32_t offset, bytes;
+} MaskEntry;
+
 struct FlutlRecorder
 {
   int width, height;
@@ -63,6 +71,8 @@ struct FlutlRecorder
   uint32_t glyph_cap, glyph_count;
   ImageEntry *images;
   uint32_t n_images, cap_images;
+  MaskEntry *masks;
+  uint32_t n_masks, cap_masks;
 
   int has_clip, clip[4];      /* x0,y0,x1,y1 */
   int in_group, group[4];
@@ -111,6 +121,42 @@ atlas_put (FlutlRecorder *rec, const void *src, size_t bytes)
   rec->new_size[rec->n_new] = (uint32_t) bytes;
   rec->n_new++;
   return (uint32_t) off;
+}
+
+static uint64_t
+hash_bytes (const uint8_t *p, size_t n)
+{
+  uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t) n;
+  size_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t v;
+    memcpy (&v, p + i, 8);
+    h = (h ^ v) * 0x100000001b3ull;
+    h ^= h >> 29;
+  }
+  for (; i < n; i++)
+    h = (h ^ p[i]) * 0x100000001b3ull;
+  return h;
+}
+
+static uint32_t
+atlas_put_dedup (FlutlRecorder *rec, const uint8_t *src, size_t bytes)
+{
+  uint64_t h = hash_bytes (src, bytes);
+  for (uint32_t i = 0; i < rec->n_masks; i++)
+    if (rec->masks[i].hash == h && rec->masks[i].bytes == bytes &&
+        memcmp (rec->atlas + rec->masks[i].offset, src, bytes) == 0)
+      return rec->masks[i].offset;
+  if (rec->n_masks == rec->cap_masks) {
+    rec->cap_masks = rec->cap_masks ? rec->cap_masks * 2 : 64;
+    rec->masks = xrealloc (rec->masks, rec->cap_masks * sizeof (MaskEntry));
+  }
+  uint32_t off = atlas_put (rec, src, bytes);
+  rec->masks[rec->n_masks].hash = h;
+  rec->masks[rec->n_masks].offset = off;
+  rec->masks[rec->n_masks].bytes = (uint32_t) bytes;
+  rec->n_masks++;
+  return off;
 }
 
 static uint16_t
@@ -219,6 +265,7 @@ drop_caches (FlutlRecorder *rec)
   for (uint32_t i = 0; i < rec->n_images; i++)
     cairo_surface_destroy (rec->images[i].surface);
   rec->n_images = 0;
+  rec->n_masks = 0;
   rec->atlas_size = ATLAS_SLACK;
   if (rec->atlas)
     memset (rec->atlas, 0, rec->atlas_cap);
@@ -247,6 +294,7 @@ flutl_recorder_free (FlutlRecorder *rec)
   free (rec->new_off);
   free (rec->new_size);
   free (rec->images);
+  free (rec->masks);
   free (rec);
 }
 
@@ -679,7 +727,7 @@ flutl_recorder_stroke (FlutlRecorder *rec)
       abort ();
     for (int y = 0; y < h; y++)
       memcpy (tight + (size_t) y * w, data + (size_t) (y0 + y) * stride + x0, w);
-    uint32_t off = atlas_put (rec, tight, (size_t) w * h);
+    uint32_t off = atlas_put_dedup (rec, tight, (size_t) w * h);
     free (tight);
     flutl_prim *p = push_prim (rec);
     p->op = FLUTL_OP_MASK;

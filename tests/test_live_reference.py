@@ -1,0 +1,44 @@
+"""Where the reference plugin (oracle/_ref, built from /root/reference) and the
+GStreamer runtime of this image are present: re-render the fixtures LIVE and
+check that the committed goldens still are what the reference produces here,
+and that the fluttml-hip element still records the committed display lists.
+Skipped elsewhere."""
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import gstenv  # noqa: E402
+import scene_pack  # noqa: E402
+
+SCENES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "scenes", "*.ttml")))
+ids = [os.path.basename(s)[:-5] for s in SCENES]
+
+
+@pytest.mark.skipif(not gstenv.available(gstenv.REF_PLUGIN_DIR),
+                    reason="reference plugin / GStreamer runtime not present")
+@pytest.mark.parametrize("ttml", SCENES, ids=ids)
+def test_reference_still_produces_the_goldens(ttml):
+    z = np.load(ttml[:-5] + ".npz")
+    W, H = int(z["width"]), int(z["height"])
+    live = np.frombuffer(gstenv.render(gstenv.REF_PLUGIN_DIR, ttml, W, H),
+                         np.uint32).reshape(-1, H, W)
+    assert np.array_equal(live, z["frames"])
+
+
+@pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
+                    reason="fluttml-hip plugin / GStreamer runtime not present")
+@pytest.mark.parametrize("ttml", SCENES, ids=ids)
+def test_element_still_records_the_committed_lists(ttml, tmp_path):
+    z = np.load(ttml[:-5] + ".npz")
+    W, H = int(z["width"]), int(z["height"])
+    pk = scene_pack.load(gstenv.dump_pack(ttml, W, H, str(tmp_path / "p.flpk")))
+    st = pk.states()
+    assert len(st) == int(z["n_states"])
+    for i, (R, P) in enumerate(st):
+        assert np.array_equal(R, z[f"regions{i}"]) and np.array_equal(P, z[f"prims{i}"])
+    assert np.array_equal(pk.atlas, z["atlas"])
