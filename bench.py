@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one batch of input: `--batch` (default
-1) overlay frames, each a DISTINCT scene state, composited by one launch of the
+8) overlay frames, each a DISTINCT scene state, composited by ONE launch of the
 tile kernel from display lists + glyph atlas already resident in HBM into a
 ring of device frames larger than the 256 MiB Infinity Cache.  At N>1 every
 rank renders its own independent stream (weak scaling, no data-path
@@ -75,14 +75,29 @@ def load_states(cfg, n_states, stream_seed):
                              else "synthetic-generator:" + variant)
 
 
+def profiled_traffic(cfg, batch):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this very
+    command (profiles/<round>_<cfg>_b<batch>_summary.json, tools/profile_gpu.sh):
+    WRITE_SIZE (exact for 16-byte stores) + FETCH_SIZE (raw: uncalibrated for the
+    4-byte mask reads).  None if that configuration has not been profiled."""
+    import glob
+    pat = os.path.join(ROOT, "profiles", f"r*_{cfg.split('_')[0]}_b{batch}_summary.json")
+    files = sorted(glob.glob(pat))
+    if not files:
+        return None
+    t = json.load(open(files[-1])).get("hbm_traffic_bytes_per_launch")
+    return int(t["write"] + t["fetch_raw"]) if t else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", default="cfg2_2160p_8regions_outline",
                     choices=sorted(CONFIGS))
-    ap.add_argument("--batch", type=int, default=1, help="frames per launch")
+    ap.add_argument("--batch", type=int, default=8,
+                    help="frames (distinct scene states) per launch = per step")
     ap.add_argument("--states", type=int, default=32, help="distinct scene states")
     ap.add_argument("--ring", type=int, default=0, help="output frames in the ring")
     ap.add_argument("--gather", action="store_true",
@@ -94,6 +109,7 @@ def main():
     import torch.distributed as dist
     import pyflutl as F
     import scenes
+    import streams
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -105,7 +121,9 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus or world == 1
 
-    W, H, states, atlas, source = load_states(args.config, args.states, 20 + rank)
+    # one independent stream per rank (weak scaling); no data-path collective
+    my_streams = streams.streams_of_rank(world, rank, world)
+    W, H, states, atlas, source = load_states(args.config, args.states, 20 + my_streams[0])
     n_states = len(states)
     B = args.batch
     frame_bytes = W * H * 4
@@ -135,27 +153,21 @@ def main():
         n_desc_steps = min(max(n_desc_steps, 1), 4096)
         descs = np.zeros(n_desc_steps * B, F.FRAME_DTYPE)
         for s in range(n_desc_steps):
-            for j in range(B):
-                st = (s * B + j) % n_states
+            for j, st in enumerate(streams.state_schedule(n_states, rank, s, B, world)):
                 descs[s * B + j] = (r_first[st], r_count[st],
                                     ((s * B + j) % ring) * frame_bytes)
         D_dev = dev(descs)
     stream = torch.cuda.current_stream().cuda_stream
-    gather_buf = None
-    if args.gather and world > 1 and rank == 0:
-        gather_buf = [torch.empty(frame_bytes, dtype=torch.uint8, device="cuda")
-                      for _ in range(world)]
 
     def step(s):
         if B == 1:
-            st = s % n_states
+            st = streams.state_schedule(n_states, rank, s, 1, world)[0]
             slot = s % ring
             F.launch_frame(stream, W, H, out.data_ptr() + slot * frame_bytes,
                            R_dev.data_ptr() + r_first[st] * 16, r_count[st],
                            P_dev, A_dev)
             if args.gather and world > 1:
-                fr = out[slot * frame_bytes:(slot + 1) * frame_bytes]
-                dist.gather(fr, gather_buf, dst=0)
+                streams.gather_frames(out[slot * frame_bytes:(slot + 1) * frame_bytes])
         else:
             ds = s % n_desc_steps
             F.launch_batch(stream, W, H, out, D_dev.data_ptr() + ds * B * 16, B,
@@ -163,8 +175,7 @@ def main():
             if args.gather and world > 1:
                 for j in range(B):
                     slot = (ds * B + j) % ring
-                    dist.gather(out[slot * frame_bytes:(slot + 1) * frame_bytes],
-                                gather_buf, dst=0)
+                    streams.gather_frames(out[slot * frame_bytes:(slot + 1) * frame_bytes])
 
     def barrier():
         if world > 1:
@@ -179,10 +190,7 @@ def main():
         step(args.warmup + s)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = streams.max_over_ranks(elapsed, torch.device("cuda"))
 
     # ---- per-launch kernel duration (HIP events on the launch stream) ------
     kern_ms = None
@@ -235,6 +243,7 @@ def main():
                          "kernel_ms": round(kern_ms, 5),
                          "algorithmic_bytes_per_launch": int(mean_alg * B)},
         }
+        res["roofline"]["traffic"] = profiled_traffic(args.config, B)
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import cpu_baseline
