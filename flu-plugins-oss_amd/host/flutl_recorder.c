@@ -49,6 +49,26 @@ typedef struct
   uint32_t offset, bytes;
 } MaskEntry;
 
+/* a piece of a pending outline path, with the CTM it is issued under */
+typedef struct
+{
+  PangoFont *font;           /* glyph outline if set, else a rectangle */
+  PangoGlyphInfo gi;
+  double x, y, w, h;
+  cairo_matrix_t m;
+} PathOp;
+
+typedef struct
+{
+  uint64_t hash;
+  uint8_t *key;
+  size_t key_len;
+  int base_x, base_y;        /* integer base the key is relative to */
+  int translatable;
+  uint32_t offset;           /* atlas offset of the tight A8 mask */
+  int x, y, w, h;            /* device box of the mask at (base_x, base_y) */
+} StrokeEntry;
+
 struct FlutlRecorder
 {
   int width, height;
@@ -73,6 +93,10 @@ struct FlutlRecorder
   uint32_t n_images, cap_images;
   MaskEntry *masks;
   uint32_t n_masks, cap_masks;
+  PathOp *ops;
+  uint32_t n_ops, cap_ops;
+  StrokeEntry *strokes;
+  uint32_t n_strokes, cap_strokes;
 
   int has_clip, clip[4];      /* x0,y0,x1,y1 */
   int in_group, group[4];
@@ -266,6 +290,9 @@ drop_caches (FlutlRecorder *rec)
     cairo_surface_destroy (rec->images[i].surface);
   rec->n_images = 0;
   rec->n_masks = 0;
+  for (uint32_t i = 0; i < rec->n_strokes; i++)
+    free (rec->strokes[i].key);
+  rec->n_strokes = 0;
   rec->atlas_size = ATLAS_SLACK;
   if (rec->atlas)
     memset (rec->atlas, 0, rec->atlas_cap);
@@ -295,6 +322,11 @@ flutl_recorder_free (FlutlRecorder *rec)
   free (rec->new_size);
   free (rec->images);
   free (rec->masks);
+  for (uint32_t i = 0; i < rec->n_ops; i++)
+    if (rec->ops[i].font)
+      g_object_unref (rec->ops[i].font);
+  free (rec->ops);
+  free (rec->strokes);
   free (rec);
 }
 
@@ -323,6 +355,10 @@ flutl_recorder_begin_frame (FlutlRecorder *rec, int width, int height)
   rec->frame_clear = 1;
   rec->group_clear = 1;
   rec->unsupported = 0;
+  for (uint32_t i = 0; i < rec->n_ops; i++)
+    if (rec->ops[i].font)
+      g_object_unref (rec->ops[i].font);
+  rec->n_ops = 0;
   flutl_recorder_set_color (rec, 0, 0, 0, 1);
 }
 
@@ -678,24 +714,155 @@ flutl_recorder_show_glyph (FlutlRecorder *rec, PangoFont *font,
   p->d = oy;
 }
 
-/* ---- strokes --------------------------------------------------------------- */
+/* ---- strokes ---------------------------------------------------------------
+ * Outline paths are not built eagerly.  The walker hands over the pieces of
+ * the path (glyph outlines, rectangles) together with the CTM each piece is
+ * issued under; at stroke time the pieces + line width form a key into a cache
+ * of coverage masks that lives across buffers.  Only on a miss is the path
+ * really built on the tracking context (by the very calls the reference makes:
+ * pango_cairo_glyph_string_path / cairo_rectangle) and stroked, once, onto the
+ * scratch A8 surface.  The reference re-strokes every outline for every
+ * buffer (gstttmlrender.c:1343-1355); that is >90 % of its time on outlined
+ * scenes.
+ *
+ * A mask is valid at any integer translation of the path (device coordinates
+ * are 24.8 fixed point, so an integer shift moves every vertex exactly), as
+ * long as the stroke was not cut by the borders of the scratch surface. */
+
+static void
+path_ops_clear (FlutlRecorder *rec)
+{
+  for (uint32_t i = 0; i < rec->n_ops; i++)
+    if (rec->ops[i].font)
+      g_object_unref (rec->ops[i].font);
+  rec->n_ops = 0;
+}
+
+static PathOp *
+path_op_push (FlutlRecorder *rec)
+{
+  if (rec->n_ops == rec->cap_ops) {
+    rec->cap_ops = rec->cap_ops ? rec->cap_ops * 2 : 128;
+    rec->ops = xrealloc (rec->ops, rec->cap_ops * sizeof (PathOp));
+  }
+  PathOp *op = &rec->ops[rec->n_ops++];
+  memset (op, 0, sizeof *op);
+  cairo_get_matrix (rec->cr, &op->m);
+  return op;
+}
 
 void
-flutl_recorder_stroke (FlutlRecorder *rec)
+flutl_recorder_path_glyph (FlutlRecorder *rec, PangoFont *font,
+    const PangoGlyphInfo *gi)
+{
+  PathOp *op = path_op_push (rec);
+  op->font = g_object_ref (font);
+  op->gi = *gi;
+}
+
+void
+flutl_recorder_path_rect (FlutlRecorder *rec, double x, double y, double w, double h)
+{
+  PathOp *op = path_op_push (rec);
+  op->x = x;
+  op->y = y;
+  op->w = w;
+  op->h = h;
+}
+
+/* Serialise what determines the coverage mask, relative to an integer base. */
+static size_t
+stroke_key (FlutlRecorder *rec, double line_width, int base_x, int base_y,
+    uint8_t **out)
+{
+  size_t per = 8 * sizeof (double) + 2 * sizeof (uint64_t);
+  size_t n = sizeof (double) + rec->n_ops * per;
+  uint8_t *k = malloc (n), *p = k;
+  if (!k)
+    abort ();
+  memcpy (p, &line_width, sizeof (double));
+  p += sizeof (double);
+  for (uint32_t i = 0; i < rec->n_ops; i++) {
+    const PathOp *op = &rec->ops[i];
+    double d[8] = { op->m.x0 - base_x, op->m.y0 - base_y, op->m.xx, op->m.yy,
+      op->x, op->y, op->w, op->h };
+    uint64_t u[2] = { 0, 0 };
+    if (op->font) {
+      u[0] = (uint64_t) (uintptr_t) pango_cairo_font_get_scaled_font (
+          (PangoCairoFont *) op->font);
+      u[1] = ((uint64_t) op->gi.glyph << 32) ^
+          ((uint64_t) (uint32_t) op->gi.geometry.x_offset << 16) ^
+          (uint64_t) (uint32_t) op->gi.geometry.y_offset;
+      d[4] = op->gi.geometry.x_offset;
+      d[5] = op->gi.geometry.y_offset;
+    }
+    memcpy (p, d, sizeof d);
+    p += sizeof d;
+    memcpy (p, u, sizeof u);
+    p += sizeof u;
+  }
+  *out = k;
+  return n;
+}
+
+static void
+stroke_emit (FlutlRecorder *rec, const StrokeEntry *e, int dx, int dy)
+{
+  if (e->w == 0)
+    return;
+  int ox = e->x + dx, oy = e->y + dy;
+  int x0 = ox, y0 = oy, x1 = ox + e->w, y1 = oy + e->h;
+  if (!clip_box (rec, &x0, &y0, &x1, &y1))
+    return;
+  flutl_prim *p = push_prim (rec);
+  p->op = FLUTL_OP_MASK;
+  p->rule = (rec->color_opaque || target_is_clear (rec))
+      ? FLUTL_RULE_LERP : FLUTL_RULE_PIXMAN;
+  p->cx0 = (int16_t) x0;
+  p->cy0 = (int16_t) y0;
+  p->cx1 = (int16_t) x1;
+  p->cy1 = (int16_t) y1;
+  p->color = rec->pixel;
+  p->a = (int32_t) e->offset;
+  p->b = e->w;
+  p->c = ox;
+  p->d = oy;
+}
+
+/* Build the pending path for real, stroke it and cut the coverage out of the
+ * scratch surface.  Returns 0 if the stroke touched the surface borders (the
+ * mask is then only valid at this very position). */
+static int
+stroke_rasterise (FlutlRecorder *rec, StrokeEntry *e)
 {
   cairo_t *cr = rec->cr;
+  cairo_new_path (cr);
+  for (uint32_t i = 0; i < rec->n_ops; i++) {
+    const PathOp *op = &rec->ops[i];
+    cairo_save (cr);
+    cairo_set_matrix (cr, &op->m);
+    if (op->font) {
+      PangoGlyphInfo gi = op->gi;
+      PangoGlyphString one = { 1, &gi, NULL, 1 };
+      pango_cairo_glyph_string_path (cr, op->font, &one);
+    } else {
+      cairo_rectangle (cr, op->x, op->y, op->w, op->h);
+    }
+    cairo_restore (cr);
+  }
   double ex1, ey1, ex2, ey2;
+  cairo_save (cr);
+  cairo_identity_matrix (cr);            /* extents in device space */
   cairo_stroke_extents (cr, &ex1, &ey1, &ex2, &ey2);
-  cairo_user_to_device (cr, &ex1, &ey1);
-  cairo_user_to_device (cr, &ex2, &ey2);
-  if (ex2 < ex1) { double t = ex1; ex1 = ex2; ex2 = t; }
-  if (ey2 < ey1) { double t = ey1; ey1 = ey2; ey2 = t; }
+  cairo_restore (cr);
+  int inside = ex1 >= 3 && ey1 >= 3 && ex2 <= rec->width - 3 && ey2 <= rec->height - 3;
   int bx0 = imax ((int) floor (ex1) - 2, 0), by0 = imax ((int) floor (ey1) - 2, 0);
   int bx1 = imin ((int) ceil (ex2) + 2, rec->width);
   int by1 = imin ((int) ceil (ey2) + 2, rec->height);
-  if (rec->color_clear || bx1 <= bx0 || by1 <= by0) {
+  e->w = e->h = 0;
+  if (bx1 <= bx0 || by1 <= by0) {
     cairo_new_path (cr);
-    return;
+    return inside;
   }
   /* coverage = what the stroker + scan converter hand to the span renderer */
   cairo_save (cr);
@@ -708,47 +875,89 @@ flutl_recorder_stroke (FlutlRecorder *rec)
   int tx0 = bx1, ty0 = by1, tx1 = -1, ty1 = -1;
   for (int y = by0; y < by1; y++) {
     const uint8_t *row = data + (size_t) y * stride;
+    int first = -1, last = -1;
     for (int x = bx0; x < bx1; x++)
       if (row[x]) {
-        if (x < tx0) tx0 = x;
-        if (x > tx1) tx1 = x;
-        if (y < ty0) ty0 = y;
-        if (y > ty1) ty1 = y;
+        if (first < 0)
+          first = x;
+        last = x;
       }
+    if (first >= 0) {
+      if (first < tx0) tx0 = first;
+      if (last > tx1) tx1 = last;
+      if (y < ty0) ty0 = y;
+      ty1 = y;
+    }
   }
   if (tx1 < tx0)
+    return inside;
+  int w = tx1 - tx0 + 1, h = ty1 - ty0 + 1;
+  uint8_t *tight = malloc ((size_t) w * h);
+  if (!tight)
+    abort ();
+  for (int y = 0; y < h; y++) {
+    memcpy (tight + (size_t) y * w, data + (size_t) (ty0 + y) * stride + tx0, w);
+    memset (data + (size_t) (ty0 + y) * stride + tx0, 0, (size_t) w);
+  }
+  cairo_surface_mark_dirty_rectangle (rec->scratch, tx0, ty0, w, h);
+  e->offset = atlas_put_dedup (rec, tight, (size_t) w * h);
+  free (tight);
+  e->x = tx0;
+  e->y = ty0;
+  e->w = w;
+  e->h = h;
+  return inside;
+}
+
+void
+flutl_recorder_stroke (FlutlRecorder *rec)
+{
+  if (rec->n_ops == 0)
     return;
-  int x0 = tx0, y0 = ty0, x1 = tx1 + 1, y1 = ty1 + 1;
-  int visible = clip_box (rec, &x0, &y0, &x1, &y1);
-  if (visible) {
-    int w = x1 - x0, h = y1 - y0;
-    uint8_t *tight = malloc ((size_t) w * h);
-    if (!tight)
-      abort ();
-    for (int y = 0; y < h; y++)
-      memcpy (tight + (size_t) y * w, data + (size_t) (y0 + y) * stride + x0, w);
-    uint32_t off = atlas_put_dedup (rec, tight, (size_t) w * h);
-    free (tight);
-    flutl_prim *p = push_prim (rec);
-    p->op = FLUTL_OP_MASK;
-    p->rule = (rec->color_opaque || target_is_clear (rec))
-        ? FLUTL_RULE_LERP : FLUTL_RULE_PIXMAN;
-    p->cx0 = (int16_t) x0;
-    p->cy0 = (int16_t) y0;
-    p->cx1 = (int16_t) x1;
-    p->cy1 = (int16_t) y1;
-    p->color = rec->pixel;
-    p->a = (int32_t) off;
-    p->b = w;
-    p->c = x0;
-    p->d = y0;
+  if (rec->color_clear) {
+    path_ops_clear (rec);
+    return;
+  }
+  for (uint32_t i = 0; i < rec->n_ops; i++) {
+    const cairo_matrix_t *m = &rec->ops[i].m;
+    if (m->xx != 1.0 || m->yy != 1.0 || m->xy != 0.0 || m->yx != 0.0) {
+      rec->unsupported++;   /* rotated writing modes: not implemented yet */
+      path_ops_clear (rec);
+      return;
+    }
+  }
+  double lw = cairo_get_line_width (rec->cr);
+  int base_x = (int) floor (rec->ops[0].m.x0), base_y = (int) floor (rec->ops[0].m.y0);
+  uint8_t *key;
+  size_t key_len = stroke_key (rec, lw, base_x, base_y, &key);
+  uint64_t h = hash_bytes (key, key_len);
+  StrokeEntry *hit = NULL;
+  for (uint32_t i = 0; i < rec->n_strokes && !hit; i++) {
+    StrokeEntry *e = &rec->strokes[i];
+    if (e->hash == h && e->key_len == key_len && memcmp (e->key, key, key_len) == 0 &&
+        (e->translatable || (e->base_x == base_x && e->base_y == base_y)))
+      hit = e;
+  }
+  if (hit) {
+    free (key);
+    stroke_emit (rec, hit, base_x - hit->base_x, base_y - hit->base_y);
+  } else {
+    if (rec->n_strokes == rec->cap_strokes) {
+      rec->cap_strokes = rec->cap_strokes ? rec->cap_strokes * 2 : 32;
+      rec->strokes = xrealloc (rec->strokes, rec->cap_strokes * sizeof (StrokeEntry));
+    }
+    StrokeEntry *e = &rec->strokes[rec->n_strokes++];
+    memset (e, 0, sizeof *e);
+    e->hash = h;
+    e->key = key;
+    e->key_len = key_len;
+    e->base_x = base_x;
+    e->base_y = base_y;
+    e->translatable = stroke_rasterise (rec, e);
+    stroke_emit (rec, e, 0, 0);
   }
   target_touched (rec);
-  /* clear what the stroke left in the scratch surface */
-  for (int y = ty0; y <= ty1; y++)
-    memset (data + (size_t) y * stride + tx0, 0, (size_t) (tx1 - tx0 + 1));
-  cairo_surface_mark_dirty_rectangle (rec->scratch, tx0, ty0, tx1 - tx0 + 1,
-      ty1 - ty0 + 1);
+  path_ops_clear (rec);
 }
 
 /* ---- images ---------------------------------------------------------------- */

@@ -66,7 +66,15 @@ void flutl_recorder_fill_rect (FlutlRecorder *rec, double x, double y, double w,
 void flutl_recorder_show_glyph (FlutlRecorder *rec, PangoFont *font,
     const PangoGlyphInfo *gi);
 
-/* cairo_stroke of the tracking context's current path with its line width
+/* Outline pass (:1153-1154, :1053-1092 with render == FALSE): the pieces of the
+ * path, each under the tracking context's current CTM.  They are only turned
+ * into a real Cairo path if the stroke-mask cache misses. */
+void flutl_recorder_path_glyph (FlutlRecorder *rec, PangoFont *font,
+    const PangoGlyphInfo *gi);
+void flutl_recorder_path_rect (FlutlRecorder *rec, double x, double y, double w,
+    double h);
+
+/* cairo_stroke of the pending path with the tracking context's line width
  * (:1212, and the intermediate strokes of show_layout in path mode). */
 void flutl_recorder_stroke (FlutlRecorder *rec);
 

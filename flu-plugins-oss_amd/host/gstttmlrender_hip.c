@@ -601,7 +601,7 @@ rect_or_path (FlutlRecorder *rec, gboolean fill, double x, double y, double w,
   if (fill) {
     flutl_recorder_fill_rect (rec, x, y, w, h);
   } else {
-    cairo_rectangle (flutl_recorder_cairo (rec), x, y, w, h);
+    flutl_recorder_path_rect (rec, x, y, w, h);
     flutl_recorder_stroke (rec);
   }
 }
@@ -738,10 +738,7 @@ walk_layout (GstTTMLRender *render, PangoLayout *layout, gboolean fill,
           if (fill) {
             flutl_recorder_show_glyph (rec, run->item->analysis.font, gi);
           } else {
-            PangoGlyphString one = *gs;
-            one.num_glyphs = 1;
-            one.glyphs = gi;
-            pango_cairo_glyph_string_path (cr, run->item->analysis.font, &one);
+            flutl_recorder_path_glyph (rec, run->item->analysis.font, gi);
           }
           cairo_restore (cr);
           cairo_translate (cr, gi->geometry.width / (double) PANGO_SCALE, 0);

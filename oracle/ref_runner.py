@@ -40,35 +40,51 @@ def _frames_in(ttml_path):
     return None
 
 
-def measure_reference(config, W, H, budget_s=40.0):
+def _push_times(plugin_dir, ttml, W, H):
+    """wall-clock times (s) at which the base class pushed each buffer:
+    GST_DEBUG=ttmlbase:5 "Pushing buffer" lines (gstttmlbase.c:183-191)"""
+    import subprocess
     import gstenv
+    env = gstenv.env_for(plugin_dir, {"GST_DEBUG": "ttmlbase:5", "GST_DEBUG_NO_COLOR": "1"})
+    cmd = [os.path.join(gstenv.CONDA, "bin", "gst-launch-1.0"), "-q", "filesrc",
+           f"location={ttml}", "!", "ttmlrender", "!",
+           f"video/x-raw,width={W},height={H}", "!", "fakesink"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr[-2000:])
+    times = []
+    for line in r.stderr.split("\n"):
+        if "Pushing buffer of" in line:
+            h, m, sec = line.split()[0].split(":")
+            times.append(int(h) * 3600 + int(m) * 60 + float(sec))
+    return times
+
+
+def measure_reference(config, W, H, plugin_dir=None):
+    """frames/s = (N - 1) / (t_last_push - t_first_push): start-up, plugin scan,
+    XML parse and the first buffer are excluded."""
+    import gstenv
+    plugin_dir = plugin_dir or gstenv.REF_PLUGIN_DIR
     cfg = CFG_OF.get(config, config)
     ttml = os.path.join(ROOT, "bench_data", cfg + ".ttml")
-    if not (gstenv.available(gstenv.REF_PLUGIN_DIR) and os.path.exists(ttml)):
+    if not (gstenv.available(plugin_dir) and os.path.exists(ttml)):
         return None
-    n = _frames_in(ttml)
-    if not n:
+    _push_times(plugin_dir, ttml, W, H)          # warm file/font caches
+    t = _push_times(plugin_dir, ttml, W, H)
+    if len(t) < 3:
         return None
-    with tempfile.NamedTemporaryFile("w", suffix=".ttml", delete=False) as f:
-        f.write(ONE_STATE)
-        one = f.name
-    try:
-        gstenv.render(gstenv.REF_PLUGIN_DIR, one, W, H, sink="fakesink")  # warm caches
-        t0 = time.perf_counter()
-        gstenv.render(gstenv.REF_PLUGIN_DIR, one, W, H, sink="fakesink")
-        t_start = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        gstenv.render(gstenv.REF_PLUGIN_DIR, ttml, W, H, sink="fakesink")
-        t_all = time.perf_counter() - t0
-    finally:
-        os.unlink(one)
-    n0 = 2   # the one-interval document yields 2 buffers (interval + trailing clear)
-    fps = (n - n0) / max(t_all - t_start, 1e-9)
-    return {"value": round(fps, 3), "unit": "frames/s", "cores": 1, "kind": "reference",
-            "sample": f"{n} buffers of bench_data/{cfg}.ttml at {W}x{H} through the "
-                      f"reference's ttmlrender (oracle/_ref, cairo 1.16.0/pango 1.45.3) "
-                      f"! fakesink; {t_all:.2f} s wall minus {t_start:.2f} s start-up"}
+    fps = (len(t) - 1) / max(t[-1] - t[0], 1e-9)
+    who = ("the reference's ttmlrender (oracle/_ref, cairo 1.16.0 / pango 1.45.3)"
+           if plugin_dir == gstenv.REF_PLUGIN_DIR else "the fluttml-hip ttmlrender element")
+    return {"value": round(fps, 3), "unit": "frames/s", "cores": 1,
+            "kind": "reference" if plugin_dir == gstenv.REF_PLUGIN_DIR else "element",
+            "sample": f"{len(t)} buffers of bench_data/{cfg}.ttml at {W}x{H} through {who} "
+                      f"! fakesink, push-to-push {t[-1] - t[0]:.3f} s (first buffer and "
+                      f"start-up excluded)"}
 
 
 if __name__ == "__main__":
-    print(measure_reference(sys.argv[1], int(sys.argv[2]), int(sys.argv[3])))
+    import gstenv
+    which = sys.argv[4] if len(sys.argv) > 4 else "ref"
+    print(measure_reference(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]),
+                            plugin_dir=gstenv.HIP_PLUGIN_DIR if which == "hip" else None))
