@@ -86,6 +86,14 @@ extern "C" int flutl_list_validate (uint32_t width, uint32_t height,
         return FLUTL_EINVAL;
       if (p.rule != FLUTL_RULE_PIXMAN && p.rule != FLUTL_RULE_LERP)
         return FLUTL_EINVAL;
+      if (p.op == FLUTL_OP_RECT || p.op == FLUTL_OP_MASK) {
+        // the kernel relies on a valid premultiplied colour (channel <= alpha):
+        // it is what makes its non-saturating adds exact
+        const uint32_t a = p.color >> 24;
+        if (((p.color >> 16) & 255u) > a || ((p.color >> 8) & 255u) > a ||
+            (p.color & 255u) > a)
+          return FLUTL_EINVAL;
+      }
       switch (p.op) {
         case FLUTL_OP_RECT:
           if (p.a > p.c || p.b > p.d)

@@ -181,24 +181,63 @@ __device__ __forceinline__ PrimU prim_load (const flutl_prim *prims, uint32_t id
   return p;
 }
 
-// Pixel state is kept packed (one a8r8g8b8 dword per pixel); blends unpack to
-// 2 x (2 x u16).
-template <bool LERP>
-__device__ __forceinline__ void px_blend (uint32_t &t, Px s, uint32_t m)
+// The strip's 4 pixels per lane are kept UNPACKED (rb / ag, 2 x 16 bit each):
+// a primitive then costs no unpack/pack, only the final store packs.
+
+// splat byte k of w into both 16-bit lanes: {w.k, 0, w.k, 0} (one v_perm_b32)
+template <int K>
+__device__ __forceinline__ u16x2 splat_byte (uint32_t w)
 {
-  Px v = unpack (t);
-  if (LERP)
-    blend_lerp (v, s, m);
-  else
-    blend_pixman (v, s, m);
-  t = pack (v);
+  return as_u16x2 (__builtin_amdgcn_perm (0u, w, 0x0c000c00u | (uint32_t) K | ((uint32_t) K << 16)));
 }
 
-__device__ __forceinline__ void px_over (uint32_t &t, Px s)
+// (solid s IN m) OVER t, pixman rule, for a VALIDATED premultiplied colour
+// (every channel <= alpha, checked by flutl_list_validate): then
+// s*m + t*(255 - sa*m) cannot exceed 255 and the saturating add is not needed.
+//   OPAQUE: alpha(s) == 255, so alpha(s IN m) == m and 255 - m == 255 ^ m.
+template <bool OPAQUE, int K>
+__device__ __forceinline__ void px_pixman (Px &t, Px s, uint32_t w)
 {
-  Px v = unpack (t);
-  over (v, s);
-  t = pack (v);
+  const u16x2 mm = splat_byte<K> (w);
+  const u16x2 sm_rb = mul_un8 (s.rb, mm);
+  const u16x2 sm_ag = mul_un8 (s.ag, mm);
+  u16x2 ia;
+  if (OPAQUE)
+    ia = as_u16x2 (as_u32 (mm) ^ 0x00ff00ffu);
+  else   // {a, 0, a, 0} from byte 2 of sm_ag, then 255 - a
+    ia = as_u16x2 (0x00ff00ffu - __builtin_amdgcn_perm (0u, as_u32 (sm_ag), 0x0c020c02u));
+  t.rb = sm_rb + mul_un8 (t.rb, ia);
+  t.ag = sm_ag + mul_un8 (t.ag, ia);
+}
+
+// cairo in-place lerp (0x7f rounding); mul_7f (255, m) == m, so the sum never
+// exceeds 255 either.  RB_ZERO: the colour has no red/blue (black outlines).
+template <bool RB_ZERO, int K>
+__device__ __forceinline__ void px_lerp (Px &t, Px s, uint32_t w)
+{
+  const u16x2 mm = splat_byte<K> (w);
+  const u16x2 im = as_u16x2 (as_u32 (mm) ^ 0x00ff00ffu);
+  if (RB_ZERO)
+    t.rb = mul_7f (t.rb, im);
+  else
+    t.rb = mul_7f (s.rb, mm) + mul_7f (t.rb, im);
+  t.ag = mul_7f (s.ag, mm) + mul_7f (t.ag, im);
+}
+
+template <bool LERP, bool FLAG>
+__device__ __forceinline__ void strip_blend (Px (&t)[4], Px s, uint32_t w)
+{
+  if (LERP) {
+    px_lerp<FLAG, 0> (t[0], s, w);
+    px_lerp<FLAG, 1> (t[1], s, w);
+    px_lerp<FLAG, 2> (t[2], s, w);
+    px_lerp<FLAG, 3> (t[3], s, w);
+  } else {
+    px_pixman<FLAG, 0> (t[0], s, w);
+    px_pixman<FLAG, 1> (t[1], s, w);
+    px_pixman<FLAG, 2> (t[2], s, w);
+    px_pixman<FLAG, 3> (t[3], s, w);
+  }
 }
 
 // The 4 A8 coverage bytes of a MASK primitive for this lane's 4 pixels on row
@@ -232,7 +271,10 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
   __shared__ uint32_t s_cnt[2][2];         // [chunk parity][wave] hit counts
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  // wave-uniform, and the compiler must know it: everything derived from it
+  // (this wave's rows, the per-prim row tests) then stays on the scalar unit
+  const int wave = __builtin_amdgcn_readfirstlane (tid >> 6);
 
   // Blocks b and b+8 share an XCD (and its L2): XCD k gets the k-th contiguous
   // band of supertiles, so the glyph masks and display-list entries of a band
@@ -275,7 +317,10 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
     // t = the surface being painted: the frame, or -- between GROUP_BEGIN and
     // GROUP_END -- the region's group surface, while the frame pixels are
     // parked in a lane-private LDS slot (no barrier: a lane reads its own).
-    uint32_t t[4] = { 0u, 0u, 0u, 0u };
+    Px t[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      t[k] = unpack (0u);
 
     const bool refill = r == 0 || !single_round;
     // cursor over (hit regions) x (128-prim chunks)
@@ -373,10 +418,10 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
             continue;
 
           if (p.op == FLUTL_OP_GROUP_BEGIN) {
-            s_park[tid] = make_uint4 (t[0], t[1], t[2], t[3]);
+            s_park[tid] = make_uint4 (pack (t[0]), pack (t[1]), pack (t[2]), pack (t[3]));
 #pragma unroll
             for (int k = 0; k < 4; k++)
-              t[k] = 0;
+              t[k] = unpack (0u);
             continue;
           }
 
@@ -403,16 +448,18 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
                 // coverage 255 on the whole strip: t = s OVER t with a uniform
                 // s.  Opaque s, or nothing painted yet: t = s exactly
                 // (MUL_UN8 (t, 0) == 0, MUL_UN8 (0, ia) == 0) under both rules.
+                const Px sc = unpack (p.color);
                 if ((p.color >> 24) == 255u || p.rule == FLUTL_RULE_LERP ||
-                    __ballot ((t[0] | t[1] | t[2] | t[3]) != 0) == 0) {
+                    __ballot ((as_u32 (t[0].rb) | as_u32 (t[0].ag) | as_u32 (t[1].rb) |
+                            as_u32 (t[1].ag) | as_u32 (t[2].rb) | as_u32 (t[2].ag) |
+                            as_u32 (t[3].rb) | as_u32 (t[3].ag)) != 0) == 0) {
 #pragma unroll
                   for (int k = 0; k < 4; k++)
-                    t[k] = p.color;
+                    t[k] = sc;
                 } else {
-                  const Px sc = unpack (p.color);
 #pragma unroll
                   for (int k = 0; k < 4; k++)
-                    px_over (t[k], sc);
+                    over (t[k], sc);
                 }
                 continue;
               }
@@ -429,13 +476,15 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
               continue;
             const Px s = unpack (p.color);
             if (p.rule == FLUTL_RULE_LERP) {
-#pragma unroll
-              for (int k = 0; k < 4; k++)
-                px_blend<true> (t[k], s, (w >> (8 * k)) & 0xffu);
+              if ((p.color & 0x00ff00ffu) == 0u)
+                strip_blend<true, true> (t, s, w);
+              else
+                strip_blend<true, false> (t, s, w);
             } else {
-#pragma unroll
-              for (int k = 0; k < 4; k++)
-                px_blend<false> (t[k], s, (w >> (8 * k)) & 0xffu);
+              if ((p.color >> 24) == 255u)
+                strip_blend<false, true> (t, s, w);
+              else
+                strip_blend<false, false> (t, s, w);
             }
           } else {
             // ---- per-pixel premultiplied source, OVER: IMAGE / GROUP_END ----
@@ -447,11 +496,11 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
               const uint4 dd = s_park[tid];
 #pragma unroll
               for (int k = 0; k < 4; k++)
-                sv[k] = ((pmask >> (8 * k)) & 1u) ? t[k] : 0u;
-              t[0] = dd.x;
-              t[1] = dd.y;
-              t[2] = dd.z;
-              t[3] = dd.w;
+                sv[k] = ((pmask >> (8 * k)) & 1u) ? pack (t[k]) : 0u;
+              t[0] = unpack (dd.x);
+              t[1] = unpack (dd.y);
+              t[2] = unpack (dd.z);
+              t[3] = unpack (dd.w);
             } else if (rowin) {
               const uint32_t rowoff = (uint32_t) p.a +
                   (uint32_t) (y - p.d) * (uint32_t) p.b + (uint32_t) (x - p.c) * 4u;
@@ -471,7 +520,7 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
                 sp.rb = mul_un8 (sp.rb, al);
                 sp.ag = mul_un8 (sp.ag, al);
               }
-              px_over (t[k], sp);
+              over (t[k], sp);
             }
           }
         }
@@ -482,10 +531,12 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
     if (x < (int) fp.width && y < (int) fp.height) {
       uint8_t *out = dst + dst_off + (size_t) y * fp.stride + (size_t) x * 4;
       if (x + 4 <= (int) fp.width && ((reinterpret_cast<uintptr_t> (out) & 15) == 0)) {
-        *reinterpret_cast<uint4 *> (out) = make_uint4 (t[0], t[1], t[2], t[3]);
+        *reinterpret_cast<uint4 *> (out) =
+            make_uint4 (pack (t[0]), pack (t[1]), pack (t[2]), pack (t[3]));
       } else {
+        const uint32_t tv[4] = { pack (t[0]), pack (t[1]), pack (t[2]), pack (t[3]) };
         for (int k = 0; k < 4 && x + k < (int) fp.width; k++)
-          reinterpret_cast<uint32_t *> (out)[k] = t[k];
+          reinterpret_cast<uint32_t *> (out)[k] = tv[k];
       }
     }
   }
