@@ -106,6 +106,8 @@ extern "C" int flutl_list_validate (uint32_t width, uint32_t height,
             return FLUTL_EINVAL;
           if (p.op == FLUTL_OP_IMAGE && ((p.a & 3) || (p.b & 3)))
             return FLUTL_EINVAL;
+          if (p.op == FLUTL_OP_MASK && (p.param & ~FLUTL_MASK_XCLIP))
+            return FLUTL_EINVAL;
           if (p.cx0 == p.cx1 || p.cy0 == p.cy1)
             break;
           if (p.cx0 < p.c || p.cy0 < p.d)

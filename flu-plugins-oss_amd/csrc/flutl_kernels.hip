@@ -242,20 +242,34 @@ __device__ __forceinline__ void strip_blend (Px (&t)[4], Px s, uint32_t w)
 
 // The 4 A8 coverage bytes of a MASK primitive for this lane's 4 pixels on row
 // y.  Issued one primitive ahead of use: OVER is order dependent, the loads
-// are not.
+// are not.  Branch free: lanes that the prim does not touch load the first
+// (slack) dword of the atlas and discard it, so no EXEC juggling is needed.
+// Bytes left/right of the mask read its zero padding (atlas contract).
 __device__ __forceinline__ uint32_t mask_fetch (const PrimU &p,
     const uint8_t *__restrict__ atlas, int x, int y)
 {
-  uint32_t w = 0;
-  if (p.op == FLUTL_OP_MASK && x < p.cx1 && x + 4 > p.cx0 && y >= p.cy0 && y < p.cy1) {
-    // 4 consecutive A8 bytes at an arbitrary byte address.  The validated list
-    // keeps this window inside the atlas allocation (16 bytes of slack on both
-    // sides); bytes outside the bbox are masked off by the caller.
-    const uint32_t off = (uint32_t) p.a + (uint32_t) (y - p.d) * (uint32_t) p.b +
-        (uint32_t) (x - p.c);
-    __builtin_memcpy (&w, atlas + off, 4);
-  }
-  return w;
+  if (p.op != FLUTL_OP_MASK)    // wave uniform
+    return 0u;
+  const bool valid = (uint32_t) (y - p.cy0) < (uint32_t) (p.cy1 - p.cy0) &&
+      (uint32_t) (x + 3 - p.cx0) < (uint32_t) (p.cx1 - p.cx0 + 3);
+  // rows and strides are < 2^15: 24-bit multiply-add (full rate)
+  const uint32_t off = __umul24 ((uint32_t) (y - p.d), (uint32_t) p.b) +
+      (uint32_t) (p.a - p.c) + (uint32_t) x;
+  uint32_t w;
+  __builtin_memcpy (&w, atlas + (valid ? off : 0u), 4);
+  return valid ? w : 0u;
+}
+
+// Per-lane pixel predicates as a byte mask over the lane's 4 pixels, by
+// unsigned range checks and shifts (VALU only: compare + s_and chains on
+// 64-bit lane masks would load the scalar unit instead).
+__device__ __forceinline__ uint32_t pixel_mask (const PrimU &p, int x, bool rowin)
+{
+  const int klo = min (max (p.cx0 - x, 0), 4);   // first pixel inside
+  const int khi = min (max (p.cx1 - x, 0), 4);   // one past the last
+  const uint32_t mlo = (uint32_t) ((1ull << (8 * klo)) - 1ull);
+  const uint32_t mhi = (uint32_t) ((1ull << (8 * khi)) - 1ull);
+  return rowin ? (mhi & ~mlo) : 0u;
 }
 
 constexpr uint32_t kListCap = 512;     // prim indices per replay round (2 KiB)
@@ -425,15 +439,7 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
             continue;
           }
 
-          // per-lane pixel predicates as a byte mask over the lane's 4 pixels,
-          // by unsigned range checks and shifts (VALU only: compare + s_and
-          // chains on 64-bit lane masks would load the scalar unit instead)
           const bool rowin = (uint32_t) (y - p.cy0) < (uint32_t) (p.cy1 - p.cy0);
-          const int klo = min (max (p.cx0 - x, 0), 4);   // first pixel inside
-          const int khi = min (max (p.cx1 - x, 0), 4);   // one past the last
-          const uint32_t mlo = (uint32_t) ((1ull << (8 * klo)) - 1ull);
-          const uint32_t mhi = (uint32_t) ((1ull << (8 * khi)) - 1ull);
-          const uint32_t pmask = rowin ? (mhi & ~mlo) : 0u;
 
           if (p.op == FLUTL_OP_RECT || p.op == FLUTL_OP_MASK) {
             // ---- solid colour through an 8-bit coverage --------------------
@@ -470,7 +476,8 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
               for (int k = 0; k < 4; k++)
                 w |= min ((uint32_t) (overlap256 (p.a, p.c, x + k) * oy) >> 8, 255u) << (8 * k);
             }
-            w &= pmask;
+            if (p.op == FLUTL_OP_RECT || (p.param & FLUTL_MASK_XCLIP))
+              w &= pixel_mask (p, x, rowin);
             // wave-level early out: nothing lands in this strip
             if (__ballot (w != 0) == 0)
               continue;
@@ -489,6 +496,7 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
           } else {
             // ---- per-pixel premultiplied source, OVER: IMAGE / GROUP_END ----
             const bool is_end = p.op == FLUTL_OP_GROUP_END;
+            const uint32_t pmask = pixel_mask (p, x, rowin);
             uint32_t sv[4] = { 0u, 0u, 0u, 0u };
             if (is_end) {
               // the group surface is what was painted since GROUP_BEGIN; swap

@@ -183,6 +183,24 @@ atlas_put_dedup (FlutlRecorder *rec, const uint8_t *src, size_t bytes)
   return off;
 }
 
+/* Store a tight w x h A8 bitmap the way the kernel wants to read it: 4 zero
+ * bytes in front of the first row, every row followed by 4 zero bytes (stride
+ * w + 4).  Returns the atlas offset of mask pixel (0,0). */
+#define MASK_PAD 4
+static uint32_t
+atlas_put_mask (FlutlRecorder *rec, const uint8_t *tight, int w, int h, int dedup)
+{
+  size_t stride = (size_t) w + MASK_PAD, bytes = MASK_PAD + stride * h;
+  uint8_t *buf = calloc (1, bytes);
+  if (!buf)
+    abort ();
+  for (int y = 0; y < h; y++)
+    memcpy (buf + MASK_PAD + y * stride, tight + (size_t) y * w, (size_t) w);
+  uint32_t off = dedup ? atlas_put_dedup (rec, buf, bytes) : atlas_put (rec, buf, bytes);
+  free (buf);
+  return off + MASK_PAD;
+}
+
 static uint16_t
 color_double_to_short (double d)
 {
@@ -635,7 +653,7 @@ glyph_rasterise (FlutlRecorder *rec, cairo_scaled_font_t *sf, GlyphEntry *e)
       abort ();
     for (int y = 0; y < th; y++)
       memcpy (tight + (size_t) y * tw, data + (size_t) (ty0 + y) * stride + tx0, tw);
-    e->offset = atlas_put (rec, tight, (size_t) tw * th);
+    e->offset = atlas_put_mask (rec, tight, tw, th, 0);
     free (tight);
     e->w = tw;
     e->h = th;
@@ -708,8 +726,9 @@ flutl_recorder_show_glyph (FlutlRecorder *rec, PangoFont *font,
   p->cx1 = (int16_t) x1;
   p->cy1 = (int16_t) y1;
   p->color = rec->pixel;
+  p->param = (x0 > ox || x1 < ox + e->w) ? FLUTL_MASK_XCLIP : 0;
   p->a = (int32_t) e->offset;
-  p->b = e->w;
+  p->b = e->w + MASK_PAD;
   p->c = ox;
   p->d = oy;
 }
@@ -823,8 +842,9 @@ stroke_emit (FlutlRecorder *rec, const StrokeEntry *e, int dx, int dy)
   p->cx1 = (int16_t) x1;
   p->cy1 = (int16_t) y1;
   p->color = rec->pixel;
+  p->param = (x0 > ox || x1 < ox + e->w) ? FLUTL_MASK_XCLIP : 0;
   p->a = (int32_t) e->offset;
-  p->b = e->w;
+  p->b = e->w + MASK_PAD;
   p->c = ox;
   p->d = oy;
 }
@@ -900,7 +920,7 @@ stroke_rasterise (FlutlRecorder *rec, StrokeEntry *e)
     memset (data + (size_t) (ty0 + y) * stride + tx0, 0, (size_t) w);
   }
   cairo_surface_mark_dirty_rectangle (rec->scratch, tx0, ty0, w, h);
-  e->offset = atlas_put_dedup (rec, tight, (size_t) w * h);
+  e->offset = atlas_put_mask (rec, tight, w, h, 1);
   free (tight);
   e->x = tx0;
   e->y = ty0;

@@ -54,7 +54,15 @@ extern "C" {
                                  * pango_cairo_show_glyph_string (:1150, one glyph)
                                  * and cairo_stroke of the outline path (:1212).
                                  * a = atlas byte offset, b = row stride (bytes),
-                                 * c,d = destination x,y of mask pixel (0,0).     */
+                                 * c,d = destination x,y of mask pixel (0,0).
+                                 * Atlas contract: every mask row is followed by
+                                 * >= 3 zero bytes and the first row preceded by
+                                 * >= 3 zero bytes, so that the kernel's 4-byte
+                                 * windows read 0 left and right of the mask; if
+                                 * [cx0,cx1) is narrower than the mask rows (the
+                                 * clip cut it) set FLUTL_MASK_XCLIP in param and
+                                 * the kernel masks the columns itself.           */
+#define FLUTL_MASK_XCLIP     1u /* param bit of a MASK prim, see above             */
 #define FLUTL_OP_IMAGE       3u /* premultiplied ARGB32 image in the atlas, OVER:
                                  * replaces set_source_surface+paint (:1272-1275)
                                  * and the blurred-outline blit (:1219-1224).
@@ -75,7 +83,7 @@ extern "C" {
 typedef struct flutl_prim {
   uint8_t  op;     /* FLUTL_OP_*                                              */
   uint8_t  rule;   /* FLUTL_RULE_*                                            */
-  uint16_t param;  /* GROUP_END: 8-bit group alpha; else 0                    */
+  uint16_t param;  /* GROUP_END: 8-bit group alpha; MASK: FLUTL_MASK_XCLIP  */
   int16_t  cx0, cy0, cx1, cy1; /* destination bbox [cx0,cx1) x [cy0,cy1) in px,
                                 * already intersected with clip, group surface
                                 * and frame; nothing is touched outside it     */

@@ -113,16 +113,20 @@ def random_scene(seed, width, height, n_regions=6, prims_per_region=24,
                 mw = int(rng.integers(3, 200 if big else 40))
                 mh = int(rng.integers(3, 60 if big else 40))
                 m = _blob_mask(rng, mw, mh)
-                stride = mw + int(rng.integers(0, 5))
+                # atlas contract: >= 3 zero bytes before the first row and after
+                # every row, unless the prim carries MASK_XCLIP
+                padded = rng.random() < 0.7
+                stride = mw + (int(rng.integers(3, 7)) if padded else int(rng.integers(0, 3)))
                 buf = np.zeros((mh, stride), np.uint8)
                 buf[:, :mw] = m
-                off = atlas.put(buf, lead=int(rng.integers(0, 4)))
+                off = atlas.put(buf, lead=int(rng.integers(3, 7)) if padded else int(rng.integers(0, 3)))
                 ox = int(rng.integers(clip[0] - mw // 2, clip[2]))
                 oy = int(rng.integers(clip[1] - mh // 2, clip[3]))
                 bb = _clip(ox, oy, ox + mw, oy + mh, clip)
                 col = _premul(rng)
                 rule = F.RULE_LERP if (col >> 24) == 255 and rng.random() < 0.5 else F.RULE_PIXMAN
-                add(F.OP_MASK, rule, bb, col, off, stride, ox, oy)
+                xclip = (not padded) or bb[0] > ox or bb[2] < ox + mw or rng.random() < 0.2
+                add(F.OP_MASK, rule, bb, col, off, stride, ox, oy, param=1 if xclip else 0)
             else:              # ARGB image
                 iw, ih = int(rng.integers(2, 50)), int(rng.integers(2, 20))
                 img = np.array([[_premul(rng) if rng.random() < 0.8 else 0
@@ -156,8 +160,9 @@ def subtitle_like_scene(seed, width, height, n_regions=8, font_px=None,
     alphabet = []
     for _ in range(40):
         w = int(rng.integers(max(2, gw // 2), gw + 1))
-        m = _blob_mask(rng, w, font_px)
-        alphabet.append((atlas.put(m), w))
+        m = np.zeros((font_px, w + 4), np.uint8)
+        m[:, :w] = _blob_mask(rng, w, font_px)
+        alphabet.append((atlas.put(m, lead=4), w))
     prims, regions = [], []
     rw = int(width * 0.8) // 4 * 4
     rh = min(int(lines * font_px * 1.15) + 8, height // max(1, n_regions))
@@ -190,22 +195,26 @@ def subtitle_like_scene(seed, width, height, n_regions=8, font_px=None,
                 ow, oh = ox1 - ox0, font_px + 2 * outline_px
                 om = np.zeros((oh, ow), np.uint8)
                 for (gx, off, w) in xs:
-                    g = np.frombuffer(bytes(atlas.buf[off:off + w * font_px]),
-                                      np.uint8).reshape(font_px, w)
+                    g = np.frombuffer(bytes(atlas.buf[off:off + (w + 4) * font_px]),
+                                      np.uint8).reshape(font_px, w + 4)[:, :w]
                     for dy in range(0, 2 * outline_px + 1, max(1, outline_px)):
                         for dx in range(0, 2 * outline_px + 1, max(1, outline_px)):
                             sub = om[dy:dy + font_px, gx - ox0 - outline_px + dx:
                                      gx - ox0 - outline_px + dx + w]
                             np.maximum(sub, g[:sub.shape[0], :sub.shape[1]], out=sub)
-                ooff = atlas.put(om)
+                omp = np.zeros((oh, ow + 4), np.uint8)
+                omp[:, :ow] = om
+                ooff = atlas.put(omp, lead=4)
                 bb = _clip(ox0, ly - outline_px, ox1, ly - outline_px + oh, box)
                 if bb[2] > bb[0] and bb[3] > bb[1]:
-                    prims.append((F.OP_MASK, F.RULE_LERP, 0, *bb, 0xff000000, ooff, ow,
+                    xc = 1 if (bb[0] > ox0 or bb[2] < ox1) else 0
+                    prims.append((F.OP_MASK, F.RULE_LERP, xc, *bb, 0xff000000, ooff, ow + 4,
                                   ox0, ly - outline_px))
             for (gx, off, w) in xs:
                 bb = _clip(gx, ly, gx + w, ly + font_px, box)
                 if bb[2] > bb[0] and bb[3] > bb[1]:
-                    prims.append((F.OP_MASK, F.RULE_PIXMAN, 0, *bb, text_col, off, w, gx, ly))
+                    xc = 1 if (bb[0] > gx or bb[2] < gx + w) else 0
+                    prims.append((F.OP_MASK, F.RULE_PIXMAN, xc, *bb, text_col, off, w + 4, gx, ly))
         if grouped:
             prims.append((F.OP_GROUP_END, 0, int(rng.integers(100, 200)), *box, 0, 0, 0, 0, 0))
         regions.append((*box, first, len(prims) - first))
