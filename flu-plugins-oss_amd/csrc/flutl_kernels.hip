@@ -34,7 +34,7 @@ namespace {
 
 typedef unsigned short u16x2 __attribute__ ((ext_vector_type (2)));
 
-constexpr int kThreads = 128;          // 2 wavefronts of 64
+constexpr int kThreads = 64;           // one wavefront per workgroup
 constexpr int kChunk = kThreads;       // prims binned per round
 
 // ---- packed 2 x 16-bit channel arithmetic ---------------------------------
@@ -139,8 +139,7 @@ struct FrameParams {
 // instruction of a wave writes four 256-byte row segments.
 constexpr int kSuperW = FLUTL_TILE_W;        // 64
 constexpr int kRG = 4;                       // row groups per wave
-constexpr int kSuperH = 2 * 4 * kRG;         // 2 waves x kRG x 4 rows
-constexpr int kWaveH = 4 * kRG;              // 16 rows per wave
+constexpr int kSuperH = 4 * kRG;             // kRG strips of 4 rows
 
 // A primitive held wave-uniformly in SGPRs.  The bin list in LDS holds prim
 // INDICES; the 32-byte primitive itself is fetched with scalar loads (the
@@ -282,13 +281,11 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
 {
   __shared__ uint32_t s_list[kListCap];    // binned prim indices, paint order
   __shared__ uint4 s_park[kThreads];       // frame pixels parked during a group
-  __shared__ uint32_t s_cnt[2][2];         // [chunk parity][wave] hit counts
 
+  // One wavefront per workgroup: no barrier anywhere, nothing shared between
+  // waves; LDS is only the wave's own bin list and park slots.
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  // wave-uniform, and the compiler must know it: everything derived from it
-  // (this wave's rows, the per-prim row tests) then stays on the scalar unit
-  const int wave = __builtin_amdgcn_readfirstlane (tid >> 6);
+  const int lane = tid;
 
   // Blocks b and b+8 share an XCD (and its L2): XCD k gets the k-th contiguous
   // band of supertiles, so the glyph masks and display-list entries of a band
@@ -312,7 +309,7 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
   }
 
   const int sx0 = (int) stx * kSuperW, sy0 = (int) sty * kSuperH;
-  const int wy0 = sy0 + wave * kWaveH;          // this wave's first row
+  const int wy0 = sy0;                          // this wave's first row
   const int x = sx0 + (lane & 15) * 4;
   const int y_lane = wy0 + (lane >> 4);         // row in row group 0
 
@@ -322,7 +319,6 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
   // re-bin in rounds (correct, slower; pathological lists only).
   uint32_t n_list = 0;
   bool single_round = true, first_fill = true;
-  uint32_t parity = 0;
 
 #pragma unroll 1
   for (int r = 0; r < kRG; r++) {
@@ -337,7 +333,7 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
       t[k] = unpack (0u);
 
     const bool refill = r == 0 || !single_round;
-    // cursor over (hit regions) x (128-prim chunks)
+    // cursor over (hit regions) x (64-prim chunks)
     uint32_t rbase = 0;                  // next batch of 64 regions to cull
     unsigned long long rmask = 0;        // hit regions of the current batch
     uint32_t rv_first = 0, rv_count = 0; // per lane: prim range of "my" region
@@ -347,8 +343,6 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
     do {
       if (refill) {
         // ======== fill: bin chunks into s_list until it could overflow ======
-        if (r != 0 || n_list != 0)
-          __syncthreads ();              // the other wave may still replay
         n_list = 0;
         for (;;) {
           if (pbase >= pcount) {         // current region exhausted
@@ -392,19 +386,13 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
           const bool hit = pi < pcount && cx0 < sx0 + kSuperW && cx1 > sx0 &&
               cy0 < sy0 + kSuperH && cy1 > sy0;
           const unsigned long long bal = __ballot (hit);
-          if (lane == 0)
-            s_cnt[parity][wave] = (uint32_t) __popcll (bal);
-          __syncthreads ();
-          const uint32_t c0 = s_cnt[parity][0], c1 = s_cnt[parity][1];
-          const uint32_t pos = n_list + (wave ? c0 : 0u) +
+          const uint32_t pos = n_list +
               (uint32_t) __popcll (bal & ((1ull << lane) - 1ull));
           if (hit)
             s_list[pos] = pidx;
-          n_list += c0 + c1;
-          parity ^= 1u;
+          n_list += (uint32_t) __popcll (bal);
           pbase += kChunk;
         }
-        __syncthreads ();                // s_list complete
         if (r == 0 && first_fill)
           single_round = done;           // everything fitted in one round?
         first_fill = false;
