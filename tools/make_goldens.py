@@ -72,26 +72,43 @@ def config(cfg):
         cfg, {"cfg0": 0, "cfg1": 1, "cfg2": 2, "cfg4": 4}[cfg]))
     pk = record(ttml, W, H)
     st = pk.states()
-    # reference frames -> SHA-256 (streamed through a file: up to tens of GB)
-    with tempfile.NamedTemporaryFile(suffix=".raw", dir="/tmp", delete=False) as t:
-        raw = t.name
-    try:
-        gstenv.render(gstenv.REF_PLUGIN_DIR, ttml, W, H, out_path=raw)
-        fb = W * H * 4
-        n = os.path.getsize(raw) // fb
-        assert n == len(st), (cfg, n, len(st))
-        keep = min(n, MAX_STATES[cfg])
-        shas, nz, bad = [], [], 0
-        with open(raw, "rb") as f:
-            for i in range(keep):
+    # reference frames -> SHA-256, streamed through a FIFO (cfg4 is 64 GB raw)
+    import threading
+    fb = W * H * 4
+    keep = min(len(st), MAX_STATES[cfg])
+    shas, nz, counts = [], [], {"n": 0, "bad": 0}
+    fifo = os.path.join(tempfile.mkdtemp(), "frames.fifo")
+    os.mkfifo(fifo)
+
+    def reader():
+        with open(fifo, "rb") as f:
+            while True:
                 buf = f.read(fb)
-                shas.append(hashlib.sha256(buf).hexdigest())
-                fr = np.frombuffer(buf, np.uint32).reshape(H, W)
-                nz.append(int((fr != 0).sum()))
-                if i < 4 or i == keep - 1:     # spot-check the oracle at full size
-                    bad += int((O.render(W, H, st[i][0], st[i][1], pk.atlas) != fr).sum())
+                while 0 < len(buf) < fb:
+                    more = f.read(fb - len(buf))
+                    if not more:
+                        break
+                    buf += more
+                if len(buf) < fb:
+                    break
+                i = counts["n"]
+                counts["n"] += 1
+                if i < keep:
+                    shas.append(hashlib.sha256(buf).hexdigest())
+                    fr = np.frombuffer(buf, np.uint32).reshape(H, W)
+                    nz.append(int((fr != 0).sum()))
+                    if i < 3 or i == keep - 1:   # spot-check the oracle at full size
+                        counts["bad"] += int((O.render(W, H, st[i][0], st[i][1], pk.atlas) != fr).sum())
+
+    th = threading.Thread(target=reader)
+    th.start()
+    try:
+        gstenv.render(gstenv.REF_PLUGIN_DIR, ttml, W, H, out_path=fifo)
     finally:
-        os.unlink(raw)
+        th.join()
+        os.unlink(fifo)
+    n, bad = counts["n"], counts["bad"]
+    assert n == len(st), (cfg, n, len(st))
     states = st[:keep]
     blob = zlib.compress(scene_pack.dumps(W, H, states, pk.atlas), 9)
     open(os.path.join(d, cfg + ".flpk.z"), "wb").write(blob)
