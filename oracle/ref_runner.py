@@ -47,9 +47,10 @@ def _push_times(plugin_dir, ttml, W, H):
     import gstenv
     env = gstenv.env_for(plugin_dir, {"GST_DEBUG": "ttmlbase:5", "GST_DEBUG_NO_COLOR": "1"})
     cmd = [os.path.join(gstenv.CONDA, "bin", "gst-launch-1.0"), "-q", "filesrc",
-           f"location={ttml}", "!", "ttmlrender", "!",
+           f"location={os.path.abspath(ttml)}", "!", "ttmlrender", "!",
            f"video/x-raw,width={W},height={H}", "!", "fakesink"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True,
+                       cwd=tempfile.gettempdir())
     if r.returncode != 0:
         raise RuntimeError(r.stderr[-2000:])
     times = []

@@ -54,10 +54,11 @@ def render(plugin_dir, ttml_path, width, height, out_path=None, extra_env=None,
         out_path = tmp.name
     sink_desc = f"filesink location={out_path}" if sink == "filesink" else "fakesink"
     cmd = [os.path.join(CONDA, "bin", "gst-launch-1.0"), "-q",
-           "filesrc", f"location={ttml_path}", "!", "ttmlrender", "!",
+           "filesrc", f"location={os.path.abspath(ttml_path)}", "!", "ttmlrender", "!",
            f"video/x-raw,width={width},height={height}", "!"] + sink_desc.split()
+    # cwd: the reference's base class can append an XML dump to ./ttml.xml
     r = subprocess.run(cmd, env=env_for(plugin_dir, extra_env), capture_output=True,
-                       text=True)
+                       text=True, cwd=tempfile.gettempdir())
     # Known bug of the reference's UNTOUCHED base class (it is in both plugins):
     # gst_ttml_state_save_data (gstttmlstate.c:440-443) reallocs the XML text
     # buffer that gstttmlbase.c still owns, so documents with embedded
