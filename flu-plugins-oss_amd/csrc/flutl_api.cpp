@@ -39,6 +39,8 @@ struct flutl_ctx {
   size_t atlas_used;   // bytes in use (incl. leading slack)
   void *frame;         // device staging frame for render_to_host
   size_t frame_cap;
+  void *listbuf;       // reusable device buffer for transient display lists
+  size_t listbuf_cap;
 };
 
 extern "C" int flutl_abi_version (void) { return FLUTL_ABI_VERSION; }
@@ -190,6 +192,8 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
   c->atlas_used = kAtlasSlack;
   c->frame = nullptr;
   c->frame_cap = 0;
+  c->listbuf = nullptr;
+  c->listbuf_cap = 0;
   *out = c;
   return FLUTL_OK;
 }
@@ -204,6 +208,8 @@ extern "C" void flutl_ctx_destroy (flutl_ctx *c)
     (void) hipFree (c->atlas);
   if (c->frame)
     (void) hipFree (c->frame);
+  if (c->listbuf)
+    (void) hipFree (c->listbuf);
   (void) hipStreamDestroy (c->stream);
   delete c;
 }
@@ -279,6 +285,24 @@ extern "C" size_t flutl_atlas_size (const flutl_ctx *c)
   return c ? c->atlas_used + kAtlasSlack : 0;
 }
 
+extern "C" int flutl_host_alloc (size_t bytes, void **out)
+{
+  if (!out || bytes == 0)
+    return FLUTL_EINVAL;
+  *out = nullptr;
+  int n = 0;
+  if (!hip_ok (hipGetDeviceCount (&n)) || n == 0)
+    return FLUTL_ENODEV;
+  return hip_ok (hipHostMalloc (out, bytes, hipHostMallocPortable)) ? FLUTL_OK
+                                                                     : FLUTL_ENOMEM;
+}
+
+extern "C" void flutl_host_free (void *ptr)
+{
+  if (ptr)
+    (void) hipHostFree (ptr);
+}
+
 extern "C" int flutl_list_create (flutl_ctx *c, uint32_t width, uint32_t height,
     const flutl_region *regions, uint32_t n_regions, const flutl_prim *prims,
     uint32_t n_prims, flutl_list **out)
@@ -347,12 +371,71 @@ extern "C" int flutl_render (flutl_ctx *c, const flutl_list *l, void *dst_dev,
       dst_stride_bytes, l->regions, l->n_regions, l->prims, c->atlas);
 }
 
+static int render_lists_to_host (flutl_ctx *c, uint32_t width, uint32_t height,
+    const flutl_region *regions_dev, uint32_t n_regions, const flutl_prim *prims_dev,
+    void *dst_host, size_t dst_stride_bytes);
+
+extern "C" int flutl_render_frame_to_host (flutl_ctx *c, uint32_t width,
+    uint32_t height, const flutl_region *regions, uint32_t n_regions,
+    const flutl_prim *prims, uint32_t n_prims, void *dst_host,
+    size_t dst_stride_bytes)
+{
+  if (!c || !dst_host || dst_stride_bytes < (size_t) width * 4)
+    return FLUTL_EINVAL;
+  int rc = flutl_list_validate (width, height, regions, n_regions, prims, n_prims,
+      c->atlas_used + kAtlasSlack);
+  if (rc)
+    return rc;
+  (void) hipSetDevice (c->device);
+  const size_t rb = ((size_t) n_regions * sizeof (flutl_region) + 31) & ~(size_t) 31;
+  const size_t pb = (size_t) n_prims * sizeof (flutl_prim);
+  if (rb + pb + 32 > c->listbuf_cap) {
+    if (c->listbuf) {
+      (void) hipStreamSynchronize (c->stream);
+      (void) hipFree (c->listbuf);
+      c->listbuf = nullptr;
+      c->listbuf_cap = 0;
+    }
+    size_t cap = (size_t) 1 << 16;
+    while (cap < rb + pb + 32)
+      cap *= 2;
+    if (!hip_ok (hipMalloc (&c->listbuf, cap)))
+      return FLUTL_ENOMEM;
+    c->listbuf_cap = cap;
+  }
+  flutl_region *rd = static_cast<flutl_region *> (c->listbuf);
+  flutl_prim *pd = reinterpret_cast<flutl_prim *> (static_cast<uint8_t *> (c->listbuf) + rb);
+  bool ok = true;
+  if (n_regions)
+    ok = ok && hip_ok (hipMemcpyAsync (rd, regions, (size_t) n_regions * sizeof (flutl_region),
+        hipMemcpyHostToDevice, c->stream));
+  if (n_prims)
+    ok = ok && hip_ok (hipMemcpyAsync (pd, prims, pb, hipMemcpyHostToDevice, c->stream));
+  if (!ok)
+    return FLUTL_ENODEV;
+  // (the final stream synchronise below also covers the H2D of the caller's
+  // pageable list memory, which hipMemcpyAsync stages before returning)
+  return render_lists_to_host (c, width, height, rd, n_regions, pd, dst_host,
+      dst_stride_bytes);
+}
+
 extern "C" int flutl_render_to_host (flutl_ctx *c, const flutl_list *l,
     void *dst_host, size_t dst_stride_bytes)
 {
   if (!c || !l || !dst_host || dst_stride_bytes < (size_t) l->width * 4)
     return FLUTL_EINVAL;
   (void) hipSetDevice (c->device);
+  return render_lists_to_host (c, l->width, l->height, l->regions, l->n_regions,
+      l->prims, dst_host, dst_stride_bytes);
+}
+
+static int render_lists_to_host (flutl_ctx *c, uint32_t width, uint32_t height,
+    const flutl_region *regions_dev, uint32_t n_regions, const flutl_prim *prims_dev,
+    void *dst_host, size_t dst_stride_bytes)
+{
+  struct { uint32_t width, height, n_regions; const flutl_region *regions;
+    const flutl_prim *prims; } lv = { width, height, n_regions, regions_dev, prims_dev };
+  const auto *l = &lv;
   const size_t tight = (size_t) l->width * 4;
   const size_t need = tight * l->height;
   if (need > c->frame_cap) {

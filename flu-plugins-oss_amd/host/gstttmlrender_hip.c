@@ -64,9 +64,94 @@ enum
   PROP_WINDOW_HEIGHT
 };
 
+/* Pool of page-locked output frames.  Blocks are wrapped as GstMemory; when
+ * downstream drops the buffer the block comes back here.  The pool is
+ * reference counted because buffers may outlive the element. */
+typedef struct
+{
+  gint refs;
+  GMutex lock;
+  gsize block_size;
+  GPtrArray *free_blocks;
+} FramePool;
+
+typedef struct
+{
+  FramePool *pool;
+  gpointer block;
+  gsize size;
+} FrameBlock;
+
+static FramePool *
+frame_pool_new (void)
+{
+  FramePool *p = g_new0 (FramePool, 1);
+  p->refs = 1;
+  g_mutex_init (&p->lock);
+  p->free_blocks = g_ptr_array_new ();
+  return p;
+}
+
+static void
+frame_pool_unref (FramePool *p)
+{
+  if (!g_atomic_int_dec_and_test (&p->refs))
+    return;
+  for (guint i = 0; i < p->free_blocks->len; i++)
+    flutl_host_free (g_ptr_array_index (p->free_blocks, i));
+  g_ptr_array_free (p->free_blocks, TRUE);
+  g_mutex_clear (&p->lock);
+  g_free (p);
+}
+
+static void
+frame_block_release (gpointer data)
+{
+  FrameBlock *b = data;
+  FramePool *p = b->pool;
+  g_mutex_lock (&p->lock);
+  /* keep at most a few frames, and only of the current size */
+  if (b->size == p->block_size && p->free_blocks->len < 6)
+    g_ptr_array_add (p->free_blocks, b->block);
+  else
+    flutl_host_free (b->block);
+  g_mutex_unlock (&p->lock);
+  frame_pool_unref (p);
+  g_free (b);
+}
+
+/* A GstBuffer over a recycled page-locked block (system memory as far as
+ * downstream is concerned), or NULL if page-locked memory is unavailable. */
+static GstBuffer *
+frame_pool_acquire (FramePool *p, gsize size, gpointer *data)
+{
+  gpointer block = NULL;
+  FrameBlock *b;
+  g_mutex_lock (&p->lock);
+  if (p->block_size != size) {
+    for (guint i = 0; i < p->free_blocks->len; i++)
+      flutl_host_free (g_ptr_array_index (p->free_blocks, i));
+    g_ptr_array_set_size (p->free_blocks, 0);
+    p->block_size = size;
+  }
+  if (p->free_blocks->len)
+    block = g_ptr_array_remove_index_fast (p->free_blocks, p->free_blocks->len - 1);
+  g_mutex_unlock (&p->lock);
+  if (!block && flutl_host_alloc (size, &block) != FLUTL_OK)
+    return NULL;
+  b = g_new0 (FrameBlock, 1);
+  b->pool = p;
+  b->block = block;
+  b->size = size;
+  g_atomic_int_inc (&p->refs);
+  *data = block;
+  return gst_buffer_new_wrapped_full (0, block, size, 0, size, b, frame_block_release);
+}
+
 /* Device-side state of one element instance. */
 typedef struct
 {
+  FramePool *pool;
   FlutlRecorder *rec;
   flutl_ctx *ctx;            /* NULL until first use; stays NULL without a GPU */
   gboolean ctx_failed;
@@ -940,22 +1025,23 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
     }
   }
   {
-    flutl_list *list = NULL;
     GstMapInfo map;
-    int rc = flutl_list_create (priv->ctx, width, height, rg, n_rg, pr, n_pr, &list);
-    if (rc != FLUTL_OK) {
-      GST_ELEMENT_ERROR (render, LIBRARY, FAILED, ("ttmlrender: invalid display list"),
-          ("flutl_list_create: %s", flutl_strerror (rc)));
-      return NULL;
+    gpointer pinned = NULL;
+    int rc;
+    buffer = frame_pool_acquire (priv->pool, (gsize) width * height * 4, &pinned);
+    if (buffer) {
+      rc = flutl_render_frame_to_host (priv->ctx, width, height, rg, n_rg, pr, n_pr,
+          pinned, (size_t) width * 4);
+    } else {                    /* no page-locked memory: plain system buffer */
+      buffer = gst_buffer_new_and_alloc ((gsize) width * height * 4);
+      gst_buffer_map (buffer, &map, GST_MAP_WRITE);
+      rc = flutl_render_frame_to_host (priv->ctx, width, height, rg, n_rg, pr, n_pr,
+          map.data, (size_t) width * 4);
+      gst_buffer_unmap (buffer, &map);
     }
-    buffer = gst_buffer_new_and_alloc ((gsize) width * height * 4);
-    gst_buffer_map (buffer, &map, GST_MAP_WRITE);
-    rc = flutl_render_to_host (priv->ctx, list, map.data, (size_t) width * 4);
-    gst_buffer_unmap (buffer, &map);
-    flutl_list_destroy (priv->ctx, list);
     if (rc != FLUTL_OK) {
       GST_ELEMENT_ERROR (render, LIBRARY, FAILED, ("ttmlrender: HIP render failed"),
-          ("flutl_render_to_host: %s", flutl_strerror (rc)));
+          ("flutl_render_frame_to_host: %s", flutl_strerror (rc)));
       gst_buffer_unref (buffer);
       return NULL;
     }
@@ -1100,6 +1186,10 @@ gst_ttmlrender_dispose (GObject *object)
     flutl_recorder_free (priv->rec);
     priv->rec = NULL;
   }
+  if (priv->pool) {
+    frame_pool_unref (priv->pool);
+    priv->pool = NULL;
+  }
   g_clear_pointer (&render->default_font_family, g_free);
   g_clear_pointer (&render->default_font_size, g_free);
   g_clear_object (&render->pango_context);
@@ -1189,6 +1279,7 @@ gst_ttmlrender_init (GstTTMLRender *render)
   render->downloader = fludownloader_helper_downloader_new (NULL);
 
   priv->rec = flutl_recorder_new ();
+  priv->pool = frame_pool_new ();
   priv->ctx = NULL;
   priv->ctx_failed = FALSE;
   priv->images = NULL;

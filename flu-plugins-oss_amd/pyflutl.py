@@ -45,6 +45,7 @@ EXPORTS = [
     "flutl_atlas_put", "flutl_atlas_reset", "flutl_atlas_size",
     "flutl_list_create", "flutl_list_destroy",
     "flutl_render", "flutl_render_to_host",
+    "flutl_host_alloc", "flutl_host_free", "flutl_render_frame_to_host",
 ]
 
 
@@ -89,6 +90,10 @@ def lib():
         L.flutl_list_destroy.restype = None
         L.flutl_render.argtypes = [vp, vp, vp, sz]
         L.flutl_render_to_host.argtypes = [vp, vp, vp, sz]
+        L.flutl_render_frame_to_host.argtypes = [vp, u32, u32, vp, u32, vp, u32, vp, sz]
+        L.flutl_host_alloc.argtypes = [sz, ctypes.POINTER(vp)]
+        L.flutl_host_free.argtypes = [vp]
+        L.flutl_host_free.restype = None
         _lib = L
     return _lib
 
@@ -200,6 +205,32 @@ class Context:
         out = np.empty((height, width), np.uint32)
         _check(lib().flutl_render_to_host(self._h, lst, _np_ptr(out), width * 4),
                "flutl_render_to_host")
+        return out
+
+    def render_frame_to_host(self, width, height, regions, prims, pinned=True):
+        """the element's per-buffer call; with pinned=True the frame lands in
+        page-locked memory from flutl_host_alloc (as the element does)"""
+        regions = np.ascontiguousarray(regions, REGION_DTYPE)
+        prims = np.ascontiguousarray(prims, PRIM_DTYPE)
+        nbytes = width * height * 4
+        if pinned:
+            ptr = ctypes.c_void_p()
+            _check(lib().flutl_host_alloc(nbytes, ctypes.byref(ptr)), "flutl_host_alloc")
+            dst = ptr
+        else:
+            out = np.empty((height, width), np.uint32)
+            dst = _np_ptr(out)
+        try:
+            _check(lib().flutl_render_frame_to_host(
+                self._h, width, height, _np_ptr(regions), len(regions), _np_ptr(prims),
+                len(prims), dst, width * 4), "flutl_render_frame_to_host")
+            if pinned:
+                out = np.ctypeslib.as_array(
+                    ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint32)),
+                    shape=(height, width)).copy()
+        finally:
+            if pinned:
+                lib().flutl_host_free(ptr)
         return out
 
     def render(self, lst, dst_ptr, stride):

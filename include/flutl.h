@@ -191,6 +191,24 @@ int  flutl_render_to_host (flutl_ctx *ctx, const flutl_list *list,
     void *dst_host, size_t dst_stride_bytes);
 int  flutl_ctx_sync (flutl_ctx *ctx);
 
+/* The whole per-buffer device step in one call, with no allocation in steady
+ * state: validate the list, copy it into the context's reusable list buffer,
+ * composite, copy the frame to dst_host (page-locked memory from
+ * flutl_host_alloc makes that copy a plain DMA), wait.  This is what
+ * gst_ttmlrender_gen_buffer's Cairo section (gstttmlrender.c:1446-1477) becomes. */
+int  flutl_render_frame_to_host (flutl_ctx *ctx, uint32_t width, uint32_t height,
+    const flutl_region *regions, uint32_t n_regions,
+    const flutl_prim *prims, uint32_t n_prims,
+    void *dst_host, size_t dst_stride_bytes);
+
+/* Page-locked host memory for output frames: a D2H copy into it is a true
+ * asynchronous DMA at PCIe rate (pageable memory goes through a bounce buffer
+ * and takes page faults on first touch).  The element wraps such blocks as
+ * GstMemory and recycles them (the reference allocates a fresh system buffer
+ * per frame, gstttmlrender.c:1442-1443).  Not tied to a context's lifetime. */
+int  flutl_host_alloc (size_t bytes, void **out);
+void flutl_host_free (void *ptr);
+
 /* Library / device info (never fails; device_count 0 without a GPU). */
 int         flutl_abi_version (void);
 int         flutl_device_count (void);

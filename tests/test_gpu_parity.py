@@ -170,3 +170,24 @@ def test_full_size_properties(gpu, size):
     assert (got[~cover] == 0).all()
     if W <= 3840:
         assert np.array_equal(got, O.render(W, H, R, P, A))
+
+
+def test_context_render_frame_to_host_pinned_and_pageable(gpu):
+    """the element's per-buffer entry point, into page-locked and plain memory"""
+    W, H = 320, 180
+    R, P, A = scenes.random_scene(21, W, H)
+    exp = O.render(W, H, R, P, A)
+    with F.Context(0) as ctx:
+        ctx.atlas_put(A[F.ATLAS_SLACK:])
+        for pinned in (True, False, True):
+            got = ctx.render_frame_to_host(W, H, R, P, pinned=pinned)
+            assert np.array_equal(got, exp)
+        # a bigger list than the context's list buffer held so far
+        R2, P2, A2 = scenes.random_scene(77, W, H, n_regions=3, prims_per_region=3000,
+                                         fixed_count=True)
+        ctx.atlas_reset()
+        ctx.atlas_put(A2[F.ATLAS_SLACK:])
+        assert np.array_equal(ctx.render_frame_to_host(W, H, R2, P2), O.render(W, H, R2, P2, A2))
+        with pytest.raises(F.FlutlError):
+            bad = P2.copy(); bad["op"][0] = 99
+            ctx.render_frame_to_host(W, H, R2, bad)
