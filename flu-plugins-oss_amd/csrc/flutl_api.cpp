@@ -274,6 +274,71 @@ extern "C" int flutl_atlas_put (flutl_ctx *c, const void *src, size_t bytes,
   return FLUTL_OK;
 }
 
+static int upload_list (flutl_ctx *c, const flutl_region *regions, uint32_t n_regions,
+    const flutl_prim *prims, uint32_t n_prims, flutl_region **rd, flutl_prim **pd);
+
+extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
+    const flutl_region *regions, uint32_t n_regions, const flutl_prim *prims,
+    uint32_t n_prims, int radius, double sigma, void *host_copy, uint32_t *offset_out)
+{
+  if (!c || !offset_out || w == 0 || h == 0 || radius < 0 || radius > 16)
+    return FLUTL_EINVAL;
+  int rc = flutl_list_validate (w, h, regions, n_regions, prims, n_prims,
+      c->atlas_used + kAtlasSlack);
+  if (rc)
+    return rc;
+  (void) hipSetDevice (c->device);
+  const size_t tight = (size_t) w * 4, bytes = tight * h;
+  // reserve the atlas entry first: growing the atlas moves it
+  const size_t off = (c->atlas_used + kAtlasAlign - 1) & ~(kAtlasAlign - 1);
+  const size_t end = off + bytes;
+  if (end + kAtlasSlack > 0x7fffffffu)
+    return FLUTL_ERANGE;
+  if ((rc = atlas_reserve (c, end + kAtlasSlack)))
+    return rc;
+  // temporary surface in the context's staging frame
+  if (bytes > c->frame_cap) {
+    if (c->frame) {
+      (void) hipStreamSynchronize (c->stream);
+      (void) hipFree (c->frame);
+      c->frame = nullptr;
+      c->frame_cap = 0;
+    }
+    if (!hip_ok (hipMalloc (&c->frame, bytes)))
+      return FLUTL_ENOMEM;
+    c->frame_cap = bytes;
+  }
+  flutl_region *rd;
+  flutl_prim *pd;
+  if ((rc = upload_list (c, regions, n_regions, prims, n_prims, &rd, &pd)))
+    return rc;
+  if ((rc = flutl_launch_frame (c->stream, w, h, c->frame, tight, rd, n_regions, pd,
+           c->atlas)))
+    return rc;
+  // Gaussian weights: host -> small device buffer kept in the list buffer's tail
+  int32_t weights[33 * 33];
+  if ((rc = flutl_blur_kernel (radius, sigma, weights)))
+    return rc;
+  const size_t wbytes = (size_t) (2 * radius + 1) * (2 * radius + 1) * 4;
+  int32_t *wdev = nullptr;
+  if (!hip_ok (hipMalloc (reinterpret_cast<void **> (&wdev), wbytes)))
+    return FLUTL_ENOMEM;
+  bool ok = hip_ok (hipMemcpyAsync (wdev, weights, wbytes, hipMemcpyHostToDevice, c->stream));
+  if (ok)
+    ok = flutl_launch_blur (c->stream, c->frame, c->atlas + off, w, h, tight, wdev,
+        radius) == FLUTL_OK;
+  if (ok && host_copy)
+    ok = hip_ok (hipMemcpyAsync (host_copy, c->atlas + off, bytes, hipMemcpyDeviceToHost,
+        c->stream));
+  ok = hip_ok (hipStreamSynchronize (c->stream)) && ok;
+  (void) hipFree (wdev);
+  if (!ok)
+    return FLUTL_ENODEV;
+  c->atlas_used = end;
+  *offset_out = (uint32_t) off;
+  return FLUTL_OK;
+}
+
 extern "C" void flutl_atlas_reset (flutl_ctx *c)
 {
   if (c)
@@ -387,6 +452,20 @@ extern "C" int flutl_render_frame_to_host (flutl_ctx *c, uint32_t width,
   if (rc)
     return rc;
   (void) hipSetDevice (c->device);
+  flutl_region *rd;
+  flutl_prim *pd;
+  if ((rc = upload_list (c, regions, n_regions, prims, n_prims, &rd, &pd)))
+    return rc;
+  // (the final stream synchronise also covers the H2D of the caller's pageable
+  // list memory, which hipMemcpyAsync stages before returning)
+  return render_lists_to_host (c, width, height, rd, n_regions, pd, dst_host,
+      dst_stride_bytes);
+}
+
+/* Copy a (validated) display list into the context's reusable list buffer. */
+static int upload_list (flutl_ctx *c, const flutl_region *regions, uint32_t n_regions,
+    const flutl_prim *prims, uint32_t n_prims, flutl_region **rd_out, flutl_prim **pd_out)
+{
   const size_t rb = ((size_t) n_regions * sizeof (flutl_region) + 31) & ~(size_t) 31;
   const size_t pb = (size_t) n_prims * sizeof (flutl_prim);
   if (rb + pb + 32 > c->listbuf_cap) {
@@ -413,10 +492,9 @@ extern "C" int flutl_render_frame_to_host (flutl_ctx *c, uint32_t width,
     ok = ok && hip_ok (hipMemcpyAsync (pd, prims, pb, hipMemcpyHostToDevice, c->stream));
   if (!ok)
     return FLUTL_ENODEV;
-  // (the final stream synchronise below also covers the H2D of the caller's
-  // pageable list memory, which hipMemcpyAsync stages before returning)
-  return render_lists_to_host (c, width, height, rd, n_regions, pd, dst_host,
-      dst_stride_bytes);
+  *rd_out = rd;
+  *pd_out = pd;
+  return FLUTL_OK;
 }
 
 extern "C" int flutl_render_to_host (flutl_ctx *c, const flutl_list *l,

@@ -71,6 +71,7 @@ typedef struct
 
 struct FlutlRecorder
 {
+  FlutlRecorder *parent;      /* child recorders put their masks in the parent's atlas */
   int width, height;
   cairo_surface_t *scratch;   /* A8, width x height */
   cairo_t *cr;
@@ -121,8 +122,19 @@ xrealloc (void *p, size_t n)
 }
 
 static uint32_t
+atlas_put_ex (FlutlRecorder *rec, const void *src, size_t bytes, int on_device);
+
+static uint32_t
 atlas_put (FlutlRecorder *rec, const void *src, size_t bytes)
 {
+  return atlas_put_ex (rec, src, bytes, 0);
+}
+
+static uint32_t
+atlas_put_ex (FlutlRecorder *rec, const void *src, size_t bytes, int on_device)
+{
+  if (rec->parent)
+    return atlas_put_ex (rec->parent, src, bytes, on_device);
   size_t off = (rec->atlas_size + ATLAS_ALIGN - 1) & ~(size_t) (ATLAS_ALIGN - 1);
   size_t end = off + bytes;
   if (end + ATLAS_SLACK > rec->atlas_cap) {
@@ -136,6 +148,8 @@ atlas_put (FlutlRecorder *rec, const void *src, size_t bytes)
   memset (rec->atlas + rec->atlas_size, 0, off - rec->atlas_size);
   memcpy (rec->atlas + off, src, bytes);
   rec->atlas_size = end;
+  if (on_device)
+    return (uint32_t) off;      /* produced on the device: nothing to upload */
   if (rec->n_new == rec->cap_new) {
     rec->cap_new = rec->cap_new ? rec->cap_new * 2 : 64;
     rec->new_off = xrealloc (rec->new_off, rec->cap_new * sizeof (uint32_t));
@@ -293,6 +307,49 @@ flutl_recorder_new (void)
     abort ();
   rec->atlas_size = ATLAS_SLACK;
   return rec;
+}
+
+FlutlRecorder *
+flutl_recorder_new_child (FlutlRecorder *parent)
+{
+  FlutlRecorder *rec = flutl_recorder_new ();
+  rec->parent = parent;
+  return rec;
+}
+
+uint32_t
+flutl_recorder_next_atlas_offset (FlutlRecorder *rec)
+{
+  while (rec->parent)
+    rec = rec->parent;
+  return (uint32_t) ((rec->atlas_size + ATLAS_ALIGN - 1) & ~(size_t) (ATLAS_ALIGN - 1));
+}
+
+uint32_t
+flutl_recorder_atlas_append_device_entry (FlutlRecorder *rec, const void *data,
+    size_t bytes)
+{
+  return atlas_put_ex (rec, data, bytes, 1);
+}
+
+void
+flutl_recorder_paint_atlas_image (FlutlRecorder *rec, uint32_t offset, int w, int h,
+    int x, int y)
+{
+  target_touched (rec);
+  int x0 = x, y0 = y, x1 = x + w, y1 = y + h;
+  if (!clip_box (rec, &x0, &y0, &x1, &y1))
+    return;
+  flutl_prim *p = push_prim (rec);
+  p->op = FLUTL_OP_IMAGE;
+  p->cx0 = (int16_t) x0;
+  p->cy0 = (int16_t) y0;
+  p->cx1 = (int16_t) x1;
+  p->cy1 = (int16_t) y1;
+  p->a = (int32_t) offset;
+  p->b = w * 4;
+  p->c = x;
+  p->d = y;
 }
 
 static void

@@ -82,6 +82,18 @@ void flutl_recorder_stroke (FlutlRecorder *rec);
 void flutl_recorder_paint_image (FlutlRecorder *rec, cairo_surface_t *img, int x,
     int y);
 
+/* ---- blurred outlines: a child recorder records the temporary surface of
+ * gstttmlrender.c:1196-1199 as its own display list; its masks go to the
+ * parent's atlas.  The device blurs it into a new atlas entry
+ * (flutl_atlas_put_blurred); the host copy of that entry is appended here
+ * without being queued for upload, and blitted with paint_atlas_image. */
+FlutlRecorder *flutl_recorder_new_child (FlutlRecorder *parent);
+uint32_t flutl_recorder_next_atlas_offset (FlutlRecorder *rec);
+uint32_t flutl_recorder_atlas_append_device_entry (FlutlRecorder *rec,
+    const void *data, size_t bytes);
+void flutl_recorder_paint_atlas_image (FlutlRecorder *rec, uint32_t offset, int w,
+    int h, int x, int y);
+
 /* ---- results of the frame -------------------------------------------------*/
 const flutl_region *flutl_recorder_regions (FlutlRecorder *rec, uint32_t *n);
 const flutl_prim *flutl_recorder_prims (FlutlRecorder *rec, uint32_t *n);

@@ -22,7 +22,7 @@
  *
  * Not implemented yet (counted and logged, never silently approximated):
  * vertical writing modes (tbrl/tblr), anamorphic font sizes, reverseOblique,
- * blurred outlines.
+ * blurred outlines at fractional positions or with a blur above 8 px.
  */
 #ifdef HAVE_CONFIG_H
 #include "config.h"
@@ -151,8 +151,16 @@ frame_pool_acquire (FramePool *p, gsize size, gpointer *data)
 /* Device-side state of one element instance. */
 typedef struct
 {
+  guint32 offset;
+  gint w, h;
+} BlurredImage;
+
+typedef struct
+{
   FramePool *pool;
   FlutlRecorder *rec;
+  FlutlRecorder *sub;        /* child recorder for blurred-outline surfaces */
+  GHashTable *blurred;       /* key (checksum) -> BlurredImage, per document */
   flutl_ctx *ctx;            /* NULL until first use; stays NULL without a GPU */
   gboolean ctx_failed;
   FlutlPackWriter *dump;     /* FLUTL_DUMP_PACK=<file>: scene-pack dump */
@@ -692,10 +700,10 @@ rect_or_path (FlutlRecorder *rec, gboolean fill, double x, double y, double w,
 }
 
 static void
-walk_layout (GstTTMLRender *render, PangoLayout *layout, gboolean fill,
-    int right_edge, gboolean show_background, GstTTMLWritingMode writing_mode)
+walk_layout (GstTTMLRender *render, FlutlRecorder *rec, PangoLayout *layout,
+    gboolean fill, int right_edge, gboolean show_background,
+    GstTTMLWritingMode writing_mode)
 {
-  FlutlRecorder *rec = get_priv (render)->rec;
   cairo_t *cr = flutl_recorder_cairo (rec);
   int n_lines = pango_layout_get_line_count (layout);
   int spacing = pango_layout_get_spacing (layout);
@@ -841,6 +849,116 @@ walk_layout (GstTTMLRender *render, PangoLayout *layout, gboolean fill,
   }
 }
 
+static gboolean flush_atlas (GstTTMLRender *render);
+static gboolean ensure_ctx (GstTTMLRender *render);
+
+/* Blurred text outline (reference :1193-1229 + gstttmlblur.c): the outline is
+ * stroked onto a cleared temporary ARGB32 surface, that surface is blurred,
+ * and the result is blitted under the text.  Here: a child recorder records
+ * the temporary surface, the device composites + blurs it into an atlas entry
+ * (cached per document: it only changes when the outline itself does), and
+ * the frame's display list blits that entry. */
+static void
+blurred_outline (GstTTMLRender *render, HipRegion *r, PangoLayout *layout, guint32 c)
+{
+  GstTTMLRenderPrivate *priv = get_priv (render);
+  FlutlRecorder *rec = priv->rec, *sub = priv->sub;
+  cairo_matrix_t m;
+  PangoRectangle rect;
+  const flutl_region *rg;
+  const flutl_prim *pr;
+  uint32_t n_rg, n_pr;
+  BlurredImage *img;
+  gchar *key;
+  GChecksum *sum;
+  int br = (int) ceilf (r->outline.length[1].f);
+  /* reference :1216-1217: (surface, int radius = blur * 2, double sigma = blur) */
+  int radius = (int) (r->outline.length[1].f * 2);
+  double sigma = r->outline.length[1].f;
+  int tw, th;
+
+  pango_layout_get_pixel_extents (layout, NULL, &rect);
+  tw = rect.width + 2 * br;
+  th = rect.height + 2 * br;
+  cairo_get_matrix (flutl_recorder_cairo (rec), &m);
+  if (m.xx != 1.0 || m.yy != 1.0 || m.xy != 0.0 || m.yx != 0.0 ||
+      m.x0 != floor (m.x0) || m.y0 != floor (m.y0) || radius > 16 || radius < 0 ||
+      !(sigma > 0.0) || tw <= 0 || th <= 0 || tw > 32767 || th > 32767) {
+    /* a fractional offset makes Cairo resample the blurred surface bilinearly */
+    GST_FIXME_OBJECT (render, "blurred textOutline at a fractional position, or "
+        "with a blur radius above 8 px, is not implemented; outline of region "
+        "'%s' not drawn", r->id);
+    return;
+  }
+  if (priv->dump_only || !ensure_ctx (render)) {
+    GST_WARNING_OBJECT (render, "blurred outline needs the device; not drawn");
+    return;
+  }
+
+  /* ---- record the temporary surface --------------------------------------- */
+  flutl_recorder_begin_frame (sub, tw, th);
+  flutl_recorder_region_begin (sub);
+  {
+    cairo_t *scr = flutl_recorder_cairo (sub);
+    cairo_translate (scr, br, br);
+    flutl_recorder_set_color (sub, COMP (c, 24), COMP (c, 16), COMP (c, 8), COMP (c, 0));
+    cairo_set_line_width (scr, r->outline.length[0].f * 2);
+    walk_layout (render, sub, layout, FALSE, r->pex, TRUE, r->writing_mode);
+    flutl_recorder_stroke (sub);
+  }
+  flutl_recorder_region_end (sub);
+  rg = flutl_recorder_regions (sub, &n_rg);
+  pr = flutl_recorder_prims (sub, &n_pr);
+
+  /* ---- blurred image: cached by what determines it ------------------------- */
+  sum = g_checksum_new (G_CHECKSUM_SHA1);
+  g_checksum_update (sum, (const guchar *) pr, n_pr * sizeof (flutl_prim));
+  g_checksum_update (sum, (const guchar *) &tw, sizeof tw);
+  g_checksum_update (sum, (const guchar *) &th, sizeof th);
+  g_checksum_update (sum, (const guchar *) &radius, sizeof radius);
+  g_checksum_update (sum, (const guchar *) &sigma, sizeof sigma);
+  key = g_strdup (g_checksum_get_string (sum));
+  g_checksum_free (sum);
+  if (!priv->blurred)
+    priv->blurred = g_hash_table_new_full (g_str_hash, g_str_equal, g_free, g_free);
+  img = g_hash_table_lookup (priv->blurred, key);
+  if (img) {
+    g_free (key);
+  } else {
+    guint32 dev_off = 0, host_off;
+    guint8 *copy = g_malloc ((gsize) tw * th * 4);
+    int rc;
+    if (!flush_atlas (render)) {          /* the sub list's masks must be in HBM */
+      g_free (copy);
+      g_free (key);
+      return;
+    }
+    rc = flutl_atlas_put_blurred (priv->ctx, tw, th, rg, n_rg, pr, n_pr, radius, sigma,
+        copy, &dev_off);
+    if (rc != FLUTL_OK) {
+      GST_ERROR_OBJECT (render, "flutl_atlas_put_blurred: %s", flutl_strerror (rc));
+      g_free (copy);
+      g_free (key);
+      return;
+    }
+    host_off = flutl_recorder_atlas_append_device_entry (rec, copy, (gsize) tw * th * 4);
+    g_free (copy);
+    if (host_off != dev_off) {
+      GST_ERROR_OBJECT (render, "atlas out of sync (%u vs %u)", host_off, dev_off);
+      g_free (key);
+      return;
+    }
+    img = g_new0 (BlurredImage, 1);
+    img->offset = dev_off;
+    img->w = tw;
+    img->h = th;
+    g_hash_table_insert (priv->blurred, key, img);
+  }
+  /* reference :1219-1224: blit at (rect.x - br, rect.y - br) under the CTM */
+  flutl_recorder_paint_atlas_image (rec, img->offset, img->w, img->h,
+      (int) m.x0 + rect.x - br, (int) m.y0 + rect.y - br);
+}
+
 /* Text outline (reference :1180-1232). */
 static void
 outline_layout (GstTTMLRender *render, HipRegion *r, PangoLayout *layout)
@@ -852,15 +970,14 @@ outline_layout (GstTTMLRender *render, HipRegion *r, PangoLayout *layout)
   double keep[4];
 
   if (r->outline.length[1].unit != GST_TTML_LENGTH_UNIT_NOT_PRESENT) {
-    GST_FIXME_OBJECT (render, "blurred textOutline is not implemented; "
-        "the outline of region '%s' is not drawn", r->id);
+    blurred_outline (render, r, layout, c);
     return;
   }
   flutl_recorder_get_color (rec, keep);
   cairo_save (cr);
   flutl_recorder_set_color (rec, COMP (c, 24), COMP (c, 16), COMP (c, 8), COMP (c, 0));
   cairo_set_line_width (cr, r->outline.length[0].f * 2);
-  walk_layout (render, layout, FALSE, r->pex, TRUE, r->writing_mode);
+  walk_layout (render, rec, layout, FALSE, r->pex, TRUE, r->writing_mode);
   flutl_recorder_stroke (rec);
   cairo_restore (cr);
   flutl_recorder_set_color (rec, keep[0], keep[1], keep[2], keep[3]);
@@ -922,7 +1039,7 @@ record_region (HipRegion *r, GstTTMLRender *render)
        * background, opaque */
       flutl_recorder_set_color (rec, 1.0 - COMP (r->bg, 24), 1.0 - COMP (r->bg, 16),
           1.0 - COMP (r->bg, 8), 1.0);
-      walk_layout (render, l->data, TRUE, r->pex, !outlined, r->writing_mode);
+      walk_layout (render, rec, l->data, TRUE, r->pex, !outlined, r->writing_mode);
     }
   }
 
@@ -950,6 +1067,27 @@ ensure_ctx (GstTTMLRender *render)
         ("ttmlrender: no usable MI355X/HIP device"),
         ("flutl_ctx_create: %s", flutl_strerror (rc)));
     return FALSE;
+  }
+  return TRUE;
+}
+
+/* Upload the atlas entries recorded since the last call. */
+static gboolean
+flush_atlas (GstTTMLRender *render)
+{
+  GstTTMLRenderPrivate *priv = get_priv (render);
+  const uint32_t *off, *size;
+  size_t atlas_size;
+  const uint8_t *atlas = flutl_recorder_atlas (priv->rec, &atlas_size);
+  uint32_t i, n = flutl_recorder_new_atlas_entries (priv->rec, &off, &size);
+  for (i = 0; i < n; i++) {
+    uint32_t dev_off = 0;
+    int rc = flutl_atlas_put (priv->ctx, atlas + off[i], size[i], &dev_off);
+    if (rc != FLUTL_OK || dev_off != off[i]) {
+      GST_ELEMENT_ERROR (render, LIBRARY, FAILED, ("ttmlrender: atlas upload failed"),
+          ("flutl_atlas_put: %s (offset %u vs %u)", flutl_strerror (rc), dev_off, off[i]));
+      return FALSE;
+    }
   }
   return TRUE;
 }
@@ -1008,22 +1146,8 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
   /* ---- device: display list -> frame ------------------------------------- */
   if (!ensure_ctx (render))
     return NULL;
-  {
-    const uint32_t *off, *size;
-    size_t atlas_size;
-    const uint8_t *atlas = flutl_recorder_atlas (rec, &atlas_size);
-    uint32_t i, n = flutl_recorder_new_atlas_entries (rec, &off, &size);
-    for (i = 0; i < n; i++) {
-      uint32_t dev_off = 0;
-      int rc = flutl_atlas_put (priv->ctx, atlas + off[i], size[i], &dev_off);
-      if (rc != FLUTL_OK || dev_off != off[i]) {
-        GST_ELEMENT_ERROR (render, LIBRARY, FAILED, ("ttmlrender: atlas upload failed"),
-            ("flutl_atlas_put: %s (offset %u vs %u)", flutl_strerror (rc), dev_off,
-                off[i]));
-        return NULL;
-      }
-    }
-  }
+  if (!flush_atlas (render))
+    return NULL;
   {
     GstMapInfo map;
     gpointer pinned = NULL;
@@ -1159,6 +1283,12 @@ gst_ttmlrender_reset (GstTTMLBase *base)
   }
   if (priv->rec)
     flutl_recorder_reset (priv->rec);
+  if (priv->sub)
+    flutl_recorder_reset (priv->sub);
+  if (priv->blurred) {
+    g_hash_table_unref (priv->blurred);
+    priv->blurred = NULL;
+  }
   if (priv->ctx) {
     flutl_ctx_sync (priv->ctx);
     flutl_atlas_reset (priv->ctx);
@@ -1181,6 +1311,10 @@ gst_ttmlrender_dispose (GObject *object)
   if (priv->ctx) {
     flutl_ctx_destroy (priv->ctx);
     priv->ctx = NULL;
+  }
+  if (priv->sub) {
+    flutl_recorder_free (priv->sub);
+    priv->sub = NULL;
   }
   if (priv->rec) {
     flutl_recorder_free (priv->rec);
@@ -1279,6 +1413,8 @@ gst_ttmlrender_init (GstTTMLRender *render)
   render->downloader = fludownloader_helper_downloader_new (NULL);
 
   priv->rec = flutl_recorder_new ();
+  priv->sub = flutl_recorder_new_child (priv->rec);
+  priv->blurred = NULL;
   priv->pool = frame_pool_new ();
   priv->ctx = NULL;
   priv->ctx_failed = FALSE;

@@ -46,6 +46,7 @@ EXPORTS = [
     "flutl_list_create", "flutl_list_destroy",
     "flutl_render", "flutl_render_to_host",
     "flutl_host_alloc", "flutl_host_free", "flutl_render_frame_to_host",
+    "flutl_atlas_put_blurred",
 ]
 
 
@@ -91,6 +92,8 @@ def lib():
         L.flutl_render.argtypes = [vp, vp, vp, sz]
         L.flutl_render_to_host.argtypes = [vp, vp, vp, sz]
         L.flutl_render_frame_to_host.argtypes = [vp, u32, u32, vp, u32, vp, u32, vp, sz]
+        L.flutl_atlas_put_blurred.argtypes = [vp, u32, u32, vp, u32, vp, u32, ctypes.c_int,
+                                              ctypes.c_double, vp, ctypes.POINTER(u32)]
         L.flutl_host_alloc.argtypes = [sz, ctypes.POINTER(vp)]
         L.flutl_host_free.argtypes = [vp]
         L.flutl_host_free.restype = None
@@ -182,6 +185,17 @@ class Context:
         _check(lib().flutl_atlas_put(self._h, _np_ptr(data), data.nbytes,
                                      ctypes.byref(off)), "flutl_atlas_put")
         return off.value
+
+    def atlas_put_blurred(self, w, h, regions, prims, radius, sigma):
+        """returns (atlas offset, host copy of the blurred w x h ARGB32 image)"""
+        regions = np.ascontiguousarray(regions, REGION_DTYPE)
+        prims = np.ascontiguousarray(prims, PRIM_DTYPE)
+        out = np.empty((h, w), np.uint32)
+        off = ctypes.c_uint32()
+        _check(lib().flutl_atlas_put_blurred(
+            self._h, w, h, _np_ptr(regions), len(regions), _np_ptr(prims), len(prims),
+            radius, float(sigma), _np_ptr(out), ctypes.byref(off)), "flutl_atlas_put_blurred")
+        return off.value, out
 
     def atlas_reset(self):
         lib().flutl_atlas_reset(self._h)

@@ -176,6 +176,21 @@ int  flutl_atlas_put (flutl_ctx *ctx, const void *src, size_t bytes,
 void flutl_atlas_reset (flutl_ctx *ctx);
 size_t flutl_atlas_size (const flutl_ctx *ctx);
 
+/* Blurred text outline (gst_ttmlrender_render_outline with a blur radius,
+ * gstttmlrender.c:1193-1229): the display list `regions/prims` is composited
+ * on the device into a cleared w x h ARGB32 temporary surface (the
+ * cairo_image_surface_create of :1196), that surface is convolved with the
+ * Gaussian kernel of gst_ttml_blur_image_surface (gstttmlblur.c:71-110,
+ * radius/sigma as its arguments) and the result becomes a NEW ATLAS ENTRY
+ * (premultiplied ARGB32, stride 4*w) whose offset is returned: the frame's
+ * display list then blits it with an IMAGE primitive (:1219-1224).
+ * If host_copy is not NULL the w*h*4 result bytes are also copied there (for
+ * scene-pack dumps).  radius <= 16. */
+int  flutl_atlas_put_blurred (flutl_ctx *ctx, uint32_t w, uint32_t h,
+    const flutl_region *regions, uint32_t n_regions,
+    const flutl_prim *prims, uint32_t n_prims,
+    int radius, double sigma, void *host_copy, uint32_t *offset_out);
+
 /* Upload (validate + H2D) a display list for a W x H frame. */
 int  flutl_list_create (flutl_ctx *ctx, uint32_t width, uint32_t height,
     const flutl_region *regions, uint32_t n_regions,

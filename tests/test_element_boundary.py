@@ -1,0 +1,67 @@
+"""The drop-in boundary of the element: factory name, rank, klass,
+pads/caps and properties with their defaults must be what the reference's
+ttmlrender exposes.  Compared LIVE against the reference plugin where both
+plugins and the GStreamer tools of this image are present; skipped elsewhere."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import gstenv  # noqa: E402
+
+need = pytest.mark.skipif(
+    not (gstenv.available(gstenv.REF_PLUGIN_DIR) and gstenv.available(gstenv.HIP_PLUGIN_DIR)),
+    reason="needs both plugins + gst-inspect of this image")
+
+
+def inspect(plugin_dir, what="ttmlrender"):
+    r = subprocess.run([os.path.join(gstenv.CONDA, "bin", "gst-inspect-1.0"), what],
+                       env=gstenv.env_for(plugin_dir), capture_output=True, text=True,
+                       cwd="/tmp")
+    assert r.returncode == 0, r.stderr
+    return r.stdout
+
+
+def section(text, start, end=None):
+    i = text.index(start)
+    j = text.index(end, i) if end else len(text)
+    return text[i:j]
+
+
+@need
+def test_factory_rank_klass_and_hierarchy():
+    ref, hip = inspect(gstenv.REF_PLUGIN_DIR), inspect(gstenv.HIP_PLUGIN_DIR)
+    for key in ("Rank", "Klass", "Long-name"):
+        get = lambda t: re.search(rf"{key}\s+(.*)", t).group(1).strip()
+        assert get(ref) == get(hip), key
+    assert "marginal" in re.search(r"Rank\s+(.*)", hip).group(1)
+    assert section(ref, "GObject", "Pad Templates") == section(hip, "GObject", "Pad Templates")
+
+
+@need
+def test_pad_templates_and_caps_are_identical():
+    ref, hip = inspect(gstenv.REF_PLUGIN_DIR), inspect(gstenv.HIP_PLUGIN_DIR)
+    assert section(ref, "Pad Templates:", "Element has") == \
+        section(hip, "Pad Templates:", "Element has")
+    assert "application/ttml+xml" in hip and "format: BGRA" in hip
+
+
+@need
+def test_properties_and_defaults_are_identical():
+    ref, hip = inspect(gstenv.REF_PLUGIN_DIR), inspect(gstenv.HIP_PLUGIN_DIR)
+    pr, ph = section(ref, "Element Properties:"), section(hip, "Element Properties:")
+    assert pr == ph
+    for must in ('default-font-family', 'Default: "Serif"', 'window-width',
+                 'Default: 720', 'Default: 576', 'assume-ordered-spans'):
+        assert must in ph, must
+
+
+@need
+def test_plugin_registers_all_three_elements():
+    out = inspect(gstenv.HIP_PLUGIN_DIR, "fluttml")
+    for el in ("ttmlparse", "ttmlsegmentedparse", "ttmlrender"):
+        assert el in out

@@ -32,8 +32,11 @@ def test_reference_still_produces_the_goldens(ttml):
 
 @pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
                     reason="fluttml-hip plugin / GStreamer runtime not present")
-@pytest.mark.parametrize("ttml", SCENES, ids=ids)
+@pytest.mark.parametrize("ttml", [s for s in SCENES if os.path.basename(s)[0] == "k"],
+                         ids=[i for i in ids if i[0] == "k"])
 def test_element_still_records_the_committed_lists(ttml, tmp_path):
+    # (g* scenes hold device-produced atlas entries -- blurred outlines -- and
+    # can only be recorded with a GPU: covered by test_gpu_scenes.py)
     z = np.load(ttml[:-5] + ".npz")
     W, H = int(z["width"]), int(z["height"])
     pk = scene_pack.load(gstenv.dump_pack(ttml, W, H, str(tmp_path / "p.flpk")))

@@ -74,11 +74,15 @@ def render(plugin_dir, ttml_path, width, height, out_path=None, extra_env=None,
     return data
 
 
-def dump_pack(ttml_path, width, height, pack_path):
-    """Run the fluttml-hip element in record-only mode (works without a GPU) and
-    return the path of the scene pack it wrote."""
+def dump_pack(ttml_path, width, height, pack_path, record_only=True):
+    """Run the fluttml-hip element and return the path of the scene pack it
+    wrote.  record_only (default) works without a GPU; with record_only=False
+    the element also renders, and device-produced atlas entries (blurred
+    outlines) are part of the pack."""
     if os.path.exists(pack_path):
         os.unlink(pack_path)
-    render(HIP_PLUGIN_DIR, ttml_path, width, height, sink="fakesink",
-           extra_env={"FLUTL_DUMP_PACK": pack_path, "FLUTL_DUMP_ONLY": "1"})
+    env = {"FLUTL_DUMP_PACK": pack_path}
+    if record_only:
+        env["FLUTL_DUMP_ONLY"] = "1"
+    render(HIP_PLUGIN_DIR, ttml_path, width, height, sink="fakesink", extra_env=env)
     return pack_path

@@ -37,19 +37,28 @@ SCENE_SIZE = (320, 180)
 MAX_STATES = {"cfg0": 8, "cfg1": 64, "cfg2": 120, "cfg4": 64}
 
 
-def record(ttml, W, H):
+def record(ttml, W, H, gpu=False):
     with tempfile.TemporaryDirectory() as d:
-        return scene_pack.load(gstenv.dump_pack(ttml, W, H, os.path.join(d, "p.flpk")))
+        return scene_pack.load(gstenv.dump_pack(ttml, W, H, os.path.join(d, "p.flpk"),
+                                                record_only=not gpu))
 
 
-def scenes():
+def scenes(gpu=False):
+    """k*.ttml: recorded without a device.  g*.ttml (gpu=True, run on an MI355X
+    box through gpurun): scenes whose display lists contain device-produced
+    atlas entries (blurred outlines); fixtures go to gpurun_out/goldens/."""
     W, H = SCENE_SIZE
     d = os.path.join(ROOT, "tests", "golden", "scenes")
-    for name in sorted(f[:-5] for f in os.listdir(d) if f.endswith(".ttml")):
+    outd = d
+    if gpu:
+        outd = os.path.join(ROOT, "gpurun_out", "goldens")
+        os.makedirs(outd, exist_ok=True)
+    for name in sorted(f[:-5] for f in os.listdir(d)
+                       if f.endswith(".ttml") and f.startswith("g" if gpu else "k")):
         ttml = os.path.join(d, name + ".ttml")
         ref = np.frombuffer(gstenv.render(gstenv.REF_PLUGIN_DIR, ttml, W, H),
                             np.uint32).reshape(-1, H, W)
-        pk = record(ttml, W, H)
+        pk = record(ttml, W, H, gpu)
         st = pk.states()
         assert len(st) == len(ref), (name, len(st), len(ref))
         out = {"width": W, "height": H, "n_states": len(st), "atlas": pk.atlas,
@@ -59,7 +68,7 @@ def scenes():
             out[f"regions{i}"] = R
             out[f"prims{i}"] = P
             bad += int((O.render(W, H, R, P, pk.atlas) != ref[i]).sum())
-        np.savez_compressed(os.path.join(d, name + ".npz"), **out)
+        np.savez_compressed(os.path.join(outd, name + ".npz"), **out)
         print(f"{name}: {len(st)} states, oracle-vs-reference mismatching px: {bad}")
 
 
@@ -123,4 +132,9 @@ def config(cfg):
 if __name__ == "__main__":
     what = sys.argv[1:] or ["scenes", "cfg0", "cfg1", "cfg2"]
     for w in what:
-        scenes() if w == "scenes" else config(w)
+        if w == "scenes":
+            scenes()
+        elif w == "gpu_scenes":
+            scenes(gpu=True)
+        else:
+            config(w)
