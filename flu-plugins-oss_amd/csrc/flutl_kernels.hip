@@ -35,7 +35,6 @@ namespace {
 typedef unsigned short u16x2 __attribute__ ((ext_vector_type (2)));
 
 constexpr int kThreads = 64;           // one wavefront per workgroup
-constexpr int kChunk = kThreads;       // prims binned per round
 
 // ---- packed 2 x 16-bit channel arithmetic ---------------------------------
 // A pixel is kept unpacked as two registers: rb = {B, R}, ag = {G, A}, one
@@ -141,9 +140,9 @@ constexpr int kSuperW = FLUTL_TILE_W;        // 64
 constexpr int kRG = 4;                       // row groups per wave
 constexpr int kSuperH = 4 * kRG;             // kRG strips of 4 rows
 
-// A primitive held wave-uniformly in SGPRs.  The bin list in LDS holds prim
-// INDICES; the 32-byte primitive itself is fetched with scalar loads (the
-// index is wave-uniform), two primitives ahead of its use.
+// A primitive held wave-uniformly in SGPRs.  During binning every lane holds
+// one candidate primitive (32 bytes = 8 VGPRs); a hit is broadcast to the
+// whole wave with 8 v_readlane -- no LDS list, no scalar loads.
 struct PrimU {
   uint32_t op, rule, param;
   int cx0, cy0, cx1, cy1;
@@ -151,32 +150,27 @@ struct PrimU {
   int a, b, c, d;
 };
 
-typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
-typedef const __attribute__ ((address_space (4))) u32x4 *const_u32x4_ptr;
-
-__device__ __forceinline__ uint32_t rfl (uint32_t v)
+__device__ __forceinline__ uint32_t rdl (uint32_t v, int l)
 {
-  return (uint32_t) __builtin_amdgcn_readfirstlane ((int) v);
+  return (uint32_t) __builtin_amdgcn_readlane ((int) v, l);
 }
 
-__device__ __forceinline__ PrimU prim_load (const flutl_prim *prims, uint32_t idx)
+__device__ __forceinline__ PrimU prim_from_lane (const uint4 &lo, const uint4 &hi, int l)
 {
-  // constant address space + uniform address => s_load_dwordx4 x2
-  const_u32x4_ptr q = (const_u32x4_ptr) (uintptr_t) (prims + idx);
-  const u32x4 lo = q[0], hi = q[1];
+  const uint32_t w0 = rdl (lo.x, l), w1 = rdl (lo.y, l), w2 = rdl (lo.z, l);
   PrimU p;
-  p.op = lo.x & 0xffu;
-  p.rule = (lo.x >> 8) & 0xffu;
-  p.param = lo.x >> 16;
-  p.cx0 = (int16_t) (lo.y & 0xffffu);
-  p.cy0 = (int16_t) (lo.y >> 16);
-  p.cx1 = (int16_t) (lo.z & 0xffffu);
-  p.cy1 = (int16_t) (lo.z >> 16);
-  p.color = lo.w;
-  p.a = (int) hi.x;
-  p.b = (int) hi.y;
-  p.c = (int) hi.z;
-  p.d = (int) hi.w;
+  p.op = w0 & 0xffu;
+  p.rule = (w0 >> 8) & 0xffu;
+  p.param = w0 >> 16;
+  p.cx0 = (int16_t) (w1 & 0xffffu);
+  p.cy0 = (int16_t) (w1 >> 16);
+  p.cx1 = (int16_t) (w2 & 0xffffu);
+  p.cy1 = (int16_t) (w2 >> 16);
+  p.color = rdl (lo.w, l);
+  p.a = (int) rdl (hi.x, l);
+  p.b = (int) rdl (hi.y, l);
+  p.c = (int) rdl (hi.z, l);
+  p.d = (int) rdl (hi.w, l);
   return p;
 }
 
@@ -271,7 +265,45 @@ __device__ __forceinline__ uint32_t pixel_mask (const PrimU &p, int x, bool rowi
   return rowin ? (mhi & ~mlo) : 0u;
 }
 
-constexpr uint32_t kListCap = 512;     // prim indices per replay round (2 KiB)
+// The lane's 4 row groups of a MASK primitive, fetched together (4 loads in
+// flight) one primitive ahead of their use.
+struct MaskFetch {
+  uint32_t w[kRG];
+};
+
+__device__ __forceinline__ MaskFetch mask_fetch4 (const PrimU &p,
+    const uint8_t *__restrict__ atlas, int x, int y0)
+{
+  MaskFetch f;
+#pragma unroll
+  for (int r = 0; r < kRG; r++)
+    f.w[r] = mask_fetch (p, atlas, x, y0 + 4 * r);
+  return f;
+}
+
+// blend one strip (4 packed pixels of the lane) with coverage dword w
+__device__ __forceinline__ void strip_apply (uint32_t (&tp)[4], const PrimU &p, uint32_t w)
+{
+  Px t[4] = { unpack (tp[0]), unpack (tp[1]), unpack (tp[2]), unpack (tp[3]) };
+  const Px s = unpack (p.color);
+  if (p.rule == FLUTL_RULE_LERP) {
+    if ((p.color & 0x00ff00ffu) == 0u)
+      strip_blend<true, true> (t, s, w);
+    else
+      strip_blend<true, false> (t, s, w);
+  } else {
+    if ((p.color >> 24) == 255u)
+      strip_blend<false, true> (t, s, w);
+    else
+      strip_blend<false, false> (t, s, w);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    tp[k] = pack (t[k]);
+  // do not let the scheduler interleave the blends of different strips: it
+  // would trade occupancy for ILP that the other waves already provide
+  __builtin_amdgcn_sched_barrier (0);
+}
 
 __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
     FrameParams fp, uint8_t *__restrict__ dst,
@@ -279,13 +311,12 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
     const flutl_region *__restrict__ regions,
     const flutl_prim *__restrict__ prims, const uint8_t *__restrict__ atlas)
 {
-  __shared__ uint32_t s_list[kListCap];    // binned prim indices, paint order
-  __shared__ uint4 s_park[kThreads];       // frame pixels parked during a group
+  // frame pixels parked during an opacity group: lane-private slots, so no
+  // barrier; this is the kernel's only LDS
+  __shared__ uint4 s_park[kRG][kThreads];
 
-  // One wavefront per workgroup: no barrier anywhere, nothing shared between
-  // waves; LDS is only the wave's own bin list and park slots.
-  const int tid = threadIdx.x;
-  const int lane = tid;
+  // One wavefront per workgroup: nothing is shared between waves.
+  const int lane = threadIdx.x;
 
   // Blocks b and b+8 share an XCD (and its L2): XCD k gets the k-th contiguous
   // band of supertiles, so the glyph masks and display-list entries of a band
@@ -309,230 +340,203 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
   }
 
   const int sx0 = (int) stx * kSuperW, sy0 = (int) sty * kSuperH;
-  const int wy0 = sy0;                          // this wave's first row
-  const int x = sx0 + (lane & 15) * 4;
-  const int y_lane = wy0 + (lane >> 4);         // row in row group 0
+  const int x_lane = sx0 + (lane & 15) * 4;
+  const int y_lane = sy0 + (lane >> 4);         // row in strip 0; strip r: + 4r
 
-  // Binning state.  The common case bins ONCE per supertile (everything fits
-  // s_list) and replays the list for each of the wave's row groups.  Only if a
-  // supertile overlaps more primitives than s_list holds does each row group
-  // re-bin in rounds (correct, slower; pathological lists only).
-  uint32_t n_list = 0;
-  bool single_round = true, first_fill = true;
-
-#pragma unroll 1
-  for (int r = 0; r < kRG; r++) {
-    const int ry0 = wy0 + 4 * r;                // scalar: rows [ry0, ry0+4)
-    const int y = y_lane + 4 * r;
-    // t = the surface being painted: the frame, or -- between GROUP_BEGIN and
-    // GROUP_END -- the region's group surface, while the frame pixels are
-    // parked in a lane-private LDS slot (no barrier: a lane reads its own).
-    Px t[4];
+  // t = the surface being painted, 4 strips x 4 packed pixels per lane: the
+  // frame, or -- between GROUP_BEGIN and GROUP_END -- the region's group
+  // surface while the frame pixels are parked in s_park.
+  uint32_t t[kRG][4];
+#pragma unroll
+  for (int r = 0; r < kRG; r++)
 #pragma unroll
     for (int k = 0; k < 4; k++)
-      t[k] = unpack (0u);
+      t[r][k] = 0u;
 
-    const bool refill = r == 0 || !single_round;
-    // cursor over (hit regions) x (64-prim chunks)
-    uint32_t rbase = 0;                  // next batch of 64 regions to cull
-    unsigned long long rmask = 0;        // hit regions of the current batch
-    uint32_t rv_first = 0, rv_count = 0; // per lane: prim range of "my" region
-    uint32_t pfirst = 0, pcount = 0, pbase = 0;
-    bool done = !refill;
+  // ---- regions, 64 at a time: one per lane, culled against the supertile ----
+  for (uint32_t rbase = 0; rbase < rcount; rbase += 64) {
+    // lanes past the end re-read the last region and are masked out
+    const uint32_t ridx = min (rbase + (uint32_t) lane, rcount - 1u);
+    const uint4 rv = *reinterpret_cast<const uint4 *> (&regions[rfirst + ridx]);
+    const int rx0 = (int16_t) (rv.x & 0xffffu), ry0r = (int16_t) (rv.x >> 16);
+    const int rx1 = (int16_t) (rv.y & 0xffffu), ry1r = (int16_t) (rv.y >> 16);
+    const bool rhit = rbase + lane < rcount && rx0 < sx0 + kSuperW && rx1 > sx0 &&
+        ry0r < sy0 + kSuperH && ry1r > sy0 && rv.w != 0;
+    unsigned long long rmask = __ballot (rhit);
+    while (rmask) {
+      const int rl = __builtin_ctzll (rmask);
+      rmask &= rmask - 1;
+      const uint32_t pfirst = rdl (rv.z, rl), pcount = rdl (rv.w, rl);
 
-    do {
-      if (refill) {
-        // ======== fill: bin chunks into s_list until it could overflow ======
-        n_list = 0;
+      // ---- the region's prims, 64 at a time: bin and replay fused ----------
+      for (uint32_t pbase = 0; pbase < pcount; pbase += 64) {
+        const uint32_t pi = pbase + (uint32_t) lane;
+        const uint4 *pp = reinterpret_cast<const uint4 *> (
+            &prims[pfirst + min (pi, pcount - 1u)]);
+        const uint4 lo = pp[0], hi = pp[1];
+        const int bx0 = (int16_t) (lo.y & 0xffffu), by0 = (int16_t) (lo.y >> 16);
+        const int bx1 = (int16_t) (lo.z & 0xffffu), by1 = (int16_t) (lo.z >> 16);
+        const bool hit = pi < pcount && bx0 < sx0 + kSuperW && bx1 > sx0 &&
+            by0 < sy0 + kSuperH && by1 > sy0;
+        unsigned long long hits = __ballot (hit);
+        if (!hits)
+          continue;
+
+        // replay the hits in paint order (= lane order); the next hit's mask
+        // bytes are requested before the current one is blended
+        PrimU nxt = prim_from_lane (lo, hi, __builtin_ctzll (hits));
+        hits &= hits - 1;
+        MaskFetch fnxt = mask_fetch4 (nxt, atlas, x_lane, y_lane);
         for (;;) {
-          if (pbase >= pcount) {         // current region exhausted
-            if (rmask == 0) {            // current batch exhausted
-              if (rbase >= rcount) {
-                done = true;
-                break;
-              }
-              // cull 64 regions against the supertile, one per lane.  Lanes
-              // past the end re-read the last region and are masked out.
-              const uint32_t ridx = min (rbase + (uint32_t) lane, rcount - 1u);
-              const uint4 rv = *reinterpret_cast<const uint4 *> (&regions[rfirst + ridx]);
-              const int rx0 = (int16_t) (rv.x & 0xffffu), ry0r = (int16_t) (rv.x >> 16);
-              const int rx1 = (int16_t) (rv.y & 0xffffu), ry1r = (int16_t) (rv.y >> 16);
-              const bool rhit = rbase + lane < rcount && rx0 < sx0 + kSuperW &&
-                  rx1 > sx0 && ry0r < sy0 + kSuperH && ry1r > sy0 && rv.w != 0;
-              rmask = __ballot (rhit);
-              rv_first = rv.z;
-              rv_count = rv.w;
-              rbase += 64;
-              continue;
-            }
-            const int rl = __builtin_ctzll (rmask);
-            rmask &= rmask - 1;
-            pfirst = (uint32_t) __builtin_amdgcn_readlane ((int) rv_first, rl);
-            pcount = (uint32_t) __builtin_amdgcn_readlane ((int) rv_count, rl);
-            pbase = 0;
-            continue;
+          // Re-materialise the lane coordinates per primitive: left visible,
+          // LICM hoists dozens of x+k / y+4r derived VGPRs out of the loops.
+          int x = x_lane, y0 = y_lane;
+          asm volatile ("" : "+v"(x), "+v"(y0));
+          const PrimU p = nxt;
+          const MaskFetch f = fnxt;
+          const bool more = hits != 0;
+          if (more) {
+            nxt = prim_from_lane (lo, hi, __builtin_ctzll (hits));
+            hits &= hits - 1;
+            fnxt = mask_fetch4 (nxt, atlas, x, y0);
           }
-          if (n_list + kChunk > kListCap)
-            break;                       // replay what we have first
-
-          // bin: lane t tests prim pbase+t against the supertile; hits are
-          // appended, in paint order, as prim indices
-          const uint32_t pi = pbase + (uint32_t) tid;
-          const uint32_t pidx = pfirst + min (pi, pcount - 1u);
-          const uint2 bb = *reinterpret_cast<const uint2 *> (
-              reinterpret_cast<const uint8_t *> (&prims[pidx]) + 4);
-          const int cx0 = (int16_t) (bb.x & 0xffffu), cy0 = (int16_t) (bb.x >> 16);
-          const int cx1 = (int16_t) (bb.y & 0xffffu), cy1 = (int16_t) (bb.y >> 16);
-          const bool hit = pi < pcount && cx0 < sx0 + kSuperW && cx1 > sx0 &&
-              cy0 < sy0 + kSuperH && cy1 > sy0;
-          const unsigned long long bal = __ballot (hit);
-          const uint32_t pos = n_list +
-              (uint32_t) __popcll (bal & ((1ull << lane) - 1ull));
-          if (hit)
-            s_list[pos] = pidx;
-          n_list += (uint32_t) __popcll (bal);
-          pbase += kChunk;
-        }
-        if (r == 0 && first_fill)
-          single_round = done;           // everything fitted in one round?
-        first_fill = false;
-      }
-
-      // ======== replay s_list for row group r, in paint order ==============
-      // 3-stage software pipeline: scalar-load prim i+2 | fetch the mask
-      // bytes of prim i+1 | blend prim i.
-      if (n_list) {
-        PrimU q0 = prim_load (prims, rfl (s_list[0]));
-        PrimU q1 = prim_load (prims, rfl (s_list[min (1u, n_list - 1u)]));
-        uint32_t f0 = mask_fetch (q0, atlas, x, y);
-        for (uint32_t i = 0; i < n_list; i++) {
-          const PrimU q2 = prim_load (prims, rfl (s_list[min (i + 2u, n_list - 1u)]));
-          const uint32_t f1 = mask_fetch (q1, atlas, x, y);
-          const PrimU p = q0;
-          const uint32_t f = f0;
-          q0 = q1;
-          q1 = q2;
-          f0 = f1;
-
-          // rows of this row group untouched by the prim: scalar skip.  A
-          // group's BEGIN/END carry the same bbox, so they skip together.
-          if (p.cy1 <= ry0 || p.cy0 >= ry0 + 4)
-            continue;
 
           if (p.op == FLUTL_OP_GROUP_BEGIN) {
-            s_park[tid] = make_uint4 (pack (t[0]), pack (t[1]), pack (t[2]), pack (t[3]));
+            uint32_t zero = 0;
+            asm volatile ("" : "+v"(zero));    // no zero vector kept alive
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-              t[k] = unpack (0u);
-            continue;
-          }
-
-          const bool rowin = (uint32_t) (y - p.cy0) < (uint32_t) (p.cy1 - p.cy0);
-
-          if (p.op == FLUTL_OP_RECT || p.op == FLUTL_OP_MASK) {
-            // ---- solid colour through an 8-bit coverage --------------------
-            uint32_t w = f;
-            if (p.op == FLUTL_OP_RECT) {
-              // is the whole 64x4 strip inside the rectangle's full-coverage
-              // interior?  (scalar test)
-              const bool full = ((p.a + 255) >> 8) <= sx0 && (p.c >> 8) >= sx0 + kSuperW &&
-                  p.cx0 <= sx0 && p.cx1 >= sx0 + kSuperW && ((p.b + 255) >> 8) <= ry0 &&
+            for (int r = 0; r < kRG; r++) {
+              s_park[r][lane] = make_uint4 (t[r][0], t[r][1], t[r][2], t[r][3]);
+#pragma unroll
+              for (int k = 0; k < 4; k++)
+                t[r][k] = zero;
+            }
+          } else if (p.op == FLUTL_OP_MASK) {
+            // ---- solid colour through an A8 mask ---------------------------
+#pragma unroll
+            for (int r = 0; r < kRG; r++) {
+              const int ry0 = sy0 + 4 * r;           // scalar row test
+              if (p.cy1 <= ry0 || p.cy0 >= ry0 + 4)
+                continue;
+              uint32_t w = f.w[r];
+              if (p.param & FLUTL_MASK_XCLIP)
+                w &= pixel_mask (p, x, true);
+              if (__ballot (w != 0) == 0)
+                continue;                            // nothing lands in this strip
+              strip_apply (t[r], p, w);
+            }
+          } else if (p.op == FLUTL_OP_RECT) {
+            // ---- solid colour through a 24.8 box ---------------------------
+            const bool xfull = ((p.a + 255) >> 8) <= sx0 && (p.c >> 8) >= sx0 + kSuperW &&
+                p.cx0 <= sx0 && p.cx1 >= sx0 + kSuperW;
+#pragma unroll
+            for (int r = 0; r < kRG; r++) {
+              const int ry0 = sy0 + 4 * r;
+              if (p.cy1 <= ry0 || p.cy0 >= ry0 + 4)
+                continue;
+              const bool full = xfull && ((p.b + 255) >> 8) <= ry0 &&
                   (p.d >> 8) >= ry0 + 4 && p.cy0 <= ry0 && p.cy1 >= ry0 + 4;
               if (full) {
                 // coverage 255 on the whole strip: t = s OVER t with a uniform
-                // s.  Opaque s, or nothing painted yet: t = s exactly
-                // (MUL_UN8 (t, 0) == 0, MUL_UN8 (0, ia) == 0) under both rules.
-                const Px sc = unpack (p.color);
+                // s.  Opaque s, LERP, or nothing painted yet: t = s exactly.
                 if ((p.color >> 24) == 255u || p.rule == FLUTL_RULE_LERP ||
-                    __ballot ((as_u32 (t[0].rb) | as_u32 (t[0].ag) | as_u32 (t[1].rb) |
-                            as_u32 (t[1].ag) | as_u32 (t[2].rb) | as_u32 (t[2].ag) |
-                            as_u32 (t[3].rb) | as_u32 (t[3].ag)) != 0) == 0) {
+                    __ballot ((t[r][0] | t[r][1] | t[r][2] | t[r][3]) != 0) == 0) {
 #pragma unroll
                   for (int k = 0; k < 4; k++)
-                    t[k] = sc;
+                    t[r][k] = p.color;
                 } else {
+                  const Px sc = unpack (p.color);
 #pragma unroll
-                  for (int k = 0; k < 4; k++)
-                    over (t[k], sc);
+                  for (int k = 0; k < 4; k++) {
+                    Px v = unpack (t[r][k]);
+                    over (v, sc);
+                    t[r][k] = pack (v);
+                  }
                 }
                 continue;
               }
               // cairo rectangular scan converter coverage
+              const int y = y0 + 4 * r;
+              const bool rowin = (uint32_t) (y - p.cy0) < (uint32_t) (p.cy1 - p.cy0);
               const int oy = overlap256 (p.b, p.d, y);
-              w = 0;
+              uint32_t w = 0;
 #pragma unroll
               for (int k = 0; k < 4; k++)
                 w |= min ((uint32_t) (overlap256 (p.a, p.c, x + k) * oy) >> 8, 255u) << (8 * k);
-            }
-            if (p.op == FLUTL_OP_RECT || (p.param & FLUTL_MASK_XCLIP))
               w &= pixel_mask (p, x, rowin);
-            // wave-level early out: nothing lands in this strip
-            if (__ballot (w != 0) == 0)
-              continue;
-            const Px s = unpack (p.color);
-            if (p.rule == FLUTL_RULE_LERP) {
-              if ((p.color & 0x00ff00ffu) == 0u)
-                strip_blend<true, true> (t, s, w);
-              else
-                strip_blend<true, false> (t, s, w);
-            } else {
-              if ((p.color >> 24) == 255u)
-                strip_blend<false, true> (t, s, w);
-              else
-                strip_blend<false, false> (t, s, w);
+              if (__ballot (w != 0) == 0)
+                continue;
+              strip_apply (t[r], p, w);
             }
           } else {
             // ---- per-pixel premultiplied source, OVER: IMAGE / GROUP_END ----
             const bool is_end = p.op == FLUTL_OP_GROUP_END;
-            const uint32_t pmask = pixel_mask (p, x, rowin);
-            uint32_t sv[4] = { 0u, 0u, 0u, 0u };
-            if (is_end) {
-              // the group surface is what was painted since GROUP_BEGIN; swap
-              // the parked frame pixels back in
-              const uint4 dd = s_park[tid];
-#pragma unroll
-              for (int k = 0; k < 4; k++)
-                sv[k] = ((pmask >> (8 * k)) & 1u) ? pack (t[k]) : 0u;
-              t[0] = unpack (dd.x);
-              t[1] = unpack (dd.y);
-              t[2] = unpack (dd.z);
-              t[3] = unpack (dd.w);
-            } else if (rowin) {
-              const uint32_t rowoff = (uint32_t) p.a +
-                  (uint32_t) (y - p.d) * (uint32_t) p.b + (uint32_t) (x - p.c) * 4u;
-#pragma unroll
-              for (int k = 0; k < 4; k++)
-                if ((pmask >> (8 * k)) & 1u)
-                  sv[k] = *reinterpret_cast<const uint32_t *> (
-                      atlas + (rowoff + 4u * (uint32_t) k));
-            }
-            if (__ballot ((sv[0] | sv[1] | sv[2] | sv[3]) != 0) == 0)
-              continue;   // 0 OVER d == d
             const u16x2 al = splat (p.param);
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-              Px sp = unpack (sv[k]);
-              if (is_end) {   // (group IN alpha)
-                sp.rb = mul_un8 (sp.rb, al);
-                sp.ag = mul_un8 (sp.ag, al);
+            for (int r = 0; r < kRG; r++) {
+              const int ry0 = sy0 + 4 * r;
+              const bool touched = !(p.cy1 <= ry0 || p.cy0 >= ry0 + 4);
+              if (!is_end && !touched)
+                continue;
+              const int y = y0 + 4 * r;
+              const bool rowin = (uint32_t) (y - p.cy0) < (uint32_t) (p.cy1 - p.cy0);
+              const uint32_t pmask = pixel_mask (p, x, rowin);
+              uint32_t sv[4] = { 0u, 0u, 0u, 0u };
+              if (is_end) {
+                // the group surface is what was painted since GROUP_BEGIN;
+                // swap the parked frame pixels back in
+                const uint4 dd = s_park[r][lane];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                  sv[k] = ((pmask >> (8 * k)) & 1u) ? t[r][k] : 0u;
+                t[r][0] = dd.x;
+                t[r][1] = dd.y;
+                t[r][2] = dd.z;
+                t[r][3] = dd.w;
+              } else {
+                const uint32_t rowoff = (uint32_t) p.a +
+                    (uint32_t) (y - p.d) * (uint32_t) p.b + (uint32_t) (x - p.c) * 4u;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                  if ((pmask >> (8 * k)) & 1u)
+                    sv[k] = *reinterpret_cast<const uint32_t *> (
+                        atlas + (rowoff + 4u * (uint32_t) k));
               }
-              over (t[k], sp);
+              if (__ballot ((sv[0] | sv[1] | sv[2] | sv[3]) != 0) == 0)
+                continue;   // 0 OVER d == d
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                Px sp = unpack (sv[k]);
+                if (is_end) {   // (group IN alpha)
+                  sp.rb = mul_un8 (sp.rb, al);
+                  sp.ag = mul_un8 (sp.ag, al);
+                }
+                Px v = unpack (t[r][k]);
+                over (v, sp);
+                t[r][k] = pack (v);
+              }
             }
           }
+          if (!more)
+            break;
         }
       }
-    } while (!done);
+    }
+  }
 
-    // ---- store: every pixel exactly once ----------------------------------
-    if (x < (int) fp.width && y < (int) fp.height) {
-      uint8_t *out = dst + dst_off + (size_t) y * fp.stride + (size_t) x * 4;
-      if (x + 4 <= (int) fp.width && ((reinterpret_cast<uintptr_t> (out) & 15) == 0)) {
-        *reinterpret_cast<uint4 *> (out) =
-            make_uint4 (pack (t[0]), pack (t[1]), pack (t[2]), pack (t[3]));
+  // ---- store: every pixel exactly once --------------------------------------
+  if (x_lane < (int) fp.width) {
+#pragma unroll
+    for (int r = 0; r < kRG; r++) {
+      const int y = y_lane + 4 * r;
+      if (y >= (int) fp.height)
+        continue;
+      uint8_t *out = dst + dst_off + (size_t) y * fp.stride + (size_t) x_lane * 4;
+      if (x_lane + 4 <= (int) fp.width && ((reinterpret_cast<uintptr_t> (out) & 15) == 0)) {
+        *reinterpret_cast<uint4 *> (out) = make_uint4 (t[r][0], t[r][1], t[r][2], t[r][3]);
       } else {
-        const uint32_t tv[4] = { pack (t[0]), pack (t[1]), pack (t[2]), pack (t[3]) };
-        for (int k = 0; k < 4 && x + k < (int) fp.width; k++)
-          reinterpret_cast<uint32_t *> (out)[k] = tv[k];
+        for (int k = 0; k < 4 && x_lane + k < (int) fp.width; k++)
+          reinterpret_cast<uint32_t *> (out)[k] = t[r][k];
       }
     }
   }
