@@ -29,6 +29,7 @@ typedef struct
   void *font;      /* cairo_scaled_font_t *, referenced */
   uint32_t glyph;
   uint32_t used;
+  double lin[4];   /* xx, yx, xy, yy of the CTM the glyph is shown under */
   uint32_t offset; /* atlas offset of the tight A8 bitmap */
   int w, h;        /* tight bitmap size; 0 x 0 = blank glyph */
   int bx, by;      /* bitmap top-left relative to the glyph origin */
@@ -52,8 +53,12 @@ typedef struct
 /* a piece of a pending outline path, with the CTM it is issued under */
 typedef struct
 {
-  PangoFont *font;           /* glyph outline if set, else a rectangle */
+  PangoFont *font;           /* glyph outline if set ... */
   PangoGlyphInfo gi;
+  cairo_scaled_font_t *sfont; /* ... or an anamorphic glyph (cairo_glyph_path under
+                               * cairo_scale (hscale, 1)) if set, else a rectangle */
+  unsigned long sglyph;
+  double hscale;
   double x, y, w, h;
   cairo_matrix_t m;
 } PathOp;
@@ -109,6 +114,8 @@ struct FlutlRecorder
 
   uint32_t unsupported;
 };
+
+static void path_ops_clear (FlutlRecorder *rec);
 
 /* ---- small helpers --------------------------------------------------------- */
 
@@ -397,9 +404,7 @@ flutl_recorder_free (FlutlRecorder *rec)
   free (rec->new_size);
   free (rec->images);
   free (rec->masks);
-  for (uint32_t i = 0; i < rec->n_ops; i++)
-    if (rec->ops[i].font)
-      g_object_unref (rec->ops[i].font);
+  path_ops_clear (rec);
   free (rec->ops);
   free (rec->strokes);
   free (rec);
@@ -430,10 +435,7 @@ flutl_recorder_begin_frame (FlutlRecorder *rec, int width, int height)
   rec->frame_clear = 1;
   rec->group_clear = 1;
   rec->unsupported = 0;
-  for (uint32_t i = 0; i < rec->n_ops; i++)
-    if (rec->ops[i].font)
-      g_object_unref (rec->ops[i].font);
-  rec->n_ops = 0;
+  path_ops_clear (rec);
   flutl_recorder_set_color (rec, 0, 0, 0, 1);
 }
 
@@ -601,19 +603,31 @@ void
 flutl_recorder_fill_rect (FlutlRecorder *rec, double x, double y, double w, double h)
 {
   cairo_matrix_t m;
-  if (!ctm_is_translation (rec->cr, &m)) {
-    rec->unsupported++;   /* rotated writing modes: not implemented yet */
-    return;
-  }
+  cairo_get_matrix (rec->cr, &m);
   if (rec->color_clear)
     return;               /* OVER with a clear source is a no-op in cairo */
-  /* cairo_rectangle: move_to (x, y) then relative segments */
-  double dx = x, dy = y;
-  cairo_matrix_transform_point (&m, &dx, &dy);
-  int32_t fx1 = fixed_from_double (dx), fy1 = fixed_from_double (dy);
-  int32_t fx2 = fx1 + fixed_from_double (w), fy2 = fy1 + fixed_from_double (h);
-  if (fx2 < fx1) { int32_t t = fx1; fx1 = fx2; fx2 = t; }
-  if (fy2 < fy1) { int32_t t = fy1; fy1 = fy2; fy2 = t; }
+  /* cairo_rectangle: move_to (x, y), then three relative segments; the start
+   * point and every segment vector are mapped through the CTM and converted to
+   * 24.8 fixed point on their own (cairo-path-fixed.c) */
+  double px = x, py = y;
+  cairo_matrix_transform_point (&m, &px, &py);
+  double ax = w, ay = 0, bx = 0, by = h;
+  cairo_matrix_transform_distance (&m, &ax, &ay);
+  cairo_matrix_transform_distance (&m, &bx, &by);
+  int32_t p0x = fixed_from_double (px), p0y = fixed_from_double (py);
+  int32_t p1x = p0x + fixed_from_double (ax), p1y = p0y + fixed_from_double (ay);
+  int32_t p2x = p1x + fixed_from_double (bx), p2y = p1y + fixed_from_double (by);
+  int32_t p3x = p2x + fixed_from_double (-ax), p3y = p2y + fixed_from_double (-ay);
+  /* a box in device space?  (translations, and the 90 degree rotation of the
+   * vertical writing modes, whose cos (pi/2) = 6e-17 vanishes in fixed point) */
+  int horiz_first = p0y == p1y && p1x == p2x && p2y == p3y && p3x == p0x;
+  int vert_first = p0x == p1x && p1y == p2y && p2x == p3x && p3y == p0y;
+  if (!horiz_first && !vert_first) {
+    rec->unsupported++;   /* general polygon fill: not a rectangle on the device */
+    return;
+  }
+  int32_t fx1 = p0x < p2x ? p0x : p2x, fx2 = p0x < p2x ? p2x : p0x;
+  int32_t fy1 = p0y < p2y ? p0y : p2y, fy2 = p0y < p2y ? p2y : p0y;
   if (fx1 == fx2 || fy1 == fy2)
     return;
   int x0 = fx1 >> 8, y0 = fy1 >> 8, x1 = (fx2 + 255) >> 8, y1 = (fy2 + 255) >> 8;
@@ -647,7 +661,7 @@ glyph_hash (const void *font, uint32_t glyph)
 }
 
 static GlyphEntry *glyph_lookup (FlutlRecorder *rec, cairo_scaled_font_t *sf,
-    uint32_t glyph);
+    uint32_t glyph, const cairo_matrix_t *m);
 
 static void
 glyph_grow (FlutlRecorder *rec)
@@ -681,14 +695,31 @@ glyph_rasterise (FlutlRecorder *rec, cairo_scaled_font_t *sf, GlyphEntry *e)
   e->w = e->h = 0;
   if (!(ext.width > 0) || !(ext.height > 0))
     return;
-  int x0 = (int) floor (ext.x_bearing) - 2, y0 = (int) floor (ext.y_bearing) - 2;
-  int w = (int) ceil (ext.width) + 6, h = (int) ceil (ext.height) + 6;
+  /* device-space box of the glyph under the linear part of the CTM (identity
+   * for plain text; a shear for reverseOblique; a rotation for vertical
+   * writing modes): Cairo makes a scaled font for that CTM and FreeType
+   * transforms the outline before rasterising */
+  cairo_matrix_t lin;
+  cairo_matrix_init (&lin, e->lin[0], e->lin[1], e->lin[2], e->lin[3], 0, 0);
+  double bx0 = 1e30, by0 = 1e30, bx1 = -1e30, by1 = -1e30;
+  for (int c = 0; c < 4; c++) {
+    double px = ext.x_bearing + ((c & 1) ? ext.width : 0);
+    double py = ext.y_bearing + ((c & 2) ? ext.height : 0);
+    cairo_matrix_transform_point (&lin, &px, &py);
+    if (px < bx0) bx0 = px;
+    if (px > bx1) bx1 = px;
+    if (py < by0) by0 = py;
+    if (py > by1) by1 = py;
+  }
+  int x0 = (int) floor (bx0) - 3, y0 = (int) floor (by0) - 3;
+  int w = (int) ceil (bx1 - bx0) + 8, h = (int) ceil (by1 - by0) + 8;
   cairo_surface_t *s = cairo_image_surface_create (CAIRO_FORMAT_A8, w, h);
   cairo_t *cr = cairo_create (s);
+  lin.x0 = -x0;                 /* glyph origin at the integer pixel (-x0, -y0) */
+  lin.y0 = -y0;
+  cairo_set_matrix (cr, &lin);
   cairo_set_scaled_font (cr, sf);
   cairo_set_source_rgba (cr, 1, 1, 1, 1);
-  g.x = -x0;
-  g.y = -y0;
   cairo_show_glyphs (cr, &g, 1);
   cairo_destroy (cr);
   cairo_surface_flush (s);
@@ -721,20 +752,27 @@ glyph_rasterise (FlutlRecorder *rec, cairo_scaled_font_t *sf, GlyphEntry *e)
 }
 
 static GlyphEntry *
-glyph_lookup (FlutlRecorder *rec, cairo_scaled_font_t *sf, uint32_t glyph)
+glyph_lookup (FlutlRecorder *rec, cairo_scaled_font_t *sf, uint32_t glyph,
+    const cairo_matrix_t *m)
 {
   if (rec->glyph_count * 2 >= rec->glyph_cap)
     glyph_grow (rec);
   uint32_t j = glyph_hash (sf, glyph) & (rec->glyph_cap - 1);
   while (rec->glyphs[j].used) {
-    if (rec->glyphs[j].font == sf && rec->glyphs[j].glyph == glyph)
-      return &rec->glyphs[j];
+    GlyphEntry *c = &rec->glyphs[j];
+    if (c->font == sf && c->glyph == glyph && c->lin[0] == m->xx && c->lin[1] == m->yx &&
+        c->lin[2] == m->xy && c->lin[3] == m->yy)
+      return c;
     j = (j + 1) & (rec->glyph_cap - 1);
   }
   GlyphEntry *e = &rec->glyphs[j];
   e->used = 1;
   e->font = cairo_scaled_font_reference (sf);
   e->glyph = glyph;
+  e->lin[0] = m->xx;
+  e->lin[1] = m->yx;
+  e->lin[2] = m->xy;
+  e->lin[3] = m->yy;
   rec->glyph_count++;
   glyph_rasterise (rec, sf, e);
   return e;
@@ -751,10 +789,7 @@ flutl_recorder_show_glyph (FlutlRecorder *rec, PangoFont *font,
     rec->unsupported++;   /* hex-box rendering of unknown glyphs */
     return;
   }
-  if (!ctm_is_translation (rec->cr, &m)) {
-    rec->unsupported++;   /* sheared / rotated glyphs: not implemented yet */
-    return;
-  }
+  cairo_get_matrix (rec->cr, &m);
   if (rec->color_clear)
     return;
   cairo_scaled_font_t *sf =
@@ -762,12 +797,19 @@ flutl_recorder_show_glyph (FlutlRecorder *rec, PangoFont *font,
   if (!sf)
     return;
   /* pango_cairo_renderer: position = current point (none -> 0,0) + offsets;
-   * cairo then adds the CTM translation and rounds half up (_cairo_lround). */
+   * cairo maps it through the CTM (a plain addition for a translation) and the
+   * image backend rounds half up (_cairo_lround). */
   double cx = (double) gi->geometry.x_offset / PANGO_SCALE;
   double cy = gi->geometry.y_offset == 0
       ? 0.0 : (double) gi->geometry.y_offset / PANGO_SCALE;
-  int ix = (int) floor (cx + m.x0 + 0.5), iy = (int) floor (cy + m.y0 + 0.5);
-  GlyphEntry *e = glyph_lookup (rec, sf, gi->glyph);
+  if (m.xx == 1.0 && m.yy == 1.0 && m.xy == 0.0 && m.yx == 0.0) {
+    cx += m.x0;
+    cy += m.y0;
+  } else {
+    cairo_matrix_transform_point (&m, &cx, &cy);
+  }
+  int ix = (int) floor (cx + 0.5), iy = (int) floor (cy + 0.5);
+  GlyphEntry *e = glyph_lookup (rec, sf, gi->glyph, &m);
   target_touched (rec);
   if (e->w == 0)
     return;
@@ -808,9 +850,12 @@ flutl_recorder_show_glyph (FlutlRecorder *rec, PangoFont *font,
 static void
 path_ops_clear (FlutlRecorder *rec)
 {
-  for (uint32_t i = 0; i < rec->n_ops; i++)
+  for (uint32_t i = 0; i < rec->n_ops; i++) {
     if (rec->ops[i].font)
       g_object_unref (rec->ops[i].font);
+    if (rec->ops[i].sfont)
+      cairo_scaled_font_destroy (rec->ops[i].sfont);
+  }
   rec->n_ops = 0;
 }
 
@@ -837,6 +882,16 @@ flutl_recorder_path_glyph (FlutlRecorder *rec, PangoFont *font,
 }
 
 void
+flutl_recorder_path_scaled_glyph (FlutlRecorder *rec, cairo_scaled_font_t *sfont,
+    unsigned long glyph, double hscale)
+{
+  PathOp *op = path_op_push (rec);
+  op->sfont = cairo_scaled_font_reference (sfont);
+  op->sglyph = glyph;
+  op->hscale = hscale;
+}
+
+void
 flutl_recorder_path_rect (FlutlRecorder *rec, double x, double y, double w, double h)
 {
   PathOp *op = path_op_push (rec);
@@ -851,7 +906,7 @@ static size_t
 stroke_key (FlutlRecorder *rec, double line_width, int base_x, int base_y,
     uint8_t **out)
 {
-  size_t per = 8 * sizeof (double) + 2 * sizeof (uint64_t);
+  size_t per = 10 * sizeof (double) + 2 * sizeof (uint64_t);
   size_t n = sizeof (double) + rec->n_ops * per;
   uint8_t *k = malloc (n), *p = k;
   if (!k)
@@ -860,10 +915,14 @@ stroke_key (FlutlRecorder *rec, double line_width, int base_x, int base_y,
   p += sizeof (double);
   for (uint32_t i = 0; i < rec->n_ops; i++) {
     const PathOp *op = &rec->ops[i];
-    double d[8] = { op->m.x0 - base_x, op->m.y0 - base_y, op->m.xx, op->m.yy,
-      op->x, op->y, op->w, op->h };
+    double d[10] = { op->m.x0 - base_x, op->m.y0 - base_y, op->m.xx, op->m.yy,
+      op->x, op->y, op->w, op->h, op->m.xy, op->m.yx };
     uint64_t u[2] = { 0, 0 };
-    if (op->font) {
+    if (op->sfont) {
+      u[0] = (uint64_t) (uintptr_t) op->sfont ^ 0x5a5a5a5a00000000ull;
+      u[1] = (uint64_t) op->sglyph;
+      d[4] = op->hscale;
+    } else if (op->font) {
       u[0] = (uint64_t) (uintptr_t) pango_cairo_font_get_scaled_font (
           (PangoCairoFont *) op->font);
       u[1] = ((uint64_t) op->gi.glyph << 32) ^
@@ -910,7 +969,7 @@ stroke_emit (FlutlRecorder *rec, const StrokeEntry *e, int dx, int dy)
  * scratch surface.  Returns 0 if the stroke touched the surface borders (the
  * mask is then only valid at this very position). */
 static int
-stroke_rasterise (FlutlRecorder *rec, StrokeEntry *e)
+stroke_rasterise (FlutlRecorder *rec, StrokeEntry *e, int fill)
 {
   cairo_t *cr = rec->cr;
   cairo_new_path (cr);
@@ -918,7 +977,12 @@ stroke_rasterise (FlutlRecorder *rec, StrokeEntry *e)
     const PathOp *op = &rec->ops[i];
     cairo_save (cr);
     cairo_set_matrix (cr, &op->m);
-    if (op->font) {
+    if (op->sfont) {
+      cairo_glyph_t g = { op->sglyph, 0, 0 };
+      cairo_scale (cr, op->hscale, 1.0);
+      cairo_set_scaled_font (cr, op->sfont);
+      cairo_glyph_path (cr, &g, 1);
+    } else if (op->font) {
       PangoGlyphInfo gi = op->gi;
       PangoGlyphString one = { 1, &gi, NULL, 1 };
       pango_cairo_glyph_string_path (cr, op->font, &one);
@@ -930,7 +994,10 @@ stroke_rasterise (FlutlRecorder *rec, StrokeEntry *e)
   double ex1, ey1, ex2, ey2;
   cairo_save (cr);
   cairo_identity_matrix (cr);            /* extents in device space */
-  cairo_stroke_extents (cr, &ex1, &ey1, &ex2, &ey2);
+  if (fill)
+    cairo_fill_extents (cr, &ex1, &ey1, &ex2, &ey2);
+  else
+    cairo_stroke_extents (cr, &ex1, &ey1, &ex2, &ey2);
   cairo_restore (cr);
   int inside = ex1 >= 3 && ey1 >= 3 && ex2 <= rec->width - 3 && ey2 <= rec->height - 3;
   int bx0 = imax ((int) floor (ex1) - 2, 0), by0 = imax ((int) floor (ey1) - 2, 0);
@@ -944,7 +1011,10 @@ stroke_rasterise (FlutlRecorder *rec, StrokeEntry *e)
   /* coverage = what the stroker + scan converter hand to the span renderer */
   cairo_save (cr);
   cairo_set_source_rgba (cr, 1, 1, 1, 1);
-  cairo_stroke (cr);
+  if (fill)
+    cairo_fill (cr);
+  else
+    cairo_stroke (cr);
   cairo_restore (cr);
   cairo_surface_flush (rec->scratch);
   uint8_t *data = cairo_image_surface_get_data (rec->scratch);
@@ -986,8 +1056,24 @@ stroke_rasterise (FlutlRecorder *rec, StrokeEntry *e)
   return inside;
 }
 
+static void path_to_mask (FlutlRecorder *rec, int fill);
+
 void
 flutl_recorder_stroke (FlutlRecorder *rec)
+{
+  path_to_mask (rec, 0);
+}
+
+/* cairo_fill of the pending path (anamorphic glyphs, :1109-1117): coverage from
+ * the polygon scan converter, same rule selection as a stroke. */
+void
+flutl_recorder_fill (FlutlRecorder *rec)
+{
+  path_to_mask (rec, 1);
+}
+
+static void
+path_to_mask (FlutlRecorder *rec, int fill)
 {
   if (rec->n_ops == 0)
     return;
@@ -995,15 +1081,8 @@ flutl_recorder_stroke (FlutlRecorder *rec)
     path_ops_clear (rec);
     return;
   }
-  for (uint32_t i = 0; i < rec->n_ops; i++) {
-    const cairo_matrix_t *m = &rec->ops[i].m;
-    if (m->xx != 1.0 || m->yy != 1.0 || m->xy != 0.0 || m->yx != 0.0) {
-      rec->unsupported++;   /* rotated writing modes: not implemented yet */
-      path_ops_clear (rec);
-      return;
-    }
-  }
-  double lw = cairo_get_line_width (rec->cr);
+  /* a fill does not depend on the line width: key it with a marker instead */
+  double lw = fill ? -1.0 : cairo_get_line_width (rec->cr);
   int base_x = (int) floor (rec->ops[0].m.x0), base_y = (int) floor (rec->ops[0].m.y0);
   uint8_t *key;
   size_t key_len = stroke_key (rec, lw, base_x, base_y, &key);
@@ -1030,7 +1109,7 @@ flutl_recorder_stroke (FlutlRecorder *rec)
     e->key_len = key_len;
     e->base_x = base_x;
     e->base_y = base_y;
-    e->translatable = stroke_rasterise (rec, e);
+    e->translatable = stroke_rasterise (rec, e, fill);
     stroke_emit (rec, e, 0, 0);
   }
   target_touched (rec);

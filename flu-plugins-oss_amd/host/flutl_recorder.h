@@ -73,6 +73,12 @@ void flutl_recorder_path_glyph (FlutlRecorder *rec, PangoFont *font,
     const PangoGlyphInfo *gi);
 void flutl_recorder_path_rect (FlutlRecorder *rec, double x, double y, double w,
     double h);
+/* anamorphic glyph (:1105-1112): cairo_scale (hscale, 1) + cairo_set_scaled_font
+ * + cairo_glyph_path of one glyph at the CTM origin */
+void flutl_recorder_path_scaled_glyph (FlutlRecorder *rec, cairo_scaled_font_t *sfont,
+    unsigned long glyph, double hscale);
+/* cairo_fill of the pending path (:1117) */
+void flutl_recorder_fill (FlutlRecorder *rec);
 
 /* cairo_stroke of the pending path with the tracking context's line width
  * (:1212, and the intermediate strokes of show_layout in path mode). */

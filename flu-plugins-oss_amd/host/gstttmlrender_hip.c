@@ -21,8 +21,8 @@
  * the odd ones; each is marked "reference:" below.
  *
  * Not implemented yet (counted and logged, never silently approximated):
- * vertical writing modes (tbrl/tblr), anamorphic font sizes, reverseOblique,
- * blurred outlines at fractional positions or with a blur above 8 px.
+ * blurred outlines at fractional positions or with a blur above 8 px,
+ * unknown-glyph boxes.
  */
 #ifdef HAVE_CONFIG_H
 #include "config.h"
@@ -465,6 +465,101 @@ smuggled_color (guint32 c, guint16 *r, guint16 *g, guint16 *b)
   *b = c & 0xFF00;
 }
 
+/* Anamorphic font size "w h" (reference :745-857): every character of the span
+ * becomes a Pango shape of the horizontally scaled glyph's size; the draw loop
+ * later fills the scaled glyph outline itself.  The font is chosen here, from
+ * the markup parsed so far -- it may not be the one Pango picks (reference
+ * comment :753-756); reproduced as is. */
+typedef struct
+{
+  unsigned long glyph;
+  double hscale;
+  cairo_scaled_font_t *font;
+} HipShape;
+
+static gpointer
+hip_shape_copy (gconstpointer data)
+{
+  const HipShape *s = data;
+  HipShape *n = g_new0 (HipShape, 1);
+  *n = *s;
+  cairo_scaled_font_reference (n->font);
+  return n;
+}
+
+static void
+hip_shape_free (gpointer data)
+{
+  HipShape *s = data;
+  cairo_scaled_font_destroy (s->font);
+  g_free (s);
+}
+
+static void
+anamorphic_shapes (GstTTMLRender *render, HipRegion *r, GstTTMLSpan *span,
+    GstTTMLAttribute *a)
+{
+  PangoAttrList *parsed = NULL;
+  PangoAttrIterator *it;
+  PangoAttribute *fd;
+  PangoFontset *fontset;
+  gint start = 0, end = 0;
+  const gchar *p = span->chars, *stop = span->chars + span->length;
+  double hscale = norm_len (render, a, 0, 0) / norm_len (render, a, 1, 1);
+
+  if (!pango_parse_markup (r->par->str, -1, 0, &parsed, NULL, NULL, NULL) || !parsed)
+    return;
+  /* the attributes in force on the text just appended */
+  it = pango_attr_list_get_iterator (parsed);
+  while (end < r->par_plain_len) {
+    pango_attr_iterator_next (it);
+    pango_attr_iterator_range (it, &start, &end);
+  }
+  fd = pango_attr_iterator_get (it, PANGO_ATTR_FONT_DESC);
+  if (fd) {
+    fontset = pango_font_map_load_fontset (pango_cairo_font_map_get_default (),
+        render->pango_context, ((PangoAttrFontDesc *) fd)->desc, NULL);
+    while (p < stop) {
+      const gchar *next = g_utf8_next_char (p);
+      gunichar wc = g_utf8_get_char (p);
+      PangoFont *font = pango_fontset_get_font (fontset, wc);
+      cairo_scaled_font_t *sf =
+          pango_cairo_font_get_scaled_font ((PangoCairoFont *) font);
+      cairo_glyph_t *glyphs = NULL;
+      int n_glyphs = 0;
+      PangoRectangle ink, logical;
+      HipShape *shape;
+      PangoAttribute *sa;
+
+      cairo_scaled_font_text_to_glyphs (sf, 0, 0, p, next - p, &glyphs, &n_glyphs,
+          NULL, NULL, NULL);
+      pango_font_get_glyph_extents (font, glyphs->index, &ink, &logical);
+      /* int *= double: truncation, as in the reference (:816-819) */
+      logical.width *= hscale;
+      ink.width *= hscale;
+      logical.x *= hscale;
+      ink.x *= hscale;
+      shape = g_new0 (HipShape, 1);
+      shape->glyph = glyphs->index;
+      shape->hscale = hscale;
+      shape->font = cairo_scaled_font_reference (sf);
+      cairo_glyph_free (glyphs);
+      g_object_unref (font);
+      sa = pango_attr_shape_new_with_data (&ink, &logical, shape, hip_shape_copy,
+          hip_shape_free);
+      sa->start_index = r->par_plain_len + (p - span->chars);
+      sa->end_index = r->par_plain_len + (next - span->chars);
+      if (!r->par_attrs)
+        r->par_attrs = pango_attr_list_new ();
+      pango_attr_list_insert (r->par_attrs, sa);
+      p = next;
+    }
+    g_object_unref (fontset);
+  }
+  pango_attr_iterator_destroy (it);
+  pango_attr_list_unref (parsed);
+}
+
 static void
 span_to_region (GstTTMLRender *render, GList **regions, GstTTMLSpan *span)
 {
@@ -543,10 +638,8 @@ span_to_region (GstTTMLRender *render, GList **regions, GstTTMLSpan *span)
     par_add_attr (r, hip_attr_new (&hip_attr_klass[HIP_ATTR_INVISIBLE], 0, start, end));
 
   a = gst_ttml_style_get_attr (&span->style, GST_TTML_ATTR_FONT_SIZE);
-  if (a && gst_ttml_attribute_is_length_present (a, 1)) {
-    /* anamorphic "w h" font size (reference :745-857): not implemented */
-    GST_FIXME_OBJECT (render, "anamorphic fontSize is not implemented");
-  }
+  if (a && gst_ttml_attribute_is_length_present (a, 1) && r->par)
+    anamorphic_shapes (render, r, span, a);
 
   a = gst_ttml_style_get_attr (&span->style, GST_TTML_ATTR_BACKGROUND_COLOR);
   if (a && (a->value.color & 0xFF)) {
@@ -811,12 +904,20 @@ walk_layout (GstTTMLRender *render, FlutlRecorder *rec, PangoLayout *layout,
             } else if (attr->klass == &hip_attr_klass[HIP_ATTR_REVERSE_OBLIQUE]) {
               oblique = TRUE;
             }
+            if (attr->klass->type == PANGO_ATTR_SHAPE) {
+              /* anamorphic glyph (reference :1101-1120): the scaled outline is
+               * filled (or stroked, in the outline pass) as a path */
+              HipShape *shape = ((PangoAttrShape *) attr)->data;
+              flutl_recorder_path_scaled_glyph (rec, shape->font, shape->glyph,
+                  shape->hscale);
+              if (fill)
+                flutl_recorder_fill (rec);
+              else
+                flutl_recorder_stroke (rec);
+              skip = TRUE;
+            }
             break;
         }
-      }
-      if (oblique) {
-        GST_FIXME_OBJECT (render, "reverseOblique is not implemented");
-        skip = TRUE;
       }
 
       if (!skip) {
@@ -825,6 +926,12 @@ walk_layout (GstTTMLRender *render, FlutlRecorder *rec, PangoLayout *layout,
         for (i = 0; i < n; i++) {
           PangoGlyphInfo *gi = &gs->glyphs[reverse ? n - 1 - i : i];
           cairo_save (cr);
+          if (oblique) {
+            /* reference :1125, :1141-1143: reverseOblique = x += y / 4 */
+            cairo_matrix_t shear;
+            cairo_matrix_init (&shear, 1, 0, 0.25, 1, 0, 0);
+            cairo_transform (cr, &shear);
+          }
           /* reference: the glyph offsets are applied here AND again by Pango */
           cairo_translate (cr, gi->geometry.x_offset / (double) PANGO_SCALE,
               gi->geometry.y_offset / (double) PANGO_SCALE);
@@ -1025,11 +1132,22 @@ record_region (HipRegion *r, GstTTMLRender *render)
     cairo_translate (cr, 0, posy);
   }
 
+  cairo_save (cr);
   if (r->writing_mode == GST_TTML_WRITING_MODE_TBRL ||
       r->writing_mode == GST_TTML_WRITING_MODE_TBLR) {
-    GST_FIXME_OBJECT (render, "vertical writing modes are not implemented; "
-        "the text of region '%s' is not drawn", r->id);
-  } else {
+    /* reference :1313-1340: the CTM is REPLACED by a quarter turn, and the
+     * shared Pango context is switched to east gravity -- for good: the
+     * reference never switches it back, so later layouts inherit it */
+    cairo_matrix_t om;
+    cairo_matrix_init_rotate (&om, G_PI / 2);
+    cairo_matrix_translate (&om, r->pox,
+        r->writing_mode == GST_TTML_WRITING_MODE_TBRL ? -r->pex : -r->poy);
+    cairo_set_matrix (cr, &om);
+    pango_context_set_base_gravity (render->pango_context, PANGO_GRAVITY_EAST);
+    pango_context_set_gravity_hint (render->pango_context, PANGO_GRAVITY_HINT_STRONG);
+    pango_cairo_update_context (cr, render->pango_context);
+  }
+  {
     for (l = r->layouts; l; l = l->next) {
       gboolean outlined =
           r->outline.length[0].unit != GST_TTML_LENGTH_UNIT_NOT_PRESENT;
@@ -1042,6 +1160,7 @@ record_region (HipRegion *r, GstTTMLRender *render)
       walk_layout (render, rec, l->data, TRUE, r->pex, !outlined, r->writing_mode);
     }
   }
+  cairo_restore (cr);
 
   if (grouped)
     flutl_recorder_group_end (rec, r->opacity);

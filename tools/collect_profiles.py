@@ -17,9 +17,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL = "flutl_composite_kernel"
 
 
+def newest(pattern):
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:] if files else []
+
+
 def pmc_avg(d):
     acc = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
+    for f in newest(os.path.join(d, "*", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             if KERNEL in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -30,7 +35,7 @@ def main():
     rnd, tags = sys.argv[1], sys.argv[2:]
     for tag in tags:
         src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
-        stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
+        stats = newest(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
         out = {"tag": tag}
         if stats:
             dst = os.path.join(ROOT, "profiles", f"{rnd}_{tag}_kernel_stats.csv")
