@@ -235,22 +235,25 @@ __device__ __forceinline__ void strip_blend (Px (&t)[4], Px s, uint32_t w)
 
 // The 4 A8 coverage bytes of a MASK primitive for this lane's 4 pixels on row
 // y.  Issued one primitive ahead of use: OVER is order dependent, the loads
-// are not.  Branch free: lanes that the prim does not touch load the first
-// (slack) dword of the atlas and discard it, so no EXEC juggling is needed.
+// are not.  Branch free AND select free: lanes that the prim does not touch
+// (and every lane, for other ops) load the first dword of the atlas, which is
+// zero by contract (include/flutl.h: leading slack), so nothing depends on the
+// loaded value until the blend -- a select on the value would make the
+// compiler wait for each load right where it is issued.
 // Bytes left/right of the mask read its zero padding (atlas contract).
 __device__ __forceinline__ uint32_t mask_fetch (const PrimU &p,
     const uint8_t *__restrict__ atlas, int x, int y)
 {
-  if (p.op != FLUTL_OP_MASK)    // wave uniform
-    return 0u;
-  const bool valid = (uint32_t) (y - p.cy0) < (uint32_t) (p.cy1 - p.cy0) &&
+  // wave uniform: no rows for other ops
+  const uint32_t rows = p.op == FLUTL_OP_MASK ? (uint32_t) (p.cy1 - p.cy0) : 0u;
+  const bool valid = (uint32_t) (y - p.cy0) < rows &&
       (uint32_t) (x + 3 - p.cx0) < (uint32_t) (p.cx1 - p.cx0 + 3);
   // rows and strides are < 2^15: 24-bit multiply-add (full rate)
   const uint32_t off = __umul24 ((uint32_t) (y - p.d), (uint32_t) p.b) +
       (uint32_t) (p.a - p.c) + (uint32_t) x;
   uint32_t w;
   __builtin_memcpy (&w, atlas + (valid ? off : 0u), 4);
-  return valid ? w : 0u;
+  return w;
 }
 
 // Per-lane pixel predicates as a byte mask over the lane's 4 pixels, by
