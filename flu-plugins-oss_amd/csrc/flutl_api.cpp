@@ -110,6 +110,9 @@ extern "C" int flutl_list_validate (uint32_t width, uint32_t height,
             return FLUTL_EINVAL;
           if (p.op == FLUTL_OP_MASK && (p.param & ~FLUTL_MASK_XCLIP))
             return FLUTL_EINVAL;
+          // the kernel forms (row - d) * stride with a signed 24-bit multiply
+          if (p.op == FLUTL_OP_MASK && (p.b > 0x7fffff || p.d < -0x400000))
+            return FLUTL_ERANGE;
           if (p.cx0 == p.cx1 || p.cy0 == p.cy1)
             break;
           if (p.cx0 < p.c || p.cy0 < p.d)

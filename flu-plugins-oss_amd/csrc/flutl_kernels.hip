@@ -40,6 +40,12 @@ constexpr int kThreads = 64;           // one wavefront per workgroup
 // A pixel is kept unpacked as two registers: rb = {B, R}, ag = {G, A}, one
 // 8-bit channel per 16-bit lane, so v_pk_mad_u16 & co process two channels.
 
+// Ablation builds for profiling notes; 0 = the product.
+#ifndef FLUTL_EXP
+#define FLUTL_EXP 0
+#endif
+
+
 struct Px {
   u16x2 rb, ag;
 };
@@ -128,7 +134,9 @@ struct FrameParams {
   uint32_t st_x, st_y;                  // supertiles per row / column
   uint32_t n_frames;
   uint32_t region_first, region_count;  // used when frames == nullptr
-  uint32_t per_xcd;                     // ceil(total_supertiles / 8)
+  uint32_t frame_first;                 // first frame of this launch
+  uint32_t xcd_frames, xcd_sts;         // workgroup mapping, see the kernel
+  uint32_t magic_stx;                   // ceil(2^32 / st_x), 0 if st_x == 1
   uint64_t stride;                      // bytes
 };
 
@@ -233,27 +241,43 @@ __device__ __forceinline__ void strip_blend (Px (&t)[4], Px s, uint32_t w)
   }
 }
 
-// The 4 A8 coverage bytes of a MASK primitive for this lane's 4 pixels on row
-// y.  Issued one primitive ahead of use: OVER is order dependent, the loads
-// are not.  Branch free AND select free: lanes that the prim does not touch
-// (and every lane, for other ops) load the first dword of the atlas, which is
-// zero by contract (include/flutl.h: leading slack), so nothing depends on the
-// loaded value until the blend -- a select on the value would make the
-// compiler wait for each load right where it is issued.
+// The A8 coverage bytes of a MASK primitive for this lane's 4 pixels in each
+// of its kRG strips (rows y0 + 4r).  Issued one primitive ahead of use: OVER
+// is order dependent, the loads are not.  Branch free AND select free: lanes
+// that the prim does not touch (and every lane, for other ops) load the first
+// dword of the atlas, which is zero by contract (include/flutl.h: leading
+// slack), so nothing depends on the loaded value until the blend -- a select
+// on the value would make the compiler wait for each load where it is issued.
 // Bytes left/right of the mask read its zero padding (atlas contract).
-__device__ __forceinline__ uint32_t mask_fetch (const PrimU &p,
-    const uint8_t *__restrict__ atlas, int x, int y)
+struct MaskFetch {
+  uint32_t w[kRG];
+};
+typedef uint32_t __attribute__ ((aligned (1))) u32_unaligned;
+
+__device__ __forceinline__ MaskFetch mask_fetch4 (const PrimU &p,
+    const uint8_t *__restrict__ atlas, int x, int y0)
 {
+  MaskFetch f;
   // wave uniform: no rows for other ops
   const uint32_t rows = p.op == FLUTL_OP_MASK ? (uint32_t) (p.cy1 - p.cy0) : 0u;
-  const bool valid = (uint32_t) (y - p.cy0) < rows &&
-      (uint32_t) (x + 3 - p.cx0) < (uint32_t) (p.cx1 - p.cx0 + 3);
-  // rows and strides are < 2^15: 24-bit multiply-add (full rate)
-  const uint32_t off = __umul24 ((uint32_t) (y - p.d), (uint32_t) p.b) +
+  const bool colin = (uint32_t) (x + 3 - p.cx0) < (uint32_t) (p.cx1 - p.cx0 + 3);
+  // |rows| and strides are < 2^15: 24-bit multiply (full rate).  SIGNED: strip
+  // 0 may lie above the mask (y0 < p.d) while a later strip of the same lane
+  // is valid, and off0 + r * step must then still be exact modulo 2^32.
+  const uint32_t off0 = (uint32_t) __mul24 (y0 - p.d, p.b) +
       (uint32_t) (p.a - p.c) + (uint32_t) x;
-  uint32_t w;
-  __builtin_memcpy (&w, atlas + (valid ? off : 0u), 4);
-  return w;
+  const uint32_t step = 4u * (uint32_t) p.b;
+#pragma unroll
+  for (int r = 0; r < kRG; r++) {
+    const bool valid = colin && (uint32_t) (y0 + 4 * r - p.cy0) < rows;
+    const uint32_t off = valid ? off0 + (uint32_t) r * step : 0u;
+#if FLUTL_EXP == 3   // ablation: no mask loads
+    f.w[r] = off;
+#else
+    f.w[r] = *reinterpret_cast<const u32_unaligned *> (atlas + off);
+#endif
+  }
+  return f;
 }
 
 // Per-lane pixel predicates as a byte mask over the lane's 4 pixels, by
@@ -268,26 +292,24 @@ __device__ __forceinline__ uint32_t pixel_mask (const PrimU &p, int x, bool rowi
   return rowin ? (mhi & ~mlo) : 0u;
 }
 
-// The lane's 4 row groups of a MASK primitive, fetched together (4 loads in
-// flight) one primitive ahead of their use.
-struct MaskFetch {
-  uint32_t w[kRG];
-};
-
-__device__ __forceinline__ MaskFetch mask_fetch4 (const PrimU &p,
-    const uint8_t *__restrict__ atlas, int x, int y0)
+// Bit r set for the strips r of the supertile with
+// floor (lo / 4) <= r < floor (hi / 4), rows relative to the supertile.
+// (Touch test: lo = first row, hi = last row + 4.  Cover test: lo = first
+// row + 3, hi = one past the last row.)  Wave uniform, scalar unit.
+__device__ __forceinline__ uint32_t strip_range (int lo, int hi)
 {
-  MaskFetch f;
-#pragma unroll
-  for (int r = 0; r < kRG; r++)
-    f.w[r] = mask_fetch (p, atlas, x, y0 + 4 * r);
-  return f;
+  const int a = min (max (lo >> 2, 0), kRG), b = min (max (hi >> 2, 0), kRG);
+  return b > a ? ((1u << b) - 1u) & ~((1u << a) - 1u) : 0u;
 }
 
 // blend one strip (4 packed pixels of the lane) with coverage dword w
-__device__ __forceinline__ void strip_apply (uint32_t (&tp)[4], const PrimU &p, uint32_t w)
+__device__ __forceinline__ void strip_apply (uint4 &v, const PrimU &p, uint32_t w)
 {
-  Px t[4] = { unpack (tp[0]), unpack (tp[1]), unpack (tp[2]), unpack (tp[3]) };
+#if FLUTL_EXP == 1   // ablation: no blend arithmetic
+  v.x ^= w;
+  return;
+#endif
+  Px t[4] = { unpack (v.x), unpack (v.y), unpack (v.z), unpack (v.w) };
   const Px s = unpack (p.color);
   if (p.rule == FLUTL_RULE_LERP) {
     if ((p.color & 0x00ff00ffu) == 0u)
@@ -300,38 +322,50 @@ __device__ __forceinline__ void strip_apply (uint32_t (&tp)[4], const PrimU &p, 
     else
       strip_blend<false, false> (t, s, w);
   }
-#pragma unroll
-  for (int k = 0; k < 4; k++)
-    tp[k] = pack (t[k]);
-  // do not let the scheduler interleave the blends of different strips: it
-  // would trade occupancy for ILP that the other waves already provide
-  __builtin_amdgcn_sched_barrier (0);
+  v = make_uint4 (pack (t[0]), pack (t[1]), pack (t[2]), pack (t[3]));
 }
 
+#ifdef FLUTL_WAVES   // ablation: pin the occupancy
+__attribute__ ((amdgpu_waves_per_eu (FLUTL_WAVES, FLUTL_WAVES)))
+#endif
 __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
     FrameParams fp, uint8_t *__restrict__ dst,
     const flutl_frame_desc *__restrict__ frames,
     const flutl_region *__restrict__ regions,
     const flutl_prim *__restrict__ prims, const uint8_t *__restrict__ atlas)
 {
-  // frame pixels parked during an opacity group: lane-private slots, so no
-  // barrier; this is the kernel's only LDS
-  __shared__ uint4 s_park[kRG][kThreads];
+  // The supertile's pixels live in LDS, not in registers: s_surf[0] is the
+  // frame, s_surf[1] the group surface of the region being painted (between
+  // GROUP_BEGIN and GROUP_END).  Every lane only ever touches its own 16-byte
+  // slots, so there is no barrier and no bank conflict (ds_*_b128, lane-linear).
+  // Why LDS: with the 16 pixels of a lane in VGPRs across four nested loops
+  // and ~20 control-flow joins per primitive, the register allocator kept up
+  // to three copies of them alive (118 VGPRs even with the blend arithmetic
+  // removed, ~450 v_mov in the loop).  A blend is ~100 VALU per strip; the
+  // LDS read + write it now costs is 16 LDS cycles per CU.
+  __shared__ uint4 s_surf[2][kRG][kThreads];
 
   // One wavefront per workgroup: nothing is shared between waves.
   const int lane = threadIdx.x;
 
-  // Blocks b and b+8 share an XCD (and its L2): XCD k gets the k-th contiguous
-  // band of supertiles, so the glyph masks and display-list entries of a band
-  // are fetched into one L2 only.  Speed only; any placement is correct.
-  const uint32_t st_per_frame = fp.st_x * fp.st_y;
-  const uint32_t total = st_per_frame * fp.n_frames;
-  const uint32_t logical = (blockIdx.x & 7u) * fp.per_xcd + (blockIdx.x >> 3);
-  if (logical >= total)
+  // Workgroup -> (frame, supertile).  Workgroups are handed to the 8 XCDs
+  // round robin (blockIdx.x & 7 is the XCD: grid.x is a multiple of 8), and
+  // -- measured, DESIGN.md 5.3 -- in lockstep: workgroup n+1 is not placed
+  // before workgroup n, so the 8 workgroups of a round should cost the same.
+  //  * batches: XCD k renders whole frames (xcd_frames of them); frames of
+  //    a batch are states of one stream with the same layout, so the 8
+  //    workgroups of a round are the same supertile of 8 sibling frames;
+  //  * fewer than 8 frames: XCD k renders the k-th contiguous band of
+  //    supertiles of every frame (xcd_sts per band).
+  // Either way an XCD's L2 sees each glyph mask and list entry of its band /
+  // frame once.  Speed only; any placement is correct.  No run-time division:
+  // the launch code chooses the grid so that these are multiply-adds.
+  const uint32_t xcd = blockIdx.x & 7u;
+  const uint32_t st = xcd * fp.xcd_sts + (blockIdx.x >> 3);
+  if (st >= fp.st_x * fp.st_y)
     return;
-  const uint32_t frame = logical / st_per_frame;
-  const uint32_t st = logical - frame * st_per_frame;
-  const uint32_t sty = st / fp.st_x;
+  const uint32_t frame = fp.frame_first + xcd * fp.xcd_frames + blockIdx.y;
+  const uint32_t sty = fp.magic_stx ? __umulhi (st, fp.magic_stx) : st;
   const uint32_t stx = st - sty * fp.st_x;
 
   uint32_t rfirst = fp.region_first, rcount = fp.region_count;
@@ -346,16 +380,17 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
   const int x_lane = sx0 + (lane & 15) * 4;
   const int y_lane = sy0 + (lane >> 4);         // row in strip 0; strip r: + 4r
 
-  // t = the surface being painted, 4 strips x 4 packed pixels per lane: the
-  // frame, or -- between GROUP_BEGIN and GROUP_END -- the region's group
-  // surface while the frame pixels are parked in s_park.
-  uint32_t t[kRG][4];
-#pragma unroll
-  for (int r = 0; r < kRG; r++)
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      t[r][k] = 0u;
+  // Wave-uniform bookkeeping (SGPRs): which strips of the current surface
+  // hold pixels (bit r); an untouched strip is transparent and is neither
+  // initialised nor read.  cur = surface being painted (0 frame, 1 group).
+  uint32_t touched = 0, touched_frame = 0, cur = 0;
 
+#define STRIP_LOAD(r)  ((touched >> (r)) & 1u ? s_surf[cur][r][lane] : make_uint4 (0u, 0u, 0u, 0u))
+#define STRIP_STORE(r, v) do { s_surf[cur][r][lane] = (v); touched |= 1u << (r); } while (0)
+
+#if FLUTL_EXP == 2     // ablation: store floor, no display list at all
+  rcount = 0;
+#endif
   // ---- regions, 64 at a time: one per lane, culled against the supertile ----
   for (uint32_t rbase = 0; rbase < rcount; rbase += 64) {
     // lanes past the end re-read the last region and are masked out
@@ -370,6 +405,10 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
       const int rl = __builtin_ctzll (rmask);
       rmask &= rmask - 1;
       const uint32_t pfirst = rdl (rv.z, rl), pcount = rdl (rv.w, rl);
+#if FLUTL_EXP == 4    // ablation: region cull only
+      touched ^= pfirst + pcount;
+      continue;
+#endif
 
       // ---- the region's prims, 64 at a time: bin and replay fused ----------
       for (uint32_t pbase = 0; pbase < pcount; pbase += 64) {
@@ -384,6 +423,10 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
         unsigned long long hits = __ballot (hit);
         if (!hits)
           continue;
+#if FLUTL_EXP == 5    // ablation: prim chunk load + bbox test only
+        touched ^= (uint32_t) hits ^ rdl (hi.x, 0);
+        continue;
+#endif
 
         // replay the hits in paint order (= lane order); the next hit's mask
         // bytes are requested before the current one is blended
@@ -403,99 +446,101 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
             hits &= hits - 1;
             fnxt = mask_fetch4 (nxt, atlas, x, y0);
           }
+#if FLUTL_EXP == 6    // ablation: replay loop without the op bodies
+          touched ^= p.color ^ rdl (f.w[0] ^ f.w[1] ^ f.w[2] ^ f.w[3], 0);
+          if (!more)
+            break;
+          continue;
+#endif
 
-          if (p.op == FLUTL_OP_GROUP_BEGIN) {
-            uint32_t zero = 0;
-            asm volatile ("" : "+v"(zero));    // no zero vector kept alive
+          if (p.op == FLUTL_OP_MASK || p.op == FLUTL_OP_RECT) {
+            // ---- solid colour through 8-bit coverage: an A8 mask, or the
+            //      24.8 box of cairo's rectangular scan converter -------------
+            const bool is_rect = p.op == FLUTL_OP_RECT;
+            // strips the clipped bbox touches, and (RECT) strips the box covers
+            // completely: bit masks made once per primitive with scalar ops
+            const uint32_t smask = strip_range (p.cy0 - sy0, p.cy1 - sy0 + 3);
+            uint32_t fmask = 0u;
+            if (is_rect && ((p.a + 255) >> 8) <= sx0 && (p.c >> 8) >= sx0 + kSuperW &&
+                p.cx0 <= sx0 && p.cx1 >= sx0 + kSuperW)
+              fmask = strip_range (max ((p.b + 255) >> 8, p.cy0) - sy0 + 3,
+                  min (p.d >> 8, p.cy1) - sy0);
 #pragma unroll
             for (int r = 0; r < kRG; r++) {
-              s_park[r][lane] = make_uint4 (t[r][0], t[r][1], t[r][2], t[r][3]);
-#pragma unroll
-              for (int k = 0; k < 4; k++)
-                t[r][k] = zero;
-            }
-          } else if (p.op == FLUTL_OP_MASK) {
-            // ---- solid colour through an A8 mask ---------------------------
-#pragma unroll
-            for (int r = 0; r < kRG; r++) {
-              const int ry0 = sy0 + 4 * r;           // scalar row test
-              if (p.cy1 <= ry0 || p.cy0 >= ry0 + 4)
+              if (((smask >> r) & 1u) == 0u)
                 continue;
-              uint32_t w = f.w[r];
-              if (p.param & FLUTL_MASK_XCLIP)
-                w &= pixel_mask (p, x, true);
+              uint32_t w;
+              if (is_rect) {
+                if ((fmask >> r) & 1u) {
+                  // coverage 255 on the whole strip: t = s OVER t with a uniform
+                  // s.  Opaque s, LERP, or nothing painted yet: t = s exactly.
+                  if ((p.color >> 24) == 255u || p.rule == FLUTL_RULE_LERP ||
+                      ((touched >> r) & 1u) == 0u) {
+                    STRIP_STORE (r, make_uint4 (p.color, p.color, p.color, p.color));
+                  } else {
+                    const Px sc = unpack (p.color);
+                    const uint4 d = s_surf[cur][r][lane];
+                    Px v0 = unpack (d.x), v1 = unpack (d.y), v2 = unpack (d.z), v3 = unpack (d.w);
+                    over (v0, sc);
+                    over (v1, sc);
+                    over (v2, sc);
+                    over (v3, sc);
+                    s_surf[cur][r][lane] = make_uint4 (pack (v0), pack (v1), pack (v2), pack (v3));
+                  }
+                  continue;
+                }
+                // cairo rectangular scan converter coverage
+                const int y = y0 + 4 * r;
+                const bool rowin = (uint32_t) (y - p.cy0) < (uint32_t) (p.cy1 - p.cy0);
+                const int oy = overlap256 (p.b, p.d, y);
+                w = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                  w |= min ((uint32_t) (overlap256 (p.a, p.c, x + k) * oy) >> 8, 255u) << (8 * k);
+                w &= pixel_mask (p, x, rowin);
+              } else {
+                w = f.w[r];
+                if (p.param & FLUTL_MASK_XCLIP)
+                  w &= pixel_mask (p, x, true);
+              }
               if (__ballot (w != 0) == 0)
                 continue;                            // nothing lands in this strip
-              strip_apply (t[r], p, w);
+              uint4 v = STRIP_LOAD (r);
+              strip_apply (v, p, w);
+              STRIP_STORE (r, v);
             }
-          } else if (p.op == FLUTL_OP_RECT) {
-            // ---- solid colour through a 24.8 box ---------------------------
-            const bool xfull = ((p.a + 255) >> 8) <= sx0 && (p.c >> 8) >= sx0 + kSuperW &&
-                p.cx0 <= sx0 && p.cx1 >= sx0 + kSuperW;
-#pragma unroll
-            for (int r = 0; r < kRG; r++) {
-              const int ry0 = sy0 + 4 * r;
-              if (p.cy1 <= ry0 || p.cy0 >= ry0 + 4)
-                continue;
-              const bool full = xfull && ((p.b + 255) >> 8) <= ry0 &&
-                  (p.d >> 8) >= ry0 + 4 && p.cy0 <= ry0 && p.cy1 >= ry0 + 4;
-              if (full) {
-                // coverage 255 on the whole strip: t = s OVER t with a uniform
-                // s.  Opaque s, LERP, or nothing painted yet: t = s exactly.
-                if ((p.color >> 24) == 255u || p.rule == FLUTL_RULE_LERP ||
-                    __ballot ((t[r][0] | t[r][1] | t[r][2] | t[r][3]) != 0) == 0) {
-#pragma unroll
-                  for (int k = 0; k < 4; k++)
-                    t[r][k] = p.color;
-                } else {
-                  const Px sc = unpack (p.color);
-#pragma unroll
-                  for (int k = 0; k < 4; k++) {
-                    Px v = unpack (t[r][k]);
-                    over (v, sc);
-                    t[r][k] = pack (v);
-                  }
-                }
-                continue;
-              }
-              // cairo rectangular scan converter coverage
-              const int y = y0 + 4 * r;
-              const bool rowin = (uint32_t) (y - p.cy0) < (uint32_t) (p.cy1 - p.cy0);
-              const int oy = overlap256 (p.b, p.d, y);
-              uint32_t w = 0;
-#pragma unroll
-              for (int k = 0; k < 4; k++)
-                w |= min ((uint32_t) (overlap256 (p.a, p.c, x + k) * oy) >> 8, 255u) << (8 * k);
-              w &= pixel_mask (p, x, rowin);
-              if (__ballot (w != 0) == 0)
-                continue;
-              strip_apply (t[r], p, w);
-            }
+          } else if (p.op == FLUTL_OP_GROUP_BEGIN) {
+            // the region's temporary surface starts transparent
+            touched_frame = touched;
+            touched = 0;
+            cur = 1;
           } else {
             // ---- per-pixel premultiplied source, OVER: IMAGE / GROUP_END ----
             const bool is_end = p.op == FLUTL_OP_GROUP_END;
+            uint32_t touched_group = 0;
+            if (is_end) {
+              // back to the frame; the group surface becomes the source
+              touched_group = touched;
+              touched = touched_frame;
+              cur = 0;
+            }
             const u16x2 al = splat (p.param);
 #pragma unroll
             for (int r = 0; r < kRG; r++) {
               const int ry0 = sy0 + 4 * r;
-              const bool touched = !(p.cy1 <= ry0 || p.cy0 >= ry0 + 4);
-              if (!is_end && !touched)
+              if (is_end ? ((touched_group >> r) & 1u) == 0u
+                         : (p.cy1 <= ry0 || p.cy0 >= ry0 + 4))
                 continue;
               const int y = y0 + 4 * r;
               const bool rowin = (uint32_t) (y - p.cy0) < (uint32_t) (p.cy1 - p.cy0);
               const uint32_t pmask = pixel_mask (p, x, rowin);
               uint32_t sv[4] = { 0u, 0u, 0u, 0u };
               if (is_end) {
-                // the group surface is what was painted since GROUP_BEGIN;
-                // swap the parked frame pixels back in
-                const uint4 dd = s_park[r][lane];
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                  sv[k] = ((pmask >> (8 * k)) & 1u) ? t[r][k] : 0u;
-                t[r][0] = dd.x;
-                t[r][1] = dd.y;
-                t[r][2] = dd.z;
-                t[r][3] = dd.w;
+                const uint4 g = s_surf[1][r][lane];
+                sv[0] = (pmask & 0x1u) ? g.x : 0u;
+                sv[1] = (pmask & 0x100u) ? g.y : 0u;
+                sv[2] = (pmask & 0x10000u) ? g.z : 0u;
+                sv[3] = (pmask & 0x1000000u) ? g.w : 0u;
               } else {
                 const uint32_t rowoff = (uint32_t) p.a +
                     (uint32_t) (y - p.d) * (uint32_t) p.b + (uint32_t) (x - p.c) * 4u;
@@ -507,6 +552,8 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
               }
               if (__ballot ((sv[0] | sv[1] | sv[2] | sv[3]) != 0) == 0)
                 continue;   // 0 OVER d == d
+              const uint4 d = STRIP_LOAD (r);
+              uint32_t dv[4] = { d.x, d.y, d.z, d.w };
 #pragma unroll
               for (int k = 0; k < 4; k++) {
                 Px sp = unpack (sv[k]);
@@ -514,10 +561,11 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
                   sp.rb = mul_un8 (sp.rb, al);
                   sp.ag = mul_un8 (sp.ag, al);
                 }
-                Px v = unpack (t[r][k]);
+                Px v = unpack (dv[k]);
                 over (v, sp);
-                t[r][k] = pack (v);
+                dv[k] = pack (v);
               }
+              STRIP_STORE (r, make_uint4 (dv[0], dv[1], dv[2], dv[3]));
             }
           }
           if (!more)
@@ -528,21 +576,28 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
   }
 
   // ---- store: every pixel exactly once --------------------------------------
-  if (x_lane < (int) fp.width) {
+  // (validated lists have balanced groups, so the frame is current here)
+  uint8_t *out = dst + dst_off + (size_t) y_lane * fp.stride + (size_t) x_lane * 4;
+  const bool interior = sx0 + kSuperW <= (int) fp.width && sy0 + kSuperH <= (int) fp.height &&
+      ((reinterpret_cast<uintptr_t> (dst) | dst_off | fp.stride) & 15u) == 0;   // scalar
+  if (interior) {
+#pragma unroll
+    for (int r = 0; r < kRG; r++)
+      *reinterpret_cast<uint4 *> (out + (size_t) (4 * r) * fp.stride) = STRIP_LOAD (r);
+  } else if (x_lane < (int) fp.width) {
+    // frame edge or unaligned destination: per-pixel bounds
 #pragma unroll
     for (int r = 0; r < kRG; r++) {
-      const int y = y_lane + 4 * r;
-      if (y >= (int) fp.height)
+      if (y_lane + 4 * r >= (int) fp.height)
         continue;
-      uint8_t *out = dst + dst_off + (size_t) y * fp.stride + (size_t) x_lane * 4;
-      if (x_lane + 4 <= (int) fp.width && ((reinterpret_cast<uintptr_t> (out) & 15) == 0)) {
-        *reinterpret_cast<uint4 *> (out) = make_uint4 (t[r][0], t[r][1], t[r][2], t[r][3]);
-      } else {
-        for (int k = 0; k < 4 && x_lane + k < (int) fp.width; k++)
-          reinterpret_cast<uint32_t *> (out)[k] = t[r][k];
-      }
+      const uint4 v = STRIP_LOAD (r);
+      const uint32_t e[4] = { v.x, v.y, v.z, v.w };
+      for (int k = 0; k < 4 && x_lane + k < (int) fp.width; k++)
+        reinterpret_cast<uint32_t *> (out + (size_t) (4 * r) * fp.stride)[k] = e[k];
     }
   }
+#undef STRIP_LOAD
+#undef STRIP_STORE
 }
 
 // ---------------------------------------------------------------------------
@@ -617,14 +672,31 @@ int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst
   fp.n_frames = n_frames;
   fp.region_first = region_first;
   fp.region_count = region_count;
-  const uint64_t total = (uint64_t) fp.st_x * fp.st_y * n_frames;
-  if (total > 0x7fffffffull)
+  if (n_frames > 8u * 65535u)
     return FLUTL_EINVAL;
-  fp.per_xcd = (uint32_t) ((total + 7) / 8);
+  const uint32_t per_frame = fp.st_x * fp.st_y;     // <= 512 * 2048
+  fp.magic_stx = fp.st_x > 1u
+      ? (uint32_t) ((0x100000000ull + fp.st_x - 1u) / fp.st_x) : 0u;
   fp.stride = stride;
-  const uint32_t grid = fp.per_xcd * 8u;   // one workgroup per supertile
-  hipLaunchKernelGGL (flutl_composite_kernel, dim3 (grid), dim3 (kThreads),
-      0, stream, fp, static_cast<uint8_t *> (dst), frames, regions, prims, atlas);
+  // one workgroup (= one wave) per supertile; grid.x is a multiple of 8 so
+  // that blockIdx.x & 7 is the XCD of the workgroup in every row of the grid
+  const uint32_t whole = n_frames / 8u, rest = n_frames % 8u;
+  if (whole) {          // XCD k renders frames [k * whole, (k + 1) * whole)
+    fp.frame_first = 0;
+    fp.xcd_frames = whole;
+    fp.xcd_sts = 0;
+    hipLaunchKernelGGL (flutl_composite_kernel, dim3 (per_frame * 8u, whole),
+        dim3 (kThreads), 0, stream, fp, static_cast<uint8_t *> (dst), frames, regions,
+        prims, atlas);
+  }
+  if (rest) {           // XCD k renders the k-th band of each remaining frame
+    fp.frame_first = whole * 8u;
+    fp.xcd_frames = 0;
+    fp.xcd_sts = (per_frame + 7u) / 8u;
+    hipLaunchKernelGGL (flutl_composite_kernel, dim3 (fp.xcd_sts * 8u, rest),
+        dim3 (kThreads), 0, stream, fp, static_cast<uint8_t *> (dst), frames, regions,
+        prims, atlas);
+  }
   return hipGetLastError () == hipSuccess ? FLUTL_OK : FLUTL_ENODEV;
 }
 

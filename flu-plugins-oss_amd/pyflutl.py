@@ -13,7 +13,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libflutl.so")
+# FLUTL_LIB: profiling builds of the same library (tools/ablate.sh); never a fallback
+LIB_PATH = os.environ.get("FLUTL_LIB") or os.path.join(HERE, "lib", "libflutl.so")
 
 # ---- IR mirrors (include/flutl.h) -----------------------------------------
 OP_RECT, OP_MASK, OP_IMAGE, OP_GROUP_BEGIN, OP_GROUP_END = 1, 2, 3, 4, 5
