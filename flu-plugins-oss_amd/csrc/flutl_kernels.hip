@@ -135,7 +135,7 @@ struct FrameParams {
   uint32_t n_frames;
   uint32_t region_first, region_count;  // used when frames == nullptr
   uint32_t frame_first;                 // first frame of this launch
-  uint32_t xcd_frames, xcd_sts;         // workgroup mapping, see the kernel
+  uint32_t xcd_frames, row_mul, row_add;   // workgroup mapping, see the kernel
   uint32_t magic_stx;                   // ceil(2^32 / st_x), 0 if st_x == 1
   uint64_t stride;                      // bytes
 };
@@ -355,18 +355,21 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
   //  * batches: XCD k renders whole frames (xcd_frames of them); frames of
   //    a batch are states of one stream with the same layout, so the 8
   //    workgroups of a round are the same supertile of 8 sibling frames;
-  //  * fewer than 8 frames: XCD k renders the k-th contiguous band of
-  //    supertiles of every frame (xcd_sts per band).
-  // Either way an XCD's L2 sees each glyph mask and list entry of its band /
-  // frame once.  Speed only; any placement is correct.  No run-time division:
-  // the launch code chooses the grid so that these are multiply-adds.
+  //  * fewer than 8 frames: XCD k renders the supertile rows k, k + 8, ... of
+  //    every frame, so a round is one column of 8 adjacent rows (a contiguous
+  //    band per XCD would leave 6 XCDs waiting on the 2 that hold the text of
+  //    a typical subtitle frame); a glyph mask is then fetched into the L2 of
+  //    each XCD whose rows it crosses.
+  // Speed only; any placement is correct.  No run-time division: the launch
+  // code chooses the grid so that these are multiply-adds.
   const uint32_t xcd = blockIdx.x & 7u;
-  const uint32_t st = xcd * fp.xcd_sts + (blockIdx.x >> 3);
-  if (st >= fp.st_x * fp.st_y)
+  const uint32_t i = blockIdx.x >> 3;
+  const uint32_t g = fp.magic_stx ? __umulhi (i, fp.magic_stx) : i;   // i / st_x
+  const uint32_t stx = i - g * fp.st_x;
+  const uint32_t sty = g * fp.row_mul + xcd * fp.row_add;
+  if (sty >= fp.st_y)
     return;
   const uint32_t frame = fp.frame_first + xcd * fp.xcd_frames + blockIdx.y;
-  const uint32_t sty = fp.magic_stx ? __umulhi (st, fp.magic_stx) : st;
-  const uint32_t stx = st - sty * fp.st_x;
 
   uint32_t rfirst = fp.region_first, rcount = fp.region_count;
   uint64_t dst_off = 0;
@@ -680,22 +683,28 @@ int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst
   fp.stride = stride;
   // one workgroup (= one wave) per supertile; grid.x is a multiple of 8 so
   // that blockIdx.x & 7 is the XCD of the workgroup in every row of the grid
+#if defined(FLUTL_MAP) && FLUTL_MAP == 3   // experiment: rows interleaved for every batch size
+  const uint32_t whole = 0, rest = n_frames;
+#else
   const uint32_t whole = n_frames / 8u, rest = n_frames % 8u;
+#endif
   if (whole) {          // XCD k renders frames [k * whole, (k + 1) * whole)
     fp.frame_first = 0;
     fp.xcd_frames = whole;
-    fp.xcd_sts = 0;
+    fp.row_mul = 1;
+    fp.row_add = 0;
     hipLaunchKernelGGL (flutl_composite_kernel, dim3 (per_frame * 8u, whole),
         dim3 (kThreads), 0, stream, fp, static_cast<uint8_t *> (dst), frames, regions,
         prims, atlas);
   }
-  if (rest) {           // XCD k renders the k-th band of each remaining frame
+  if (rest) {           // XCD k renders rows k, k + 8, ... of each remaining frame
     fp.frame_first = whole * 8u;
     fp.xcd_frames = 0;
-    fp.xcd_sts = (per_frame + 7u) / 8u;
-    hipLaunchKernelGGL (flutl_composite_kernel, dim3 (fp.xcd_sts * 8u, rest),
-        dim3 (kThreads), 0, stream, fp, static_cast<uint8_t *> (dst), frames, regions,
-        prims, atlas);
+    fp.row_mul = 8;
+    fp.row_add = 1;
+    hipLaunchKernelGGL (flutl_composite_kernel,
+        dim3 ((fp.st_y + 7u) / 8u * fp.st_x * 8u, rest), dim3 (kThreads), 0, stream, fp,
+        static_cast<uint8_t *> (dst), frames, regions, prims, atlas);
   }
   return hipGetLastError () == hipSuccess ? FLUTL_OK : FLUTL_ENODEV;
 }
