@@ -249,6 +249,8 @@ __device__ __forceinline__ void strip_blend (Px (&t)[4], Px s, uint32_t w)
 // slack), so nothing depends on the loaded value until the blend -- a select
 // on the value would make the compiler wait for each load where it is issued.
 // Bytes left/right of the mask read its zero padding (atlas contract).
+typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
+
 struct MaskFetch {
   uint32_t w[kRG];
 };
@@ -302,6 +304,43 @@ __device__ __forceinline__ uint32_t strip_range (int lo, int hi)
   return b > a ? ((1u << b) - 1u) & ~((1u << a) - 1u) : 0u;
 }
 
+// Parking of frame pixels in the destination frame during an opacity group
+// (see the kernel).  whole = the supertile is inside the frame and the rows
+// are 16-byte aligned (wave uniform); else nx / ny = pixels left to the frame
+// edge from this lane's first pixel: pixels outside the frame are never
+// stored, nor read back.  The read-back is by the lane that stored, at the
+// same address, later in program order: no fence is needed for that.
+__device__ __forceinline__ void park_store (uint8_t *o, uint4 v, bool whole, int nx, int ny)
+{
+  if (whole) {
+    *reinterpret_cast<uint4 *> (o) = v;
+    return;
+  }
+  if (ny <= 0)
+    return;
+  uint32_t *q = reinterpret_cast<uint32_t *> (o);
+  const uint32_t e[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (k < nx)
+      q[k] = e[k];
+}
+
+__device__ __forceinline__ uint4 park_load (const uint8_t *o, bool whole, int nx, int ny)
+{
+  if (whole)
+    return *reinterpret_cast<const uint4 *> (o);
+  const uint32_t *q = reinterpret_cast<const uint32_t *> (o);
+  uint32_t e[4] = { 0u, 0u, 0u, 0u };
+  if (ny > 0) {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (k < nx)
+        e[k] = q[k];
+  }
+  return make_uint4 (e[0], e[1], e[2], e[3]);
+}
+
 // blend one strip (4 packed pixels of the lane) with coverage dword w
 __device__ __forceinline__ void strip_apply (uint4 &v, const PrimU &p, uint32_t w)
 {
@@ -325,25 +364,33 @@ __device__ __forceinline__ void strip_apply (uint4 &v, const PrimU &p, uint32_t 
   v = make_uint4 (pack (t[0]), pack (t[1]), pack (t[2]), pack (t[3]));
 }
 
-#ifdef FLUTL_WAVES   // ablation: pin the occupancy
-__attribute__ ((amdgpu_waves_per_eu (FLUTL_WAVES, FLUTL_WAVES)))
+// 8 waves per SIMD: the kernel is bound by dependent loads and by instruction
+// issue of short scalar/vector sequences, both of which more waves hide
+// (measured 5 -> 8 waves: +12 %); 4 KB of LDS per wave allows exactly 8.
+#ifndef FLUTL_WAVES
+#define FLUTL_WAVES 8
 #endif
+__attribute__ ((amdgpu_waves_per_eu (FLUTL_WAVES, FLUTL_WAVES)))
 __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
     FrameParams fp, uint8_t *__restrict__ dst,
     const flutl_frame_desc *__restrict__ frames,
     const flutl_region *__restrict__ regions,
     const flutl_prim *__restrict__ prims, const uint8_t *__restrict__ atlas)
 {
-  // The supertile's pixels live in LDS, not in registers: s_surf[0] is the
-  // frame, s_surf[1] the group surface of the region being painted (between
-  // GROUP_BEGIN and GROUP_END).  Every lane only ever touches its own 16-byte
-  // slots, so there is no barrier and no bank conflict (ds_*_b128, lane-linear).
+  // The supertile's pixels live in LDS, not in registers.  Every lane only
+  // ever touches its own 16-byte slots, so there is no barrier and no bank
+  // conflict (ds_*_b128, lane-linear).
   // Why LDS: with the 16 pixels of a lane in VGPRs across four nested loops
   // and ~20 control-flow joins per primitive, the register allocator kept up
   // to three copies of them alive (118 VGPRs even with the blend arithmetic
   // removed, ~450 v_mov in the loop).  A blend is ~100 VALU per strip; the
   // LDS read + write it now costs is 16 LDS cycles per CU.
-  __shared__ uint4 s_surf[2][kRG][kThreads];
+  // ONE surface only (4 KB, 8 waves per SIMD): between GROUP_BEGIN and
+  // GROUP_END it holds the region's group surface, and the frame pixels
+  // painted so far -- none, unless regions overlap -- are parked in the
+  // lane's own pixels of the destination frame, which are written for good
+  // at the end anyway.
+  __shared__ uint4 s_surf[kRG][kThreads];
 
   // One wavefront per workgroup: nothing is shared between waves.
   const int lane = threadIdx.x;
@@ -385,13 +432,21 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
 
   // Wave-uniform bookkeeping (SGPRs): which strips of the current surface
   // hold pixels (bit r); an untouched strip is transparent and is neither
-  // initialised nor read.  cur = surface being painted (0 frame, 1 group).
-  uint32_t touched = 0, touched_frame = 0, cur = 0;
+  // initialised nor read.
+  uint32_t touched = 0, touched_frame = 0;
+  // the whole supertile is inside the frame and its rows are 16-byte aligned
+  const bool interior = sx0 + kSuperW <= (int) fp.width && sy0 + kSuperH <= (int) fp.height &&
+      ((reinterpret_cast<uintptr_t> (dst) | dst_off | fp.stride) & 15u) == 0;   // scalar
 
-#define STRIP_LOAD(r)  ((touched >> (r)) & 1u ? s_surf[cur][r][lane] : make_uint4 (0u, 0u, 0u, 0u))
-#define STRIP_STORE(r, v) do { s_surf[cur][r][lane] = (v); touched |= 1u << (r); } while (0)
+#define STRIP_LOAD(r)  ((touched >> (r)) & 1u ? s_surf[r][lane] : make_uint4 (0u, 0u, 0u, 0u))
+#define STRIP_STORE(r, v) do { s_surf[r][lane] = (v); touched |= 1u << (r); } while (0)
 
-#if FLUTL_EXP == 2     // ablation: store floor, no display list at all
+  // this lane's pixels of strip r in the destination frame (x, y0 = the lane's
+  // first pixel of strip 0; recomputed where needed, not kept in registers)
+#define STRIP_OUT(r, x, y0) \
+  (dst + dst_off + (size_t) ((y0) + 4 * (r)) * fp.stride + (size_t) (x) * 4)
+
+#if FLUTL_EXP == 2    // ablation: store floor, no display list at all
   rcount = 0;
 #endif
   // ---- regions, 64 at a time: one per lane, culled against the supertile ----
@@ -482,13 +537,13 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
                     STRIP_STORE (r, make_uint4 (p.color, p.color, p.color, p.color));
                   } else {
                     const Px sc = unpack (p.color);
-                    const uint4 d = s_surf[cur][r][lane];
+                    const uint4 d = s_surf[r][lane];
                     Px v0 = unpack (d.x), v1 = unpack (d.y), v2 = unpack (d.z), v3 = unpack (d.w);
                     over (v0, sc);
                     over (v1, sc);
                     over (v2, sc);
                     over (v3, sc);
-                    s_surf[cur][r][lane] = make_uint4 (pack (v0), pack (v1), pack (v2), pack (v3));
+                    s_surf[r][lane] = make_uint4 (pack (v0), pack (v1), pack (v2), pack (v3));
                   }
                   continue;
                 }
@@ -513,19 +568,24 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
               STRIP_STORE (r, v);
             }
           } else if (p.op == FLUTL_OP_GROUP_BEGIN) {
-            // the region's temporary surface starts transparent
+            // the region's temporary surface starts transparent; what the
+            // frame holds here so far (overlapping regions only) is parked
             touched_frame = touched;
+#pragma unroll
+            for (int r = 0; r < kRG; r++)
+              if ((touched >> r) & 1u)
+                park_store (STRIP_OUT (r, x, y0), s_surf[r][lane], interior,
+                    (int) fp.width - x, (int) fp.height - (y0 + 4 * r));
             touched = 0;
-            cur = 1;
           } else {
             // ---- per-pixel premultiplied source, OVER: IMAGE / GROUP_END ----
             const bool is_end = p.op == FLUTL_OP_GROUP_END;
             uint32_t touched_group = 0;
             if (is_end) {
-              // back to the frame; the group surface becomes the source
+              // back to the frame; the group surface becomes the source.  A
+              // strip the group did not touch still holds its frame pixels.
               touched_group = touched;
-              touched = touched_frame;
-              cur = 0;
+              touched = touched_frame & ~touched_group;
             }
             const u16x2 al = splat (p.param);
 #pragma unroll
@@ -538,12 +598,19 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
               const bool rowin = (uint32_t) (y - p.cy0) < (uint32_t) (p.cy1 - p.cy0);
               const uint32_t pmask = pixel_mask (p, x, rowin);
               uint32_t sv[4] = { 0u, 0u, 0u, 0u };
+              uint4 d;
               if (is_end) {
-                const uint4 g = s_surf[1][r][lane];
+                const uint4 g = s_surf[r][lane];
                 sv[0] = (pmask & 0x1u) ? g.x : 0u;
                 sv[1] = (pmask & 0x100u) ? g.y : 0u;
                 sv[2] = (pmask & 0x10000u) ? g.z : 0u;
                 sv[3] = (pmask & 0x1000000u) ? g.w : 0u;
+                d = make_uint4 (0u, 0u, 0u, 0u);
+                if ((touched_frame >> r) & 1u) {
+                  d = park_load (STRIP_OUT (r, x, y0), interior,
+                      (int) fp.width - x, (int) fp.height - y);
+                  STRIP_STORE (r, d);     // the frame strip is back
+                }
               } else {
                 const uint32_t rowoff = (uint32_t) p.a +
                     (uint32_t) (y - p.d) * (uint32_t) p.b + (uint32_t) (x - p.c) * 4u;
@@ -555,7 +622,8 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
               }
               if (__ballot ((sv[0] | sv[1] | sv[2] | sv[3]) != 0) == 0)
                 continue;   // 0 OVER d == d
-              const uint4 d = STRIP_LOAD (r);
+              if (!is_end)
+                d = STRIP_LOAD (r);
               uint32_t dv[4] = { d.x, d.y, d.z, d.w };
 #pragma unroll
               for (int k = 0; k < 4; k++) {
@@ -580,13 +648,17 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
 
   // ---- store: every pixel exactly once --------------------------------------
   // (validated lists have balanced groups, so the frame is current here)
-  uint8_t *out = dst + dst_off + (size_t) y_lane * fp.stride + (size_t) x_lane * 4;
-  const bool interior = sx0 + kSuperW <= (int) fp.width && sy0 + kSuperH <= (int) fp.height &&
-      ((reinterpret_cast<uintptr_t> (dst) | dst_off | fp.stride) & 15u) == 0;   // scalar
+  uint8_t *const out = STRIP_OUT (0, x_lane, y_lane);
   if (interior) {
 #pragma unroll
-    for (int r = 0; r < kRG; r++)
-      *reinterpret_cast<uint4 *> (out + (size_t) (4 * r) * fp.stride) = STRIP_LOAD (r);
+    for (int r = 0; r < kRG; r++) {
+      // streaming (nt) stores: the frame is written once and never read here,
+      // so it should not evict glyph masks and list entries from the L2
+      // (measured +6 % on the whole kernel; the store-only floor is unchanged)
+      const uint4 v = STRIP_LOAD (r);
+      const u32x4 nv = { v.x, v.y, v.z, v.w };
+      __builtin_nontemporal_store (nv, reinterpret_cast<u32x4 *> (out + (size_t) (4 * r) * fp.stride));
+    }
   } else if (x_lane < (int) fp.width) {
     // frame edge or unaligned destination: per-pixel bounds
 #pragma unroll
@@ -599,6 +671,7 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
         reinterpret_cast<uint32_t *> (out + (size_t) (4 * r) * fp.stride)[k] = e[k];
     }
   }
+#undef STRIP_OUT
 #undef STRIP_LOAD
 #undef STRIP_STORE
 }
