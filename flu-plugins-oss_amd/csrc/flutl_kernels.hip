@@ -145,7 +145,10 @@ struct FrameParams {
 // groups r, the 4 pixels at column 4*(l%16), row 4*r + l/16 -- so one store
 // instruction of a wave writes four 256-byte row segments.
 constexpr int kSuperW = FLUTL_TILE_W;        // 64
-constexpr int kRG = 4;                       // row groups per wave
+#ifndef FLUTL_KRG
+#define FLUTL_KRG 4
+#endif
+constexpr int kRG = FLUTL_KRG;               // row groups per wave
 constexpr int kSuperH = 4 * kRG;             // kRG strips of 4 rows
 
 // A primitive held wave-uniformly in SGPRs.  During binning every lane holds
@@ -161,6 +164,45 @@ struct PrimU {
 __device__ __forceinline__ uint32_t rdl (uint32_t v, int l)
 {
   return (uint32_t) __builtin_amdgcn_readlane ((int) v, l);
+}
+
+// The 8 raw dwords of lane l's primitive; decoded (cheap scalar ops) only
+// where it is used, so that the prefetched NEXT primitive costs 8 SGPRs, not 12.
+struct PrimRaw {
+  uint32_t w[8];
+};
+
+__device__ __forceinline__ PrimRaw prim_raw_from_lane (const uint4 &lo, const uint4 &hi, int l)
+{
+  PrimRaw q;
+  q.w[0] = rdl (lo.x, l);
+  q.w[1] = rdl (lo.y, l);
+  q.w[2] = rdl (lo.z, l);
+  q.w[3] = rdl (lo.w, l);
+  q.w[4] = rdl (hi.x, l);
+  q.w[5] = rdl (hi.y, l);
+  q.w[6] = rdl (hi.z, l);
+  q.w[7] = rdl (hi.w, l);
+  return q;
+}
+
+__device__ __forceinline__ PrimU prim_decode (const PrimRaw &q)
+{
+  const uint32_t w0 = q.w[0], w1 = q.w[1], w2 = q.w[2];
+  PrimU p;
+  p.op = w0 & 0xffu;
+  p.rule = (w0 >> 8) & 0xffu;
+  p.param = w0 >> 16;
+  p.cx0 = (int16_t) (w1 & 0xffffu);
+  p.cy0 = (int16_t) (w1 >> 16);
+  p.cx1 = (int16_t) (w2 & 0xffffu);
+  p.cy1 = (int16_t) (w2 >> 16);
+  p.color = q.w[3];
+  p.a = (int) q.w[4];
+  p.b = (int) q.w[5];
+  p.c = (int) q.w[6];
+  p.d = (int) q.w[7];
+  return p;
 }
 
 __device__ __forceinline__ PrimU prim_from_lane (const uint4 &lo, const uint4 &hi, int l)
@@ -271,8 +313,11 @@ __device__ __forceinline__ MaskFetch mask_fetch4 (const PrimU &p,
   const uint32_t step = 4u * (uint32_t) p.b;
 #pragma unroll
   for (int r = 0; r < kRG; r++) {
-    const bool valid = colin && (uint32_t) (y0 + 4 * r - p.cy0) < rows;
-    const uint32_t off = valid ? off0 + (uint32_t) r * step : 0u;
+    const bool valid = colin & ((uint32_t) (y0 + 4 * r - p.cy0) < rows);
+    uint32_t off = valid ? off0 + (uint32_t) r * step : 0u;
+    // keep the select on the 32-bit offset (not on a 64-bit pointer): the load
+    // then takes the atlas base from SGPRs and this VGPR as its offset
+    asm volatile ("" : "+v"(off));
 #if FLUTL_EXP == 3   // ablation: no mask loads
     f.w[r] = off;
 #else
@@ -488,21 +533,21 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
 
         // replay the hits in paint order (= lane order); the next hit's mask
         // bytes are requested before the current one is blended
-        PrimU nxt = prim_from_lane (lo, hi, __builtin_ctzll (hits));
+        PrimRaw nxt = prim_raw_from_lane (lo, hi, __builtin_ctzll (hits));
         hits &= hits - 1;
-        MaskFetch fnxt = mask_fetch4 (nxt, atlas, x_lane, y_lane);
+        MaskFetch fnxt = mask_fetch4 (prim_decode (nxt), atlas, x_lane, y_lane);
         for (;;) {
           // Re-materialise the lane coordinates per primitive: left visible,
           // LICM hoists dozens of x+k / y+4r derived VGPRs out of the loops.
           int x = x_lane, y0 = y_lane;
           asm volatile ("" : "+v"(x), "+v"(y0));
-          const PrimU p = nxt;
+          const PrimU p = prim_decode (nxt);
           const MaskFetch f = fnxt;
           const bool more = hits != 0;
           if (more) {
-            nxt = prim_from_lane (lo, hi, __builtin_ctzll (hits));
+            nxt = prim_raw_from_lane (lo, hi, __builtin_ctzll (hits));
             hits &= hits - 1;
-            fnxt = mask_fetch4 (nxt, atlas, x, y0);
+            fnxt = mask_fetch4 (prim_decode (nxt), atlas, x, y0);
           }
 #if FLUTL_EXP == 6    // ablation: replay loop without the op bodies
           touched ^= p.color ^ rdl (f.w[0] ^ f.w[1] ^ f.w[2] ^ f.w[3], 0);
