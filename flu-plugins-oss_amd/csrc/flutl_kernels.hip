@@ -285,11 +285,11 @@ __device__ __forceinline__ void strip_blend (Px (&t)[4], Px s, uint32_t w)
 
 // The A8 coverage bytes of a MASK primitive for this lane's 4 pixels in each
 // of its kRG strips (rows y0 + 4r).  Issued one primitive ahead of use: OVER
-// is order dependent, the loads are not.  Branch free AND select free: lanes
-// that the prim does not touch (and every lane, for other ops) load the first
-// dword of the atlas, which is zero by contract (include/flutl.h: leading
-// slack), so nothing depends on the loaded value until the blend -- a select
-// on the value would make the compiler wait for each load where it is issued.
+// is order dependent, the loads are not.  Select free: lanes that the prim
+// does not touch load the first dword of the atlas, which is zero by contract
+// (include/flutl.h: leading slack), so nothing depends on the loaded value
+// until the blend -- a select on the value would make the compiler wait for
+// each load where it is issued.  Other ops load nothing.
 // Bytes left/right of the mask read its zero padding (atlas contract).
 typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
 
@@ -302,8 +302,12 @@ __device__ __forceinline__ MaskFetch mask_fetch4 (const PrimU &p,
     const uint8_t *__restrict__ atlas, int x, int y0)
 {
   MaskFetch f;
-  // wave uniform: no rows for other ops
-  const uint32_t rows = p.op == FLUTL_OP_MASK ? (uint32_t) (p.cy1 - p.cy0) : 0u;
+#pragma unroll
+  for (int r = 0; r < kRG; r++)
+    f.w[r] = 0u;
+  if (p.op != FLUTL_OP_MASK)    // wave uniform
+    return f;
+  const uint32_t rows = (uint32_t) (p.cy1 - p.cy0);
   const bool colin = (uint32_t) (x + 3 - p.cx0) < (uint32_t) (p.cx1 - p.cx0 + 3);
   // |rows| and strides are < 2^15: 24-bit multiply (full rate).  SIGNED: strip
   // 0 may lie above the mask (y0 < p.d) while a later strip of the same lane
@@ -409,13 +413,13 @@ __device__ __forceinline__ void strip_apply (uint4 &v, const PrimU &p, uint32_t 
   v = make_uint4 (pack (t[0]), pack (t[1]), pack (t[2]), pack (t[3]));
 }
 
-// 8 waves per SIMD: the kernel is bound by dependent loads and by instruction
-// issue of short scalar/vector sequences, both of which more waves hide
-// (measured 5 -> 8 waves: +12 %); 4 KB of LDS per wave allows exactly 8.
+// At least 6 waves per SIMD (4 KB of LDS per wave allows 8): measured 5 -> 6
+// waves +4 %, 6 = 7 = 8 -- and at 8 the 96-SGPR budget makes the compiler
+// spill scalars into VGPR lanes, +60 VALU per wave on a VALU-bound kernel.
 #ifndef FLUTL_WAVES
-#define FLUTL_WAVES 8
+#define FLUTL_WAVES 6
 #endif
-__attribute__ ((amdgpu_waves_per_eu (FLUTL_WAVES, FLUTL_WAVES)))
+__attribute__ ((amdgpu_waves_per_eu (FLUTL_WAVES)))
 __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
     FrameParams fp, uint8_t *__restrict__ dst,
     const flutl_frame_desc *__restrict__ frames,
