@@ -62,7 +62,8 @@ __device__ __forceinline__ Px unpack (uint32_t p)
 {
   Px r;
   r.rb = as_u16x2 (p & 0x00ff00ffu);
-  r.ag = as_u16x2 ((p >> 8) & 0x00ff00ffu);
+  // {0, A, 0, G} in one v_perm_b32 instead of shift + and
+  r.ag = as_u16x2 (__builtin_amdgcn_perm (0u, p, 0x0c030c01u));
   return r;
 }
 __device__ __forceinline__ uint32_t pack (Px p)
@@ -254,17 +255,20 @@ __device__ __forceinline__ void px_pixman (Px &t, Px s, uint32_t w)
 }
 
 // cairo in-place lerp (0x7f rounding); mul_7f (255, m) == m, so the sum never
-// exceeds 255 either.  RB_ZERO: the colour has no red/blue (black outlines).
-template <bool RB_ZERO, int K>
+// exceeds 255 either.  BLACK: the colour is opaque black (the usual outline),
+// s * m is then {0, 0, 0, m} without a multiplication.
+template <bool BLACK, int K>
 __device__ __forceinline__ void px_lerp (Px &t, Px s, uint32_t w)
 {
   const u16x2 mm = splat_byte<K> (w);
   const u16x2 im = as_u16x2 (as_u32 (mm) ^ 0x00ff00ffu);
-  if (RB_ZERO)
+  if (BLACK) {
     t.rb = mul_7f (t.rb, im);
-  else
+    t.ag = as_u16x2 (as_u32 (mm) & 0xffff0000u) + mul_7f (t.ag, im);
+  } else {
     t.rb = mul_7f (s.rb, mm) + mul_7f (t.rb, im);
-  t.ag = mul_7f (s.ag, mm) + mul_7f (t.ag, im);
+    t.ag = mul_7f (s.ag, mm) + mul_7f (t.ag, im);
+  }
 }
 
 template <bool LERP, bool FLAG>
@@ -400,7 +404,7 @@ __device__ __forceinline__ void strip_apply (uint4 &v, const PrimU &p, uint32_t 
   Px t[4] = { unpack (v.x), unpack (v.y), unpack (v.z), unpack (v.w) };
   const Px s = unpack (p.color);
   if (p.rule == FLUTL_RULE_LERP) {
-    if ((p.color & 0x00ff00ffu) == 0u)
+    if (p.color == 0xff000000u)
       strip_blend<true, true> (t, s, w);
     else
       strip_blend<true, false> (t, s, w);
