@@ -351,9 +351,18 @@ __device__ __forceinline__ uint32_t pixel_mask (const PrimU &p, int x, bool rowi
 // floor (lo / 4) <= r < floor (hi / 4), rows relative to the supertile.
 // (Touch test: lo = first row, hi = last row + 4.  Cover test: lo = first
 // row + 3, hi = one past the last row.)  Wave uniform, scalar unit.
+__device__ __forceinline__ int clamp_scalar (int v, int hi)
+{
+  // two scalar ops; written as min (max ()) it becomes v_med3_i32 +
+  // v_readfirstlane, i.e. vector-unit work for a wave-uniform value
+  int a = max (v, 0);
+  asm volatile ("" : "+s"(a));
+  return min (a, hi);
+}
+
 __device__ __forceinline__ uint32_t strip_range (int lo, int hi)
 {
-  const int a = min (max (lo >> 2, 0), kRG), b = min (max (hi >> 2, 0), kRG);
+  const int a = clamp_scalar (lo >> 2, kRG), b = clamp_scalar (hi >> 2, kRG);
   return b > a ? ((1u << b) - 1u) & ~((1u << a) - 1u) : 0u;
 }
 
@@ -567,57 +576,68 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
           if (p.op == FLUTL_OP_MASK || p.op == FLUTL_OP_RECT) {
             // ---- solid colour through 8-bit coverage: an A8 mask, or the
             //      24.8 box of cairo's rectangular scan converter -------------
-            const bool is_rect = p.op == FLUTL_OP_RECT;
             // strips the clipped bbox touches, and (RECT) strips the box covers
             // completely: bit masks made once per primitive with scalar ops
             const uint32_t smask = strip_range (p.cy0 - sy0, p.cy1 - sy0 + 3);
             uint32_t fmask = 0u;
-            if (is_rect && ((p.a + 255) >> 8) <= sx0 && (p.c >> 8) >= sx0 + kSuperW &&
-                p.cx0 <= sx0 && p.cx1 >= sx0 + kSuperW)
-              fmask = strip_range (max ((p.b + 255) >> 8, p.cy0) - sy0 + 3,
-                  min (p.d >> 8, p.cy1) - sy0);
+            uint32_t w[kRG];
+            if (p.op == FLUTL_OP_RECT) {
+              if (((p.a + 255) >> 8) <= sx0 && (p.c >> 8) >= sx0 + kSuperW &&
+                  p.cx0 <= sx0 && p.cx1 >= sx0 + kSuperW)
+                fmask = strip_range (max ((p.b + 255) >> 8, p.cy0) - sy0 + 3,
+                    min (p.d >> 8, p.cy1) - sy0);
+#pragma unroll
+              for (int r = 0; r < kRG; r++) {
+                w[r] = 0u;
+                if ((((smask & ~fmask) >> r) & 1u) == 0u)
+                  continue;
+                // cairo rectangular scan converter coverage (box edges only)
+                const int y = y0 + 4 * r;
+                const bool rowin = (uint32_t) (y - p.cy0) < (uint32_t) (p.cy1 - p.cy0);
+                const int oy = overlap256 (p.b, p.d, y);
+                uint32_t c = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                  c |= min ((uint32_t) (overlap256 (p.a, p.c, x + k) * oy) >> 8, 255u) << (8 * k);
+                w[r] = c & pixel_mask (p, x, rowin);
+              }
+            } else {
+#pragma unroll
+              for (int r = 0; r < kRG; r++)
+                w[r] = f.w[r];
+              if (p.param & FLUTL_MASK_XCLIP) {
+                const uint32_t pm = pixel_mask (p, x, true);
+#pragma unroll
+                for (int r = 0; r < kRG; r++)
+                  w[r] &= pm;
+              }
+            }
 #pragma unroll
             for (int r = 0; r < kRG; r++) {
               if (((smask >> r) & 1u) == 0u)
                 continue;
-              uint32_t w;
-              if (is_rect) {
-                if ((fmask >> r) & 1u) {
-                  // coverage 255 on the whole strip: t = s OVER t with a uniform
-                  // s.  Opaque s, LERP, or nothing painted yet: t = s exactly.
-                  if ((p.color >> 24) == 255u || p.rule == FLUTL_RULE_LERP ||
-                      ((touched >> r) & 1u) == 0u) {
-                    STRIP_STORE (r, make_uint4 (p.color, p.color, p.color, p.color));
-                  } else {
-                    const Px sc = unpack (p.color);
-                    const uint4 d = s_surf[r][lane];
-                    Px v0 = unpack (d.x), v1 = unpack (d.y), v2 = unpack (d.z), v3 = unpack (d.w);
-                    over (v0, sc);
-                    over (v1, sc);
-                    over (v2, sc);
-                    over (v3, sc);
-                    s_surf[r][lane] = make_uint4 (pack (v0), pack (v1), pack (v2), pack (v3));
-                  }
-                  continue;
+              if ((fmask >> r) & 1u) {
+                // coverage 255 on the whole strip: t = s OVER t with a uniform
+                // s.  Opaque s, LERP, or nothing painted yet: t = s exactly.
+                if ((p.color >> 24) == 255u || p.rule == FLUTL_RULE_LERP ||
+                    ((touched >> r) & 1u) == 0u) {
+                  STRIP_STORE (r, make_uint4 (p.color, p.color, p.color, p.color));
+                } else {
+                  const Px sc = unpack (p.color);
+                  const uint4 d = s_surf[r][lane];
+                  Px v0 = unpack (d.x), v1 = unpack (d.y), v2 = unpack (d.z), v3 = unpack (d.w);
+                  over (v0, sc);
+                  over (v1, sc);
+                  over (v2, sc);
+                  over (v3, sc);
+                  s_surf[r][lane] = make_uint4 (pack (v0), pack (v1), pack (v2), pack (v3));
                 }
-                // cairo rectangular scan converter coverage
-                const int y = y0 + 4 * r;
-                const bool rowin = (uint32_t) (y - p.cy0) < (uint32_t) (p.cy1 - p.cy0);
-                const int oy = overlap256 (p.b, p.d, y);
-                w = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                  w |= min ((uint32_t) (overlap256 (p.a, p.c, x + k) * oy) >> 8, 255u) << (8 * k);
-                w &= pixel_mask (p, x, rowin);
-              } else {
-                w = f.w[r];
-                if (p.param & FLUTL_MASK_XCLIP)
-                  w &= pixel_mask (p, x, true);
+                continue;
               }
-              if (__ballot (w != 0) == 0)
+              if (__ballot (w[r] != 0) == 0)
                 continue;                            // nothing lands in this strip
               uint4 v = STRIP_LOAD (r);
-              strip_apply (v, p, w);
+              strip_apply (v, p, w[r]);
               STRIP_STORE (r, v);
             }
           } else if (p.op == FLUTL_OP_GROUP_BEGIN) {
@@ -675,6 +695,20 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
               }
               if (__ballot ((sv[0] | sv[1] | sv[2] | sv[3]) != 0) == 0)
                 continue;   // 0 OVER d == d
+              if (is_end && ((touched_frame >> r) & 1u) == 0u) {
+                // nothing under the group here (regions that do not overlap,
+                // the usual case): x OVER 0 == x, only the IN remains
+                uint32_t o[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                  Px sp = unpack (sv[k]);
+                  sp.rb = mul_un8 (sp.rb, al);
+                  sp.ag = mul_un8 (sp.ag, al);
+                  o[k] = pack (sp);
+                }
+                STRIP_STORE (r, make_uint4 (o[0], o[1], o[2], o[3]));
+                continue;
+              }
               if (!is_end)
                 d = STRIP_LOAD (r);
               uint32_t dv[4] = { d.x, d.y, d.z, d.w };
