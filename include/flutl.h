@@ -58,7 +58,10 @@ extern "C" {
                                  * Atlas contract: every mask row is followed by
                                  * >= 3 zero bytes and the first row preceded by
                                  * >= 3 zero bytes, so that the kernel's 4-byte
-                                 * windows read 0 left and right of the mask; if
+                                 * windows read 0 left and right of the mask, and
+                                 * the FIRST 16 BYTES OF THE ATLAS ARE ZERO (lanes
+                                 * outside a mask read them instead); stride
+                                 * < 2^23; if
                                  * [cx0,cx1) is narrower than the mask rows (the
                                  * clip cut it) set FLUTL_MASK_XCLIP in param and
                                  * the kernel masks the columns itself.           */
@@ -99,7 +102,8 @@ typedef struct flutl_region {
   uint32_t count;          /* number of prims                                 */
 } flutl_region; /* 16 bytes */
 
-/* Output tile of the compositor kernel: one workgroup per tile. */
+/* Output tile of the compositor kernel (the north star's 64x8): one wave
+ * composites two of them stacked, a 64x16 "supertile", strip (64x4) by strip. */
 #define FLUTL_TILE_W 64
 #define FLUTL_TILE_H 8
 
