@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--ring", type=int, default=0, help="output frames in the ring")
     ap.add_argument("--gather", action="store_true",
                     help="RCCL gather of every finished frame to rank 0")
+    ap.add_argument("--over-video", action="store_true",
+                    help="fused mode: composite each overlay OVER a resident video frame "
+                         "(flutl_launch_batch_over); adds 4*W*H read bytes per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -146,10 +149,15 @@ def main():
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).cuda()
     R_dev, P_dev, A_dev = dev(R_all), dev(P_all), dev(atlas)
     out = torch.empty(ring * frame_bytes, dtype=torch.uint8, device="cuda")
+    video = None
+    if args.over_video:      # opaque synthetic video, one frame per ring slot
+        video = torch.randint(0, 256, (ring * frame_bytes,), dtype=torch.uint8, device="cuda")
+        video[3::4] = 255
     # batch descriptors: step s renders states [s*B, s*B+B) mod n_states into
     # ring slots [s*B, ...) mod ring
-    n_desc_steps = (n_states * ring) // np.gcd(n_states, ring) // B if B > 1 else 0
-    if B > 1:
+    n_desc_steps = ((n_states * ring) // np.gcd(n_states, ring) // B
+                    if (B > 1 or args.over_video) else 0)
+    if B > 1 or args.over_video:
         n_desc_steps = min(max(n_desc_steps, 1), 4096)
         descs = np.zeros(n_desc_steps * B, F.FRAME_DTYPE)
         for s in range(n_desc_steps):
@@ -160,7 +168,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def step(s):
-        if B == 1:
+        if B == 1 and video is None:
             st = streams.state_schedule(n_states, rank, s, 1, world)[0]
             slot = s % ring
             F.launch_frame(stream, W, H, out.data_ptr() + slot * frame_bytes,
@@ -170,8 +178,12 @@ def main():
                 streams.gather_frames(out[slot * frame_bytes:(slot + 1) * frame_bytes])
         else:
             ds = s % n_desc_steps
-            F.launch_batch(stream, W, H, out, D_dev.data_ptr() + ds * B * 16, B,
-                           R_dev, P_dev, A_dev)
+            if video is not None:
+                F.launch_batch_over(stream, W, H, out, video,
+                                    D_dev.data_ptr() + ds * B * 16, B, R_dev, P_dev, A_dev)
+            else:
+                F.launch_batch(stream, W, H, out, D_dev.data_ptr() + ds * B * 16, B,
+                               R_dev, P_dev, A_dev)
             if args.gather and world > 1:
                 for j in range(B):
                     slot = (ds * B + j) % ring
@@ -214,7 +226,7 @@ def main():
     if rank == 0:
         frames = args.steps * B * world
         fps = frames / elapsed
-        mean_alg = float(np.mean(alg_bytes))
+        mean_alg = float(np.mean(alg_bytes)) + (frame_bytes if args.over_video else 0)
         achieved = mean_alg * B / (kern_ms * 1e-3) / 1e9
         res = {
             "metric": "4K overlay frames/s" if H == 2160 else "overlay frames/s",
@@ -234,6 +246,7 @@ def main():
                        "frames_per_step": B, "distinct_states": n_states,
                        "scene_source": source, "output_ring_frames": ring,
                        "streams": world, "gather_to_rank0": bool(args.gather),
+                       "fused_over_video": bool(args.over_video),
                        "parallelism": f"{world} independent stream(s), one per GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -243,7 +256,8 @@ def main():
                          "kernel_ms": round(kern_ms, 5),
                          "algorithmic_bytes_per_launch": int(mean_alg * B)},
         }
-        res["roofline"]["traffic"] = profiled_traffic(args.config, B)
+        if not args.over_video:
+            res["roofline"]["traffic"] = profiled_traffic(args.config, B)
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import cpu_baseline

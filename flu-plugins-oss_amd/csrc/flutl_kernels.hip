@@ -432,9 +432,14 @@ __device__ __forceinline__ void strip_apply (uint4 &v, const PrimU &p, uint32_t 
 #ifndef FLUTL_WAVES
 #define FLUTL_WAVES 6
 #endif
+// VIDEO: the finished overlay pixel is composited OVER the pixel of a video
+// frame (same geometry as dst) in the store epilogue -- the "blend over the
+// video buffer" of the north star, fused so that the overlay never exists in
+// memory.  Separate instantiation: the plain overlay path pays nothing.
+template <bool VIDEO>
 __attribute__ ((amdgpu_waves_per_eu (FLUTL_WAVES)))
 __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
-    FrameParams fp, uint8_t *__restrict__ dst,
+    FrameParams fp, uint8_t *__restrict__ dst, const uint8_t *__restrict__ video,
     const flutl_frame_desc *__restrict__ frames,
     const flutl_region *__restrict__ regions,
     const flutl_prim *__restrict__ prims, const uint8_t *__restrict__ atlas)
@@ -498,7 +503,8 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
   uint32_t touched = 0, touched_frame = 0;
   // the whole supertile is inside the frame and its rows are 16-byte aligned
   const bool interior = sx0 + kSuperW <= (int) fp.width && sy0 + kSuperH <= (int) fp.height &&
-      ((reinterpret_cast<uintptr_t> (dst) | dst_off | fp.stride) & 15u) == 0;   // scalar
+      ((reinterpret_cast<uintptr_t> (dst) | (VIDEO ? reinterpret_cast<uintptr_t> (video) : 0) |
+          dst_off | fp.stride) & 15u) == 0;   // scalar
 
 #define STRIP_LOAD(r)  ((touched >> (r)) & 1u ? s_surf[r][lane] : make_uint4 (0u, 0u, 0u, 0u))
 #define STRIP_STORE(r, v) do { s_surf[r][lane] = (v); touched |= 1u << (r); } while (0)
@@ -736,13 +742,29 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
   // ---- store: every pixel exactly once --------------------------------------
   // (validated lists have balanced groups, so the frame is current here)
   uint8_t *const out = STRIP_OUT (0, x_lane, y_lane);
+  const uint8_t *const vin = VIDEO
+      ? video + dst_off + (size_t) y_lane * fp.stride + (size_t) x_lane * 4 : nullptr;
   if (interior) {
 #pragma unroll
     for (int r = 0; r < kRG; r++) {
       // streaming (nt) stores: the frame is written once and never read here,
       // so it should not evict glyph masks and list entries from the L2
       // (measured +6 % on the whole kernel; the store-only floor is unchanged)
-      const uint4 v = STRIP_LOAD (r);
+      uint4 v = STRIP_LOAD (r);
+      if (VIDEO) {
+        const u32x4 q = __builtin_nontemporal_load (
+            reinterpret_cast<const u32x4 *> (vin + (size_t) (4 * r) * fp.stride));
+        if ((touched >> r) & 1u) {
+          Px d0 = unpack (q.x), d1 = unpack (q.y), d2 = unpack (q.z), d3 = unpack (q.w);
+          over (d0, unpack (v.x));
+          over (d1, unpack (v.y));
+          over (d2, unpack (v.z));
+          over (d3, unpack (v.w));
+          v = make_uint4 (pack (d0), pack (d1), pack (d2), pack (d3));
+        } else {
+          v = make_uint4 (q.x, q.y, q.z, q.w);      // nothing painted: the video pixel
+        }
+      }
       const u32x4 nv = { v.x, v.y, v.z, v.w };
       __builtin_nontemporal_store (nv, reinterpret_cast<u32x4 *> (out + (size_t) (4 * r) * fp.stride));
     }
@@ -754,8 +776,15 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
         continue;
       const uint4 v = STRIP_LOAD (r);
       const uint32_t e[4] = { v.x, v.y, v.z, v.w };
-      for (int k = 0; k < 4 && x_lane + k < (int) fp.width; k++)
-        reinterpret_cast<uint32_t *> (out + (size_t) (4 * r) * fp.stride)[k] = e[k];
+      for (int k = 0; k < 4 && x_lane + k < (int) fp.width; k++) {
+        uint32_t o = e[k];
+        if (VIDEO) {
+          Px d = unpack (reinterpret_cast<const uint32_t *> (vin + (size_t) (4 * r) * fp.stride)[k]);
+          over (d, unpack (o));
+          o = pack (d);
+        }
+        reinterpret_cast<uint32_t *> (out + (size_t) (4 * r) * fp.stride)[k] = o;
+      }
     }
   }
 #undef STRIP_OUT
@@ -820,7 +849,7 @@ __global__ __launch_bounds__ (256) void flutl_blur_kernel_dev (
 }
 
 int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst,
-    size_t stride, const flutl_frame_desc *frames, uint32_t n_frames,
+    const void *video, size_t stride, const flutl_frame_desc *frames, uint32_t n_frames,
     uint32_t region_first, uint32_t region_count, const flutl_region *regions,
     const flutl_prim *prims, const uint8_t *atlas)
 {
@@ -841,6 +870,16 @@ int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst
   fp.magic_stx = fp.st_x > 1u
       ? (uint32_t) ((0x100000000ull + fp.st_x - 1u) / fp.st_x) : 0u;
   fp.stride = stride;
+#define LAUNCH(grid) do { \
+    if (video) \
+      hipLaunchKernelGGL (flutl_composite_kernel<true>, grid, dim3 (kThreads), 0, stream, fp, \
+          static_cast<uint8_t *> (dst), static_cast<const uint8_t *> (video), frames, \
+          regions, prims, atlas); \
+    else \
+      hipLaunchKernelGGL (flutl_composite_kernel<false>, grid, dim3 (kThreads), 0, stream, fp, \
+          static_cast<uint8_t *> (dst), static_cast<const uint8_t *> (nullptr), frames, \
+          regions, prims, atlas); \
+  } while (0)
   // one workgroup (= one wave) per supertile; grid.x is a multiple of 8 so
   // that blockIdx.x & 7 is the XCD of the workgroup in every row of the grid
 #if defined(FLUTL_MAP) && FLUTL_MAP == 3   // experiment: rows interleaved for every batch size
@@ -853,19 +892,16 @@ int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst
     fp.xcd_frames = whole;
     fp.row_mul = 1;
     fp.row_add = 0;
-    hipLaunchKernelGGL (flutl_composite_kernel, dim3 (per_frame * 8u, whole),
-        dim3 (kThreads), 0, stream, fp, static_cast<uint8_t *> (dst), frames, regions,
-        prims, atlas);
+    LAUNCH (dim3 (per_frame * 8u, whole));
   }
   if (rest) {           // XCD k renders rows k, k + 8, ... of each remaining frame
     fp.frame_first = whole * 8u;
     fp.xcd_frames = 0;
     fp.row_mul = 8;
     fp.row_add = 1;
-    hipLaunchKernelGGL (flutl_composite_kernel,
-        dim3 ((fp.st_y + 7u) / 8u * fp.st_x * 8u, rest), dim3 (kThreads), 0, stream, fp,
-        static_cast<uint8_t *> (dst), frames, regions, prims, atlas);
+    LAUNCH (dim3 ((fp.st_y + 7u) / 8u * fp.st_x * 8u, rest));
   }
+#undef LAUNCH
   return hipGetLastError () == hipSuccess ? FLUTL_OK : FLUTL_ENODEV;
 }
 
@@ -875,7 +911,7 @@ extern "C" int flutl_launch_frame (void *stream, uint32_t width, uint32_t height
     void *dst, size_t dst_stride_bytes, const flutl_region *regions,
     uint32_t n_regions, const flutl_prim *prims, const uint8_t *atlas)
 {
-  return launch_tiles (static_cast<hipStream_t> (stream), width, height, dst,
+  return launch_tiles (static_cast<hipStream_t> (stream), width, height, dst, nullptr,
       dst_stride_bytes, nullptr, 1, 0, n_regions, regions, prims, atlas);
 }
 
@@ -886,8 +922,19 @@ extern "C" int flutl_launch_batch (void *stream, uint32_t width, uint32_t height
 {
   if (!frames)
     return FLUTL_EINVAL;
-  return launch_tiles (static_cast<hipStream_t> (stream), width, height, dst,
+  return launch_tiles (static_cast<hipStream_t> (stream), width, height, dst, nullptr,
       dst_stride_bytes, frames, n_frames, 0, 0, regions, prims, atlas);
+}
+
+extern "C" int flutl_launch_batch_over (void *stream, uint32_t width, uint32_t height,
+    void *dst, const void *video, size_t stride_bytes, const flutl_frame_desc *frames,
+    uint32_t n_frames, const flutl_region *regions, const flutl_prim *prims,
+    const uint8_t *atlas)
+{
+  if (!frames || !video || video == dst)
+    return FLUTL_EINVAL;
+  return launch_tiles (static_cast<hipStream_t> (stream), width, height, dst, video,
+      stride_bytes, frames, n_frames, 0, 0, regions, prims, atlas);
 }
 
 extern "C" int flutl_launch_blur (void *stream, const void *src, void *dst,

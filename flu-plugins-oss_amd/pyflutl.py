@@ -41,6 +41,7 @@ assert FRAME_DTYPE.itemsize == 16
 EXPORTS = [
     "flutl_abi_version", "flutl_device_count", "flutl_strerror",
     "flutl_list_validate", "flutl_launch_frame", "flutl_launch_batch",
+    "flutl_launch_batch_over",
     "flutl_launch_blur", "flutl_blur_kernel",
     "flutl_ctx_create", "flutl_ctx_destroy", "flutl_ctx_sync",
     "flutl_atlas_put", "flutl_atlas_reset", "flutl_atlas_size",
@@ -75,6 +76,7 @@ def lib():
         L.flutl_list_validate.argtypes = [u32, u32, vp, u32, vp, u32, sz]
         L.flutl_launch_frame.argtypes = [vp, u32, u32, vp, sz, vp, u32, vp, vp]
         L.flutl_launch_batch.argtypes = [vp, u32, u32, vp, sz, vp, u32, vp, vp, vp]
+        L.flutl_launch_batch_over.argtypes = [vp, u32, u32, vp, vp, sz, vp, u32, vp, vp, vp]
         L.flutl_launch_blur.argtypes = [vp, vp, vp, u32, u32, sz, vp, ctypes.c_int]
         L.flutl_blur_kernel.argtypes = [ctypes.c_int, ctypes.c_double, vp]
         L.flutl_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
@@ -152,6 +154,17 @@ def launch_batch(stream, width, height, dst, frames_dev, n_frames, regions_dev,
                                     stride or width * 4, p(frames_dev), n_frames,
                                     p(regions_dev), p(prims_dev), p(atlas_dev)),
            "flutl_launch_batch")
+
+
+def launch_batch_over(stream, width, height, dst, video, frames_dev, n_frames,
+                      regions_dev, prims_dev, atlas_dev, stride=None):
+    """overlay_i OVER video_i in one launch; video has the geometry of dst."""
+    p = _dev_ptr
+    _check(lib().flutl_launch_batch_over(ctypes.c_void_p(stream), width, height, p(dst),
+                                         p(video), stride or width * 4, p(frames_dev),
+                                         n_frames, p(regions_dev), p(prims_dev),
+                                         p(atlas_dev)),
+           "flutl_launch_batch_over")
 
 
 def launch_blur(stream, src, dst, w, h, kernel_dev, radius, stride=None):

@@ -147,6 +147,19 @@ int flutl_launch_batch (void *stream, uint32_t width, uint32_t height,
     const flutl_region *regions, const flutl_prim *prims,
     const uint8_t *atlas);
 
+/* The same batch, composited OVER video frames in the same launch: frame i of
+ * the result is  overlay_i OVER video_i  (pixman OVER of premultiplied pixels,
+ * saturating), where video_i = video + frames[i].dst_offset has the geometry
+ * of the destination (same stride) and `video` != `dst`.  This is the mixing
+ * step the reference leaves to a downstream element (plugins/ttml/README.md:
+ * 47-50, "videomixer"/"compositor" after ttmlrender); fused here the overlay
+ * frame never exists in memory.  Opaque video in, opaque video out. */
+int flutl_launch_batch_over (void *stream, uint32_t width, uint32_t height,
+    void *dst, const void *video, size_t stride_bytes,
+    const flutl_frame_desc *frames /* device */, uint32_t n_frames,
+    const flutl_region *regions, const flutl_prim *prims,
+    const uint8_t *atlas);
+
 /* Gaussian blur of a premultiplied ARGB32 image with pixman's convolution
  * semantics: replaces gst_ttml_blur_image_surface (gstttmlblur.c:71-110).
  * `kernel_fixed` = (2r+1)^2 pixman 16.16 weights (device), as produced by

@@ -89,14 +89,9 @@ def test_context_rejects_invalid_list(gpu):
         assert e.value.code == -34
 
 
-def test_batch_launch_equals_single_launches(gpu):
-    import torch
-    W, H = 256, 64
-    lists = [scenes.random_scene(s, W, H, n_regions=4) for s in range(5)]
-    # concatenate: shared prim array + atlas, per-frame region ranges
-    regs, prims, atl, frames = [], [], scenes.AtlasBuilder(), []
-    atlas_parts = []
-    base_off = 0
+def _concat_lists(lists, W, H):
+    """Several display lists -> one region / prim array + atlas + frame descriptors."""
+    regs, prims, frames = [], [], []
     atlas_all = np.zeros(F.ATLAS_SLACK, np.uint8)
     for i, (R, P, A) in enumerate(lists):
         R, P = R.copy(), P.copy()
@@ -107,16 +102,52 @@ def test_batch_launch_equals_single_launches(gpu):
         frames.append((sum(len(r) for r in regs), len(R), i * W * H * 4))
         regs.append(R); prims.append(P)
         atlas_all = np.concatenate([atlas_all, A[F.ATLAS_SLACK:]])
-    R = np.concatenate(regs); P = np.concatenate(prims)
-    Fd = np.array(frames, F.FRAME_DTYPE)
-    dst = torch.zeros(len(lists) * W * H * 4, dtype=torch.uint8, device="cuda")
+    return (np.concatenate(regs), np.concatenate(prims), atlas_all,
+            np.array(frames, F.FRAME_DTYPE))
+
+
+# 5 frames: rows interleaved over the XCDs; 8: whole frames per XCD; 19: both launches
+@pytest.mark.parametrize("n_frames", [5, 8, 19])
+def test_batch_launch_equals_single_launches(gpu, n_frames):
+    import torch
+    W, H = 256, 64
+    lists = [scenes.random_scene(s, W, H, n_regions=4) for s in range(n_frames)]
+    R, P, atlas_all, Fd = _concat_lists(lists, W, H)
+    dst = torch.full((n_frames * W * H * 4,), 0x5A, dtype=torch.uint8, device="cuda")
     F.launch_batch(torch.cuda.current_stream().cuda_stream, W, H, dst,
-                   gpu.to_dev(Fd), len(lists), gpu.to_dev(R), gpu.to_dev(P),
+                   gpu.to_dev(Fd), n_frames, gpu.to_dev(R), gpu.to_dev(P),
                    gpu.to_dev(atlas_all))
     torch.cuda.synchronize()
-    out = dst.cpu().numpy().view(np.uint32).reshape(len(lists), H, W)
+    out = dst.cpu().numpy().view(np.uint32).reshape(n_frames, H, W)
     for i, (Ri, Pi, Ai) in enumerate(lists):
         assert np.array_equal(out[i], O.render(W, H, Ri, Pi, Ai)), i
+
+
+@pytest.mark.parametrize("size,n_frames", [((256, 64), 3), ((130, 50), 9), ((63, 7), 2),
+                                           ((1280, 720), 2)])
+def test_fused_over_video_equals_overlay_then_pixman_over(gpu, size, n_frames):
+    """flutl_launch_batch_over == (overlay from the oracle) OVER video, pixman rule
+    (the OVER itself is pinned by kats.image)."""
+    import torch
+    W, H = size
+    lists = [scenes.random_scene(900 + s, W, H, n_regions=5) for s in range(n_frames)]
+    R, P, atlas_all, Fd = _concat_lists(lists, W, H)
+    rng = np.random.default_rng(W * 7 + n_frames)
+    video = rng.integers(0, 1 << 32, (n_frames, H, W), dtype=np.uint64).astype(np.uint32)
+    video[0] |= 0xFF000000                       # frame 0: opaque video, the usual case
+    vd = gpu.to_dev(video)
+    dst = torch.full((n_frames * W * H * 4,), 0x5A, dtype=torch.uint8, device="cuda")
+    F.launch_batch_over(torch.cuda.current_stream().cuda_stream, W, H, dst, vd,
+                        gpu.to_dev(Fd), n_frames, gpu.to_dev(R), gpu.to_dev(P),
+                        gpu.to_dev(atlas_all))
+    torch.cuda.synchronize()
+    out = dst.cpu().numpy().view(np.uint32).reshape(n_frames, H, W)
+    for i, (Ri, Pi, Ai) in enumerate(lists):
+        overlay = O.render(W, H, Ri, Pi, Ai)
+        exp = O.over(overlay.reshape(-1), video[i].reshape(-1)).reshape(H, W)
+        assert np.array_equal(out[i], exp), (i, int((out[i] != exp).sum()))
+    assert np.array_equal(vd.cpu().numpy().view(np.uint32).reshape(video.shape), video), \
+        "the video frames were written to"
 
 
 def test_blur_matches_pixman_kats(gpu, kats):
