@@ -282,34 +282,43 @@ static int upload_list (flutl_ctx *c, const flutl_region *regions, uint32_t n_re
 
 extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
     const flutl_region *regions, uint32_t n_regions, const flutl_prim *prims,
-    uint32_t n_prims, int radius, double sigma, void *host_copy, uint32_t *offset_out)
+    uint32_t n_prims, int radius, double sigma, uint32_t distx, uint32_t disty,
+    const int32_t *box, void *host_copy, uint32_t *offset_out)
 {
-  if (!c || !offset_out || w == 0 || h == 0 || radius < 0 || radius > 16)
+  if (!c || !offset_out || w == 0 || h == 0 || w > 32766 || h > 32766 || radius < 0 ||
+      radius > 16 || distx > 127 || disty > 127)
     return FLUTL_EINVAL;
   int rc = flutl_list_validate (w, h, regions, n_regions, prims, n_prims,
       c->atlas_used + kAtlasSlack);
   if (rc)
     return rc;
   (void) hipSetDevice (c->device);
+  // a fractional blit position: the entry is the blurred surface resampled by
+  // the constant bilinear weights, one pixel wider and higher
+  const bool resample = distx != 0 || disty != 0 || box != nullptr;
+  const uint32_t ew = resample ? w + 1 : w, eh = resample ? h + 1 : h;
   const size_t tight = (size_t) w * 4, bytes = tight * h;
+  const size_t etight = (size_t) ew * 4, ebytes = etight * eh;
   // reserve the atlas entry first: growing the atlas moves it
   const size_t off = (c->atlas_used + kAtlasAlign - 1) & ~(kAtlasAlign - 1);
-  const size_t end = off + bytes;
+  const size_t end = off + ebytes;
   if (end + kAtlasSlack > 0x7fffffffu)
     return FLUTL_ERANGE;
   if ((rc = atlas_reserve (c, end + kAtlasSlack)))
     return rc;
-  // temporary surface in the context's staging frame
-  if (bytes > c->frame_cap) {
+  // temporary surface (and, when resampling, the blurred one) in the
+  // context's staging frame
+  const size_t need = resample ? 2 * bytes : bytes;
+  if (need > c->frame_cap) {
     if (c->frame) {
       (void) hipStreamSynchronize (c->stream);
       (void) hipFree (c->frame);
       c->frame = nullptr;
       c->frame_cap = 0;
     }
-    if (!hip_ok (hipMalloc (&c->frame, bytes)))
+    if (!hip_ok (hipMalloc (&c->frame, need)))
       return FLUTL_ENOMEM;
-    c->frame_cap = bytes;
+    c->frame_cap = need;
   }
   flutl_region *rd;
   flutl_prim *pd;
@@ -318,7 +327,7 @@ extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
   if ((rc = flutl_launch_frame (c->stream, w, h, c->frame, tight, rd, n_regions, pd,
            c->atlas)))
     return rc;
-  // Gaussian weights: host -> small device buffer kept in the list buffer's tail
+  // Gaussian weights: host -> small device buffer
   int32_t weights[33 * 33];
   if ((rc = flutl_blur_kernel (radius, sigma, weights)))
     return rc;
@@ -326,12 +335,16 @@ extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
   int32_t *wdev = nullptr;
   if (!hip_ok (hipMalloc (reinterpret_cast<void **> (&wdev), wbytes)))
     return FLUTL_ENOMEM;
+  uint8_t *blurred = resample ? static_cast<uint8_t *> (c->frame) + bytes : c->atlas + off;
   bool ok = hip_ok (hipMemcpyAsync (wdev, weights, wbytes, hipMemcpyHostToDevice, c->stream));
   if (ok)
-    ok = flutl_launch_blur (c->stream, c->frame, c->atlas + off, w, h, tight, wdev,
+    ok = flutl_launch_blur (c->stream, c->frame, blurred, w, h, tight, wdev,
         radius) == FLUTL_OK;
+  if (ok && resample)
+    ok = flutl_launch_resample (c->stream, blurred, c->atlas + off, w, h, tight, etight,
+        distx, disty, box) == FLUTL_OK;
   if (ok && host_copy)
-    ok = hip_ok (hipMemcpyAsync (host_copy, c->atlas + off, bytes, hipMemcpyDeviceToHost,
+    ok = hip_ok (hipMemcpyAsync (host_copy, c->atlas + off, ebytes, hipMemcpyDeviceToHost,
         c->stream));
   ok = hip_ok (hipStreamSynchronize (c->stream)) && ok;
   (void) hipFree (wdev);

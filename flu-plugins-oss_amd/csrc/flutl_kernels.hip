@@ -848,6 +848,55 @@ __global__ __launch_bounds__ (256) void flutl_blur_kernel_dev (
   dst[(size_t) y * stride_px + x] = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
 }
 
+// Bilinear resample by CONSTANT 7-bit weights: an ARGB32 surface blitted at a
+// fractional device position (cairo picks PIXMAN_FILTER_BILINEAR; the transform
+// is a pure translation, so every pixel has the same weights).  pixman-inlines.h
+// bilinear_interpolation with BILINEAR_INTERPOLATION_BITS = 7, REPEAT_NONE:
+// out (i, j) mixes src (i-1, j-1), (i, j-1), (i-1, j), (i, j); w x h -> (w+1) x (h+1).
+// The reference paints the surface through a cairo_rectangle + cairo_fill of its
+// extent (gstttmlrender.c:1221-1224): the box edges, fractional too, add the
+// rectangular scan converter's coverage as an a8 mask (sample IN coverage,
+// MUL_UN8 per channel); box = that rectangle in 24.8 relative to out (0, 0).
+// HBM bound, 8 bytes per output pixel with the re-reads served by the L1/L2.
+struct ResampleBox {
+  int x1, y1, x2, y2;
+  int enabled;
+};
+
+__global__ __launch_bounds__ (256) void flutl_resample_kernel_dev (
+    const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int w, int h,
+    int src_stride_px, int dst_stride_px, uint32_t distx, uint32_t disty, ResampleBox box)
+{
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (i > w || j > h)
+    return;
+  auto at = [&] (int x, int y) -> uint32_t {
+    return (x >= 0 && y >= 0 && x < w && y < h) ? src[(size_t) y * src_stride_px + x] : 0u;
+  };
+  const uint32_t tl = at (i - 1, j - 1), tr = at (i, j - 1), bl = at (i - 1, j), br = at (i, j);
+  const uint32_t dx = distx << 1, dy = disty << 1;
+  const uint32_t dxy = dx * dy, dxiy = (dx << 8) - dxy, dixy = (dy << 8) - dxy,
+      dixiy = 256u * 256u - (dy << 8) - (dx << 8) + dxy;
+  uint32_t r = 0;
+#pragma unroll
+  for (int sh = 0; sh < 32; sh += 8) {
+    const uint32_t c = ((tl >> sh) & 255u) * dixiy + ((tr >> sh) & 255u) * dxiy +
+        ((bl >> sh) & 255u) * dixy + ((br >> sh) & 255u) * dxy;
+    r |= ((c >> 16) & 255u) << sh;
+  }
+  if (box.enabled) {
+    const uint32_t cov = min ((uint32_t) (overlap256 (box.x1, box.x2, i) *
+        overlap256 (box.y1, box.y2, j)) >> 8, 255u);
+    Px v = unpack (r);
+    const u16x2 cc = splat (cov);
+    v.rb = mul_un8 (v.rb, cc);
+    v.ag = mul_un8 (v.ag, cc);
+    r = pack (v);
+  }
+  dst[(size_t) j * dst_stride_px + i] = r;
+}
+
 int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst,
     const void *video, size_t stride, const flutl_frame_desc *frames, uint32_t n_frames,
     uint32_t region_first, uint32_t region_count, const flutl_region *regions,
@@ -952,5 +1001,29 @@ extern "C" int flutl_launch_blur (void *stream, const void *src, void *dst,
       static_cast<hipStream_t> (stream), static_cast<const uint32_t *> (src),
       static_cast<uint32_t *> (dst), (int) w, (int) h, (int) (stride_bytes / 4),
       kernel_fixed, radius);
+  return hipGetLastError () == hipSuccess ? FLUTL_OK : FLUTL_ENODEV;
+}
+
+extern "C" int flutl_launch_resample (void *stream, const void *src, void *dst,
+    uint32_t w, uint32_t h, size_t src_stride_bytes, size_t dst_stride_bytes,
+    uint32_t distx, uint32_t disty, const int32_t *box)
+{
+  if (!src || !dst || w == 0 || h == 0 || w > 32766 || h > 32766 || distx > 127 ||
+      disty > 127 || (src_stride_bytes & 3) || (dst_stride_bytes & 3) ||
+      src_stride_bytes < (size_t) w * 4 || dst_stride_bytes < (size_t) (w + 1) * 4)
+    return FLUTL_EINVAL;
+  ResampleBox b = { 0, 0, 0, 0, 0 };
+  if (box) {
+    // 24.8 coordinates of at most a frame: the overlap product stays below 2^31
+    for (int k = 0; k < 4; k++)
+      if (box[k] < -(1 << 24) || box[k] > (1 << 24))
+        return FLUTL_EINVAL;
+    b = ResampleBox { box[0], box[1], box[2], box[3], 1 };
+  }
+  dim3 grid ((w + 1 + 63) / 64, (h + 1 + 3) / 4);
+  hipLaunchKernelGGL (flutl_resample_kernel_dev, grid, dim3 (256), 0,
+      static_cast<hipStream_t> (stream), static_cast<const uint32_t *> (src),
+      static_cast<uint32_t *> (dst), (int) w, (int) h, (int) (src_stride_bytes / 4),
+      (int) (dst_stride_bytes / 4), distx, disty, b);
   return hipGetLastError () == hipSuccess ? FLUTL_OK : FLUTL_ENODEV;
 }

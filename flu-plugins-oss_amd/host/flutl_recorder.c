@@ -241,6 +241,12 @@ fixed_from_double (double d)
   return (int32_t) nearbyint (d * 256.0);
 }
 
+int32_t
+flutl_recorder_fixed_from_double (double d)
+{
+  return fixed_from_double (d);
+}
+
 static int
 imax (int a, int b)
 {

@@ -100,6 +100,9 @@ uint32_t flutl_recorder_atlas_append_device_entry (FlutlRecorder *rec,
 void flutl_recorder_paint_atlas_image (FlutlRecorder *rec, uint32_t offset, int w,
     int h, int x, int y);
 
+/* _cairo_fixed_from_double: device coordinate -> Cairo's 24.8 fixed point */
+int32_t flutl_recorder_fixed_from_double (double d);
+
 /* ---- results of the frame -------------------------------------------------*/
 const flutl_region *flutl_recorder_regions (FlutlRecorder *rec, uint32_t *n);
 const flutl_prim *flutl_recorder_prims (FlutlRecorder *rec, uint32_t *n);

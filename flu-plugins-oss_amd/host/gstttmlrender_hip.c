@@ -21,8 +21,8 @@
  * the odd ones; each is marked "reference:" below.
  *
  * Not implemented yet (counted and logged, never silently approximated):
- * blurred outlines at fractional positions or with a blur above 8 px,
- * unknown-glyph boxes.
+ * blurred outlines under a rotated CTM or with a blur above 8 px, unknown-glyph
+ * boxes.
  */
 #ifdef HAVE_CONFIG_H
 #include "config.h"
@@ -165,6 +165,9 @@ typedef struct
   gboolean ctx_failed;
   FlutlPackWriter *dump;     /* FLUTL_DUMP_PACK=<file>: scene-pack dump */
   gboolean dump_only;        /* FLUTL_DUMP_ONLY=1: record, do not render */
+  gboolean timing;           /* FLUTL_TIMING=1: host / device split on stderr at dispose */
+  gint64 t_record, t_device;
+  guint n_timed;
   GHashTable *images;        /* id -> cairo_surface_t (decoded PNGs) */
 } GstTTMLRenderPrivate;
 
@@ -982,20 +985,50 @@ blurred_outline (GstTTMLRender *render, HipRegion *r, PangoLayout *layout, guint
   /* reference :1216-1217: (surface, int radius = blur * 2, double sigma = blur) */
   int radius = (int) (r->outline.length[1].f * 2);
   double sigma = r->outline.length[1].f;
-  int tw, th;
+  int tw, th, dst_x, dst_y;
+  guint32 distx, disty;
+  gboolean fractional;
+  int32_t box[4] = { 0, 0, 0, 0 };
 
   pango_layout_get_pixel_extents (layout, NULL, &rect);
   tw = rect.width + 2 * br;
   th = rect.height + 2 * br;
   cairo_get_matrix (flutl_recorder_cairo (rec), &m);
-  if (m.xx != 1.0 || m.yy != 1.0 || m.xy != 0.0 || m.yx != 0.0 ||
-      m.x0 != floor (m.x0) || m.y0 != floor (m.y0) || radius > 16 || radius < 0 ||
-      !(sigma > 0.0) || tw <= 0 || th <= 0 || tw > 32767 || th > 32767) {
-    /* a fractional offset makes Cairo resample the blurred surface bilinearly */
-    GST_FIXME_OBJECT (render, "blurred textOutline at a fractional position, or "
-        "with a blur radius above 8 px, is not implemented; outline of region "
-        "'%s' not drawn", r->id);
+  if (m.xx != 1.0 || m.yy != 1.0 || m.xy != 0.0 || m.yx != 0.0 || radius > 16 ||
+      radius < 0 || !(sigma > 0.0) || tw <= 0 || th <= 0 || tw > 32766 || th > 32766 ||
+      fabs (m.x0) > 30000.0 || fabs (m.y0) > 30000.0) {
+    GST_FIXME_OBJECT (render, "blurred textOutline under a rotated CTM (vertical "
+        "writing modes), or with a blur radius above 8 px, is not implemented; "
+        "outline of region '%s' not drawn", r->id);
     return;
+  }
+  /* reference :1219-1224: the blurred surface is set as source at the INTEGER
+   * user position (rect.x - br, rect.y - br) and a rectangle of its extent is
+   * filled under the CTM.  If the CTM offset is fractional (e.g. displayAlign
+   * center: posy = diff / 2.0) Cairo (a) resamples the surface with pixman's
+   * bilinear filter -- constant weights, the transform being a pure
+   * translation: translation in 16.16 rounded to nearest, 7 bits of its
+   * fraction -- and (b) antialiases the box edges.  Both pinned against the
+   * real libraries by tests/golden/kats.npz fracblit_*. */
+  {
+    const double X0 = m.x0 + (rect.x - br), Y0 = m.y0 + (rect.y - br);
+    const gint64 fx = (gint64) floor (-X0 * 65536.0 + 0.5);
+    const gint64 fy = (gint64) floor (-Y0 * 65536.0 + 0.5);
+    fractional = X0 != floor (X0) || Y0 != floor (Y0);
+    distx = (guint32) ((fx >> 9) & 0x7f);
+    disty = (guint32) ((fy >> 9) & 0x7f);
+    if (fractional) {           /* resampled entry: one pixel more, starts one earlier */
+      dst_x = (int) (-1 - (fx >> 16));
+      dst_y = (int) (-1 - (fy >> 16));
+      box[0] = flutl_recorder_fixed_from_double (X0) - dst_x * 256;
+      box[1] = flutl_recorder_fixed_from_double (Y0) - dst_y * 256;
+      box[2] = box[0] + tw * 256;
+      box[3] = box[1] + th * 256;
+    } else {
+      dst_x = (int) X0;
+      dst_y = (int) Y0;
+      distx = disty = 0;
+    }
   }
   if (priv->dump_only || !ensure_ctx (render)) {
     GST_WARNING_OBJECT (render, "blurred outline needs the device; not drawn");
@@ -1024,6 +1057,9 @@ blurred_outline (GstTTMLRender *render, HipRegion *r, PangoLayout *layout, guint
   g_checksum_update (sum, (const guchar *) &th, sizeof th);
   g_checksum_update (sum, (const guchar *) &radius, sizeof radius);
   g_checksum_update (sum, (const guchar *) &sigma, sizeof sigma);
+  g_checksum_update (sum, (const guchar *) &distx, sizeof distx);
+  g_checksum_update (sum, (const guchar *) &disty, sizeof disty);
+  g_checksum_update (sum, (const guchar *) box, sizeof box);
   key = g_strdup (g_checksum_get_string (sum));
   g_checksum_free (sum);
   if (!priv->blurred)
@@ -1033,7 +1069,8 @@ blurred_outline (GstTTMLRender *render, HipRegion *r, PangoLayout *layout, guint
     g_free (key);
   } else {
     guint32 dev_off = 0, host_off;
-    guint8 *copy = g_malloc ((gsize) tw * th * 4);
+    const int ew = tw + (fractional ? 1 : 0), eh = th + (fractional ? 1 : 0);
+    guint8 *copy = g_malloc ((gsize) ew * eh * 4);
     int rc;
     if (!flush_atlas (render)) {          /* the sub list's masks must be in HBM */
       g_free (copy);
@@ -1041,14 +1078,14 @@ blurred_outline (GstTTMLRender *render, HipRegion *r, PangoLayout *layout, guint
       return;
     }
     rc = flutl_atlas_put_blurred (priv->ctx, tw, th, rg, n_rg, pr, n_pr, radius, sigma,
-        copy, &dev_off);
+        distx, disty, fractional ? box : NULL, copy, &dev_off);
     if (rc != FLUTL_OK) {
       GST_ERROR_OBJECT (render, "flutl_atlas_put_blurred: %s", flutl_strerror (rc));
       g_free (copy);
       g_free (key);
       return;
     }
-    host_off = flutl_recorder_atlas_append_device_entry (rec, copy, (gsize) tw * th * 4);
+    host_off = flutl_recorder_atlas_append_device_entry (rec, copy, (gsize) ew * eh * 4);
     g_free (copy);
     if (host_off != dev_off) {
       GST_ERROR_OBJECT (render, "atlas out of sync (%u vs %u)", host_off, dev_off);
@@ -1057,13 +1094,12 @@ blurred_outline (GstTTMLRender *render, HipRegion *r, PangoLayout *layout, guint
     }
     img = g_new0 (BlurredImage, 1);
     img->offset = dev_off;
-    img->w = tw;
-    img->h = th;
+    img->w = ew;
+    img->h = eh;
     g_hash_table_insert (priv->blurred, key, img);
   }
   /* reference :1219-1224: blit at (rect.x - br, rect.y - br) under the CTM */
-  flutl_recorder_paint_atlas_image (rec, img->offset, img->w, img->h,
-      (int) m.x0 + rect.x - br, (int) m.y0 + rect.y - br);
+  flutl_recorder_paint_atlas_image (rec, img->offset, img->w, img->h, dst_x, dst_y);
 }
 
 /* Text outline (reference :1180-1232). */
@@ -1223,6 +1259,7 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
   const flutl_prim *pr;
   uint32_t n_rg, n_pr;
   GstBuffer *buffer = NULL;
+  gint64 t_start = 0, t_recorded = 0;
 
   GST_DEBUG_OBJECT (render, "buffer %" GST_TIME_FORMAT " + %" GST_TIME_FORMAT
       ", frame %dx%d", GST_TIME_ARGS (ts), GST_TIME_ARGS (duration), width, height);
@@ -1230,6 +1267,7 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
     return NULL;
 
   /* ---- host: scene state -> display list -------------------------------- */
+  t_start = priv->timing ? g_get_monotonic_time () : 0;
   flutl_recorder_begin_frame (rec, width, height);
   if (base->state.saved_region_attr_stacks) {
     gpointer ctx[2] = { render, &regions };
@@ -1265,6 +1303,7 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
   /* ---- device: display list -> frame ------------------------------------- */
   if (!ensure_ctx (render))
     return NULL;
+  t_recorded = priv->timing ? g_get_monotonic_time () : 0;
   if (!flush_atlas (render))
     return NULL;
   {
@@ -1288,6 +1327,12 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
       gst_buffer_unref (buffer);
       return NULL;
     }
+  }
+  if (priv->timing) {
+    gint64 t_end = g_get_monotonic_time ();
+    priv->t_record += t_recorded - t_start;
+    priv->t_device += t_end - t_recorded;
+    priv->n_timed++;
   }
   return buffer;
 }
@@ -1423,6 +1468,12 @@ gst_ttmlrender_dispose (GObject *object)
   GstTTMLRenderPrivate *priv = get_priv (render);
 
   gst_ttmlrender_reset (GST_TTMLBASE (render));
+  if (priv->timing && priv->n_timed) {
+    g_printerr ("ttmlrender-hip timing: %u buffers, record %.1f us, "
+        "atlas+upload+kernel+D2H %.1f us per buffer\n", priv->n_timed,
+        (double) priv->t_record / priv->n_timed, (double) priv->t_device / priv->n_timed);
+    priv->n_timed = 0;
+  }
   if (priv->dump) {
     flutl_pack_writer_free (priv->dump);
     priv->dump = NULL;
@@ -1541,4 +1592,5 @@ gst_ttmlrender_init (GstTTMLRender *render)
   dump = g_getenv ("FLUTL_DUMP_PACK");
   priv->dump = dump ? flutl_pack_writer_new (dump) : NULL;
   priv->dump_only = g_getenv ("FLUTL_DUMP_ONLY") != NULL;
+  priv->timing = g_getenv ("FLUTL_TIMING") != NULL;
 }

@@ -42,7 +42,7 @@ EXPORTS = [
     "flutl_abi_version", "flutl_device_count", "flutl_strerror",
     "flutl_list_validate", "flutl_launch_frame", "flutl_launch_batch",
     "flutl_launch_batch_over",
-    "flutl_launch_blur", "flutl_blur_kernel",
+    "flutl_launch_blur", "flutl_blur_kernel", "flutl_launch_resample",
     "flutl_ctx_create", "flutl_ctx_destroy", "flutl_ctx_sync",
     "flutl_atlas_put", "flutl_atlas_reset", "flutl_atlas_size",
     "flutl_list_create", "flutl_list_destroy",
@@ -96,7 +96,9 @@ def lib():
         L.flutl_render_to_host.argtypes = [vp, vp, vp, sz]
         L.flutl_render_frame_to_host.argtypes = [vp, u32, u32, vp, u32, vp, u32, vp, sz]
         L.flutl_atlas_put_blurred.argtypes = [vp, u32, u32, vp, u32, vp, u32, ctypes.c_int,
-                                              ctypes.c_double, vp, ctypes.POINTER(u32)]
+                                              ctypes.c_double, u32, u32, vp, vp,
+                                              ctypes.POINTER(u32)]
+        L.flutl_launch_resample.argtypes = [vp, vp, vp, u32, u32, sz, sz, u32, u32, vp]
         L.flutl_host_alloc.argtypes = [sz, ctypes.POINTER(vp)]
         L.flutl_host_free.argtypes = [vp]
         L.flutl_host_free.restype = None
@@ -167,6 +169,18 @@ def launch_batch_over(stream, width, height, dst, video, frames_dev, n_frames,
            "flutl_launch_batch_over")
 
 
+def launch_resample(stream, src, dst, w, h, distx, disty, box=None, src_stride=None,
+                    dst_stride=None):
+    """pixman bilinear resample by constant 7-bit weights: w x h -> (w+1) x (h+1);
+    box = 24.8 rectangle whose edge coverage multiplies the samples, or None"""
+    p = _dev_ptr
+    b = None if box is None else np.ascontiguousarray(box, np.int32)
+    _check(lib().flutl_launch_resample(ctypes.c_void_p(stream), p(src), p(dst), w, h,
+                                       src_stride or w * 4, dst_stride or (w + 1) * 4,
+                                       distx, disty, None if b is None else _np_ptr(b)),
+           "flutl_launch_resample")
+
+
 def launch_blur(stream, src, dst, w, h, kernel_dev, radius, stride=None):
     p = _dev_ptr
     _check(lib().flutl_launch_blur(ctypes.c_void_p(stream), p(src), p(dst), w, h,
@@ -200,15 +214,21 @@ class Context:
                                      ctypes.byref(off)), "flutl_atlas_put")
         return off.value
 
-    def atlas_put_blurred(self, w, h, regions, prims, radius, sigma):
-        """returns (atlas offset, host copy of the blurred w x h ARGB32 image)"""
+    def atlas_put_blurred(self, w, h, regions, prims, radius, sigma, distx=0, disty=0,
+                          box=None):
+        """returns (atlas offset, host copy of the entry: the blurred w x h ARGB32
+        image, or -- distx/disty != 0 -- its (h+1) x (w+1) bilinear resample)"""
         regions = np.ascontiguousarray(regions, REGION_DTYPE)
         prims = np.ascontiguousarray(prims, PRIM_DTYPE)
-        out = np.empty((h, w), np.uint32)
+        grow = 1 if (distx or disty or box is not None) else 0
+        b = None if box is None else np.ascontiguousarray(box, np.int32)
+        out = np.empty((h + grow, w + grow), np.uint32)
         off = ctypes.c_uint32()
         _check(lib().flutl_atlas_put_blurred(
             self._h, w, h, _np_ptr(regions), len(regions), _np_ptr(prims), len(prims),
-            radius, float(sigma), _np_ptr(out), ctypes.byref(off)), "flutl_atlas_put_blurred")
+            radius, float(sigma), distx, disty, None if b is None else _np_ptr(b),
+            _np_ptr(out), ctypes.byref(off)),
+            "flutl_atlas_put_blurred")
         return off.value, out
 
     def atlas_reset(self):

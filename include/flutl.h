@@ -173,6 +173,20 @@ int flutl_launch_blur (void *stream, const void *src, void *dst,
  * (gstttmlblur.c:27-67).  Writes (2r+1)^2 16.16 weights to out. */
 int flutl_blur_kernel (int radius, double sigma, int32_t *out);
 
+/* pixman PIXMAN_FILTER_BILINEAR resample of a premultiplied ARGB32 image under
+ * a pure fractional translation: replaces what cairo_paint does at
+ * gstttmlrender.c:1219-1224 when the CTM offset is not an integer.  distx /
+ * disty = the 7-bit weights of the right / lower neighbour; dst is
+ * (w+1) x (h+1): dst (i, j) mixes src (i-1, j-1), (i, j-1), (i-1, j), (i, j),
+ * transparent outside the source (PIXMAN_REPEAT_NONE).
+ * box (host pointer, 4 ints, or NULL): the reference paints the surface
+ * through cairo_rectangle + cairo_fill of its extent (:1221-1224); {x1, y1, x2,
+ * y2} is that rectangle in Cairo's 24.8 fixed point relative to dst (0, 0),
+ * and its antialiased edge coverage multiplies the sample (pixman IN). */
+int flutl_launch_resample (void *stream, const void *src, void *dst,
+    uint32_t w, uint32_t h, size_t src_stride_bytes, size_t dst_stride_bytes,
+    uint32_t distx, uint32_t disty, const int32_t *box);
+
 /* ---- context API (library-owned HBM; what the GStreamer element uses) ---- */
 
 typedef struct flutl_ctx flutl_ctx;     /* one per element instance / thread  */
@@ -201,12 +215,19 @@ size_t flutl_atlas_size (const flutl_ctx *ctx);
  * radius/sigma as its arguments) and the result becomes a NEW ATLAS ENTRY
  * (premultiplied ARGB32, stride 4*w) whose offset is returned: the frame's
  * display list then blits it with an IMAGE primitive (:1219-1224).
- * If host_copy is not NULL the w*h*4 result bytes are also copied there (for
+ * distx / disty (0..127): when the blit position is fractional Cairo samples
+ * the blurred surface with pixman's bilinear filter, whose 7-bit weights are
+ * constant for a pure translation; the entry is then the blurred surface
+ * resampled by them, (w+1) x (h+1), stride 4*(w+1), blitted at integer
+ * coordinates (see flutl_launch_resample, also for `box`).  0, 0, NULL: the
+ * blurred surface itself.
+ * If host_copy is not NULL the entry's bytes are also copied there (for
  * scene-pack dumps).  radius <= 16. */
 int  flutl_atlas_put_blurred (flutl_ctx *ctx, uint32_t w, uint32_t h,
     const flutl_region *regions, uint32_t n_regions,
     const flutl_prim *prims, uint32_t n_prims,
-    int radius, double sigma, void *host_copy, uint32_t *offset_out);
+    int radius, double sigma, uint32_t distx, uint32_t disty, const int32_t *box,
+    void *host_copy, uint32_t *offset_out);
 
 /* Upload (validate + H2D) a display list for a W x H frame. */
 int  flutl_list_create (flutl_ctx *ctx, uint32_t width, uint32_t height,

@@ -312,6 +312,67 @@ int flutl_oracle_blur (const uint32_t *src, uint32_t *dst, uint32_t w,
   return FLUTL_OK;
 }
 
+/* An ARGB32 surface blitted at a fractional device position (the blurred
+ * outline of gstttmlrender.c:1219-1224 under a CTM with fractional x0/y0):
+ * cairo 1.16 selects PIXMAN_FILTER_BILINEAR; pixman 0.40 samples at the pixel
+ * centre, x1 = x * 65536 + t (t = the pattern translation in 16.16, rounded to
+ * nearest from the double), weights = 7 bits of the fraction, constant over
+ * the image because the transform is a pure translation
+ * (pixman-inlines.h bilinear_interpolation, BILINEAR_INTERPOLATION_BITS = 7).
+ *
+ * flutl_oracle_frac_origin: device origin (double) -> integer destination of
+ * resampled pixel (0,0) and the 7-bit weight of the right/lower neighbour.
+ * flutl_oracle_resample: w x h -> (w+1) x (h+1); pixel (i,j) mixes source
+ * pixels (i-1,j-1), (i,j-1), (i-1,j), (i,j), transparent outside. */
+void flutl_oracle_frac_origin (double origin, int *base, uint32_t *dist)
+{
+  const int64_t t = (int64_t) floor (-origin * 65536.0 + 0.5);
+  *base = (int) (-1 - (t >> 16));
+  *dist = (uint32_t) ((t >> 9) & 0x7f);
+}
+
+static uint32_t bilinear_px (uint32_t tl, uint32_t tr, uint32_t bl, uint32_t br,
+    uint32_t distx, uint32_t disty)
+{
+  distx <<= 1;
+  disty <<= 1;
+  const uint32_t dxy = distx * disty, dxiy = (distx << 8) - dxy,
+      dixy = (disty << 8) - dxy,
+      dixiy = 256 * 256 - (disty << 8) - (distx << 8) + dxy;
+  uint32_t r = 0;
+  for (int sh = 0; sh < 32; sh += 8) {
+    const uint32_t c = ((tl >> sh) & 255) * dixiy + ((tr >> sh) & 255) * dxiy +
+        ((bl >> sh) & 255) * dixy + ((br >> sh) & 255) * dxy;
+    r |= ((c >> 16) & 255) << sh;
+  }
+  return r;
+}
+
+/* box: NULL, or the 24.8 box {x1, y1, x2, y2} of the cairo_rectangle + cairo_fill
+ * that the reference paints the surface through (:1221-1224), relative to
+ * resampled pixel (0,0): its antialiased edge coverage (rectangular scan
+ * converter, see flutl_oracle_rect_coverage) multiplies the sample (pixman IN
+ * with an a8 mask: MUL_UN8 per channel) before the OVER. */
+void flutl_oracle_resample (const uint32_t *src, uint32_t w, uint32_t h,
+    uint32_t distx, uint32_t disty, const int32_t *box,
+    uint32_t *dst /* (w+1) x (h+1) */)
+{
+#define SRC(x, y) (((x) >= 0 && (y) >= 0 && (x) < (int) w && (y) < (int) h) \
+    ? src[(size_t) (y) * w + (x)] : 0u)
+  for (int j = 0; j <= (int) h; j++)
+    for (int i = 0; i <= (int) w; i++)
+    {
+      uint32_t v = bilinear_px (SRC (i - 1, j - 1), SRC (i, j - 1),
+          SRC (i - 1, j), SRC (i, j), distx, disty);
+      if (box) {
+        const uint32_t cov = flutl_oracle_rect_coverage (box[0], box[1], box[2], box[3], i, j);
+        v = un8x4_mul_un8 (v, cov);
+      }
+      dst[(size_t) j * (w + 1) + i] = v;
+    }
+#undef SRC
+}
+
 /* ---- array forms (so that Python tests can check whole tables quickly) --- */
 void flutl_oracle_blend_n (uint32_t rule, const uint32_t *s, const uint32_t *m,
     const uint32_t *d, uint32_t *out, size_t n)

@@ -438,6 +438,70 @@ kat_blur (const char *dir)
   fclose (f);
 }
 
+/* Table 9: an ARGB32 surface painted at a FRACTIONAL device position, issued
+ * like the blurred-outline blit of gstttmlrender.c:1219-1224 (set_source_surface
+ * at integer (px, py) under a CTM translated by doubles, then cairo_paint):
+ * cairo picks the bilinear filter, pixman resamples with 7-bit weights.
+ * Odd records paint; even records fill the rectangle of the surface's extent,
+ * as the reference does: the box edges then add an antialiased coverage.
+ * record: tx, ty f64; px, py i32; src SW x SH u32; dst0, out DW x DH u32 */
+static void
+kat_fracblit (const char *dir)
+{
+  FILE *f = open_out (dir, "fracblit.bin");
+  enum { SW = 10, SH = 7, DW = 24, DH = 16 };
+  const double fr[] = { 0.5, 0.25, 0.75, 0.125, 1.0 / 3.0, 0.99, 0.004, 0.0 };
+  for (int it = 0; it < 160; it++) {
+    uint32_t src[SW * SH], d0[DW * DH], px[DW * DH];
+    for (int i = 0; i < SW * SH; i++)
+      src[i] = (it % 5 == 4) ? 0xff804020u : rand_premul ();
+    for (int i = 0; i < DW * DH; i++)
+      d0[i] = px[i] = (it % 3 == 0) ? 0 : rand_premul ();
+    uint64_t r = splitmix64 ();
+    double tx, ty;
+    if (it < 64) {
+      tx = 3 + fr[it % 8];
+      ty = 2 + fr[(it / 8) % 8];
+    } else {
+      tx = ((r & 0xfffff) / 1048576.0) * 9.0 - 1.5;
+      ty = (((r >> 20) & 0xfffff) / 1048576.0) * 6.0 - 1.5;
+      if (it % 7 == 0)
+        ty = (double) (int) ty;       /* fractional in x only */
+      if (it >= 128) {
+        /* just below / above a 7-bit weight boundary: pins how cairo rounds
+         * the translation to 16.16 */
+        int kx = (int) ((r >> 48) & 127), ky = (int) ((r >> 55) & 127);
+        tx = 3 + (kx * 512 + ((it & 1) ? 0.4 : -0.4)) / 65536.0;
+        ty = 2 + (ky * 512 + ((it & 2) ? 0.6 : -0.6)) / 65536.0;
+      }
+    }
+    int ox = (int) ((r >> 40) & 3) - 1, oy = (int) ((r >> 44) & 3) - 1;
+    cairo_surface_t *s = surf (px, DW, DH);
+    cairo_surface_t *is = surf (src, SW, SH);
+    cairo_t *cr = cairo_create (s);
+    cairo_translate (cr, tx, ty);
+    cairo_set_source_surface (cr, is, ox, oy);
+    if (it & 1) {
+      cairo_paint (cr);
+    } else {                        /* exactly as :1219-1224: a fill of the extent */
+      cairo_rectangle (cr, ox, oy, SW, SH);
+      cairo_fill (cr);
+    }
+    cairo_destroy (cr);
+    cairo_surface_finish (s);
+    cairo_surface_destroy (s);
+    cairo_surface_destroy (is);
+    wf64 (f, tx);
+    wf64 (f, ty);
+    w32 (f, (uint32_t) ox);
+    w32 (f, (uint32_t) oy);
+    fwrite (src, 4, SW * SH, f);
+    fwrite (d0, 4, DW * DH, f);
+    fwrite (px, 4, DW * DH, f);
+  }
+  fclose (f);
+}
+
 int
 main (int argc, char **argv)
 {
@@ -455,5 +519,6 @@ main (int argc, char **argv)
   kat_stroke (argv[1]);
   kat_image (argv[1]);
   kat_blur (argv[1]);
+  kat_fracblit (argv[1]);
   return 0;
 }

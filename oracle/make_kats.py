@@ -66,6 +66,15 @@ def main():
             off += 4 * W * H
             i += 1
         out["blur_count"] = np.array(i)
+        SW, SH, DW, DH = 10, 7, 24, 16
+        b = np.fromfile(f("fracblit.bin"), np.dtype(
+            [("t", "<f8", 2), ("o", "<i4", 2), ("src", "<u4", (SH, SW)),
+             ("d", "<u4", (DH, DW)), ("out", "<u4", (DH, DW))]))
+        out["fracblit_t"] = b["t"]
+        out["fracblit_o"] = b["o"]
+        out["fracblit_src"] = b["src"]
+        out["fracblit_dst"] = b["d"]
+        out["fracblit_out"] = b["out"]
     dst = os.path.join(ROOT, "tests", "golden", "kats.npz")
     os.makedirs(os.path.dirname(dst), exist_ok=True)
     np.savez_compressed(dst, **out)

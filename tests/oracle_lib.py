@@ -104,6 +104,48 @@ def blur(src, kernel, radius):
     return out
 
 
+def frac_origin(origin):
+    """device origin (double) -> (integer destination of resampled pixel 0, 7-bit weight)"""
+    import ctypes
+    base, dist = ctypes.c_int(), ctypes.c_uint32()
+    L = lib()
+    L.flutl_oracle_frac_origin.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_int),
+                                           ctypes.POINTER(ctypes.c_uint32)]
+    L.flutl_oracle_frac_origin.restype = None
+    L.flutl_oracle_frac_origin(float(origin), ctypes.byref(base), ctypes.byref(dist))
+    return base.value, dist.value
+
+
+def resample(src, distx, disty, box=None):
+    """pixman bilinear resample of an ARGB32 image by constant 7-bit weights -> (h+1, w+1);
+    box = 24.8 {x1, y1, x2, y2} of the fill it is painted through (edge coverage), or None"""
+    import ctypes
+    src = np.ascontiguousarray(src, np.uint32)
+    h, w = src.shape
+    out = np.empty((h + 1, w + 1), np.uint32)
+    L = lib()
+    u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+    L.flutl_oracle_resample.argtypes = [u32p, ctypes.c_uint32, ctypes.c_uint32,
+                                        ctypes.c_uint32, ctypes.c_uint32,
+                                        ctypes.c_void_p, u32p]
+    L.flutl_oracle_resample.restype = None
+    b = None if box is None else np.ascontiguousarray(box, np.int32)
+    L.flutl_oracle_resample(src, w, h, int(distx), int(disty),
+                            None if b is None else b.ctypes.data, out)
+    return out
+
+
+def fixed_24_8(d):
+    """_cairo_fixed_from_double: nearest 1/256, ties to even"""
+    import math
+    v = d * 256.0
+    f = math.floor(v)
+    r = v - f
+    if r > 0.5 or (r == 0.5 and (int(f) & 1)):
+        f += 1
+    return int(f)
+
+
 def blur_kernel(radius, sigma):
     out = np.empty((2 * radius + 1) ** 2, np.int32)
     lib().flutl_oracle_blur_kernel(radius, float(sigma), out)

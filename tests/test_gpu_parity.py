@@ -167,6 +167,28 @@ def test_blur_matches_pixman_kats(gpu, kats):
                                              for y, x in bad[:6]])
 
 
+@pytest.mark.parametrize("size", [(10, 7), (64, 4), (65, 5), (301, 57)])
+def test_resample_matches_oracle_and_cairo_kats(gpu, kats, size):
+    """flutl_launch_resample == oracle (pinned by the real-cairo fractional blits)."""
+    import torch
+    w, h = size
+    rng = np.random.default_rng(w * 31 + h)
+    for distx, disty in [(64, 0), (0, 32), (1, 127), (96, 17)]:
+        if (w, h) == (10, 7):       # the KAT images themselves
+            src = kats["fracblit_src"][(distx + disty) % len(kats["fracblit_src"])]
+        else:
+            src = rng.integers(0, 1 << 32, (h, w), dtype=np.uint64).astype(np.uint32)
+        sd = gpu.to_dev(src)
+        dd = torch.full(((h + 1) * (w + 1) * 4,), 0x77, dtype=torch.uint8, device="cuda")
+        for box in (None, [256 - 2 * distx, 256 - 2 * disty,
+                           256 - 2 * distx + w * 256, 256 - 2 * disty + h * 256]):
+            F.launch_resample(torch.cuda.current_stream().cuda_stream, sd, dd, w, h,
+                              distx, disty, box)
+            torch.cuda.synchronize()
+            got = dd.cpu().numpy().view(np.uint32).reshape(h + 1, w + 1)
+            assert np.array_equal(got, O.resample(src, distx, disty, box)), (distx, disty, box)
+
+
 def test_blur_matches_oracle_large(gpu):
     import torch
     rng = np.random.default_rng(3)
