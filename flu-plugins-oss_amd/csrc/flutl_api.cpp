@@ -12,6 +12,7 @@
 #include <string.h>
 #include <mutex>
 #include <new>
+#include <vector>
 #include "flutl.h"
 
 namespace {
@@ -152,12 +153,12 @@ extern "C" int flutl_list_validate (uint32_t width, uint32_t height,
 
 extern "C" int flutl_blur_kernel (int radius, double sigma, int32_t *out)
 {
-  if (radius < 0 || radius > 16 || !out || !(sigma > 0.0))
+  if (radius < 0 || radius > 128 || !out || !(sigma > 0.0))
     return FLUTL_EINVAL;
   const double scale2 = 2.0 * sigma * sigma;
   const double scale1 = 1.0 / (M_PI * scale2);
   const int size = 2 * radius + 1;
-  double acc[33 * 33];
+  std::vector<double> acc ((size_t) size * size);
   double sum = 0.0;
   int i = 0;
   for (int x = -radius; x <= radius; ++x)
@@ -286,7 +287,7 @@ extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
     const int32_t *box, void *host_copy, uint32_t *offset_out)
 {
   if (!c || !offset_out || w == 0 || h == 0 || w > 32766 || h > 32766 || radius < 0 ||
-      radius > 16 || distx > 127 || disty > 127)
+      radius > 128 || distx > 127 || disty > 127)
     return FLUTL_EINVAL;
   int rc = flutl_list_validate (w, h, regions, n_regions, prims, n_prims,
       c->atlas_used + kAtlasSlack);
@@ -328,15 +329,15 @@ extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
            c->atlas)))
     return rc;
   // Gaussian weights: host -> small device buffer
-  int32_t weights[33 * 33];
-  if ((rc = flutl_blur_kernel (radius, sigma, weights)))
+  std::vector<int32_t> weights ((size_t) (2 * radius + 1) * (2 * radius + 1));
+  if ((rc = flutl_blur_kernel (radius, sigma, weights.data ())))
     return rc;
   const size_t wbytes = (size_t) (2 * radius + 1) * (2 * radius + 1) * 4;
   int32_t *wdev = nullptr;
   if (!hip_ok (hipMalloc (reinterpret_cast<void **> (&wdev), wbytes)))
     return FLUTL_ENOMEM;
   uint8_t *blurred = resample ? static_cast<uint8_t *> (c->frame) + bytes : c->atlas + off;
-  bool ok = hip_ok (hipMemcpyAsync (wdev, weights, wbytes, hipMemcpyHostToDevice, c->stream));
+  bool ok = hip_ok (hipMemcpyAsync (wdev, weights.data (), wbytes, hipMemcpyHostToDevice, c->stream));
   if (ok)
     ok = flutl_launch_blur (c->stream, c->frame, blurred, w, h, tight, wdev,
         radius) == FLUTL_OK;

@@ -798,7 +798,9 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
 // per 32x8 output tile; the (32+2r) x (8+2r) source halo and the (2r+1)^2
 // 16.16 weights are staged in LDS; accumulation is exact int32:
 //   acc_c += chan_c * f;  out_c = clip ((acc_c + 0x8000) >> 16, 0, 255).
-constexpr int kBlurTW = 32, kBlurTH = 8, kBlurMaxR = 16;
+constexpr int kBlurTW = 32, kBlurTH = 8;
+constexpr int kBlurMaxR = 16;      // LDS-tiled kernel (<= 18 KB of LDS)
+constexpr int kBlurMaxRWide = 128; // flutl_blur_wide_kernel_dev: taps straight from L1/L2
 
 __global__ __launch_bounds__ (256) void flutl_blur_kernel_dev (
     const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int w, int h,
@@ -845,6 +847,43 @@ __global__ __launch_bounds__ (256) void flutl_blur_kernel_dev (
   // its upper 16 bits were zero; on MI355X they are not (observed: R |= B).
   // Keep the four clamps opaque so that the plain med3 form is emitted.
   asm volatile ("" : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));
+  dst[(size_t) y * stride_px + x] = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
+}
+
+// The same convolution for radii whose halo does not fit the LDS tile (blur
+// lengths above 8 px, rare): one pixel per lane, taps and weights read through
+// the L1/L2.  Same arithmetic, same results; O((2r+1)^2) loads per pixel.
+__global__ __launch_bounds__ (256) void flutl_blur_wide_kernel_dev (
+    const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int w, int h,
+    int stride_px, const int32_t *__restrict__ kern, int radius)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h)
+    return;
+  const int size = 2 * radius + 1;
+  int32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  for (int j = 0; j < size; j++) {
+    const int sy = y - radius + j;
+    if (sy < 0 || sy >= h)
+      continue;
+    const uint32_t *row = src + (size_t) sy * stride_px;
+    const int32_t *krow = kern + j * size;
+    const int i0 = max (0, radius - x), i1 = min (size, w - x + radius);
+    for (int i = i0; i < i1; i++) {
+      const int32_t f = krow[i];
+      const uint32_t p = row[x - radius + i];
+      a0 += (int32_t) (p & 0xff) * f;
+      a1 += (int32_t) ((p >> 8) & 0xff) * f;
+      a2 += (int32_t) ((p >> 16) & 0xff) * f;
+      a3 += (int32_t) (p >> 24) * f;
+    }
+  }
+  uint32_t o0 = (uint32_t) min (max ((a0 + 0x8000) >> 16, 0), 255);
+  uint32_t o1 = (uint32_t) min (max ((a1 + 0x8000) >> 16, 0), 255);
+  uint32_t o2 = (uint32_t) min (max ((a2 + 0x8000) >> 16, 0), 255);
+  uint32_t o3 = (uint32_t) min (max ((a3 + 0x8000) >> 16, 0), 255);
+  asm volatile ("" : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));   // see above
   dst[(size_t) y * stride_px + x] = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
 }
 
@@ -991,8 +1030,15 @@ extern "C" int flutl_launch_blur (void *stream, const void *src, void *dst,
     int radius)
 {
   if (!src || !dst || !kernel_fixed || w == 0 || h == 0 || radius < 0 ||
-      radius > kBlurMaxR || (stride_bytes & 3) || stride_bytes < (size_t) w * 4)
+      radius > kBlurMaxRWide || (stride_bytes & 3) || stride_bytes < (size_t) w * 4)
     return FLUTL_EINVAL;
+  if (radius > kBlurMaxR) {
+    hipLaunchKernelGGL (flutl_blur_wide_kernel_dev, dim3 ((w + 63) / 64, (h + 3) / 4),
+        dim3 (256), 0, static_cast<hipStream_t> (stream),
+        static_cast<const uint32_t *> (src), static_cast<uint32_t *> (dst), (int) w,
+        (int) h, (int) (stride_bytes / 4), kernel_fixed, radius);
+    return hipGetLastError () == hipSuccess ? FLUTL_OK : FLUTL_ENODEV;
+  }
   const int size = 2 * radius + 1;
   const size_t lds = ((size_t) (kBlurTW + 2 * radius) * (kBlurTH + 2 * radius) +
       (size_t) size * size) * 4;

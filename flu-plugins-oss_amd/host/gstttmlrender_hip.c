@@ -21,7 +21,7 @@
  * the odd ones; each is marked "reference:" below.
  *
  * Not implemented yet (counted and logged, never silently approximated):
- * blurred outlines under a rotated CTM or with a blur above 8 px, unknown-glyph
+ * blurred outlines under a rotated CTM or with a blur above 64 px, unknown-glyph
  * boxes.
  */
 #ifdef HAVE_CONFIG_H
@@ -994,11 +994,11 @@ blurred_outline (GstTTMLRender *render, HipRegion *r, PangoLayout *layout, guint
   tw = rect.width + 2 * br;
   th = rect.height + 2 * br;
   cairo_get_matrix (flutl_recorder_cairo (rec), &m);
-  if (m.xx != 1.0 || m.yy != 1.0 || m.xy != 0.0 || m.yx != 0.0 || radius > 16 ||
+  if (m.xx != 1.0 || m.yy != 1.0 || m.xy != 0.0 || m.yx != 0.0 || radius > 128 ||
       radius < 0 || !(sigma > 0.0) || tw <= 0 || th <= 0 || tw > 32766 || th > 32766 ||
       fabs (m.x0) > 30000.0 || fabs (m.y0) > 30000.0) {
     GST_FIXME_OBJECT (render, "blurred textOutline under a rotated CTM (vertical "
-        "writing modes), or with a blur radius above 8 px, is not implemented; "
+        "writing modes), or with a blur length above 64 px, is not implemented; "
         "outline of region '%s' not drawn", r->id);
     return;
   }

@@ -222,7 +222,7 @@ size_t flutl_atlas_size (const flutl_ctx *ctx);
  * coordinates (see flutl_launch_resample, also for `box`).  0, 0, NULL: the
  * blurred surface itself.
  * If host_copy is not NULL the entry's bytes are also copied there (for
- * scene-pack dumps).  radius <= 16. */
+ * scene-pack dumps).  radius <= 128. */
 int  flutl_atlas_put_blurred (flutl_ctx *ctx, uint32_t w, uint32_t h,
     const flutl_region *regions, uint32_t n_regions,
     const flutl_prim *prims, uint32_t n_prims,

@@ -196,8 +196,10 @@ def test_blur_matches_oracle_large(gpu):
     a = rng.integers(0, 256, (h, w)).astype(np.uint32)
     src = (a << 24) | ((a * rng.integers(0, 256, (h, w)) // 255) << 16) | (a >> 1)
     src = src.astype(np.uint32)
-    for r, sigma in [(2, 1.0), (6, 3.0)]:
+    # radius 16 is the last LDS-tiled one; 17, 40 take the wide kernel
+    for r, sigma in [(2, 1.0), (6, 3.0), (16, 8.0), (17, 8.5), (40, 20.0)]:
         k = F.blur_kernel(r, sigma)
+        assert np.array_equal(k, O.blur_kernel(r, sigma))
         d = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
         F.launch_blur(torch.cuda.current_stream().cuda_stream, gpu.to_dev(src), d,
                       w, h, gpu.to_dev(k), r)
