@@ -123,6 +123,30 @@ def test_batch_launch_equals_single_launches(gpu, n_frames):
         assert np.array_equal(out[i], O.render(W, H, Ri, Pi, Ai)), i
 
 
+@pytest.mark.parametrize("size,n_frames,seed0", [((200, 72), 40, 1000), ((97, 41), 27, 2000),
+                                                 ((512, 96), 12, 3000)])
+def test_fuzz_batches_against_oracle(gpu, size, n_frames, seed0):
+    """Many adversarial lists (overlapping regions, opacity groups over painted
+    pixels -> the park path, images, clipped masks) in one launch, every frame
+    against the oracle."""
+    import torch
+    W, H = size
+    lists = [scenes.random_scene(seed0 + s, W, H, n_regions=3 + s % 10,
+                                 prims_per_region=8 + (s * 7) % 40)
+             for s in range(n_frames)]
+    R, P, atlas_all, Fd = _concat_lists(lists, W, H)
+    assert F.validate(W, H, R, P, atlas_all.size) == 0
+    dst = torch.full((n_frames * W * H * 4,), 0xC3, dtype=torch.uint8, device="cuda")
+    F.launch_batch(torch.cuda.current_stream().cuda_stream, W, H, dst,
+                   gpu.to_dev(Fd), n_frames, gpu.to_dev(R), gpu.to_dev(P),
+                   gpu.to_dev(atlas_all))
+    torch.cuda.synchronize()
+    out = dst.cpu().numpy().view(np.uint32).reshape(n_frames, H, W)
+    for i, (Ri, Pi, Ai) in enumerate(lists):
+        exp = O.render(W, H, Ri, Pi, Ai)
+        assert np.array_equal(out[i], exp), (i, int((out[i] != exp).sum()))
+
+
 @pytest.mark.parametrize("size,n_frames", [((256, 64), 3), ((130, 50), 9), ((63, 7), 2),
                                            ((1280, 720), 2)])
 def test_fused_over_video_equals_overlay_then_pixman_over(gpu, size, n_frames):
