@@ -44,6 +44,8 @@ def load_states(cfg, n_states, stream_seed):
     if pack is not None:
         return pack.width, pack.height, pack.states(n_states), pack.atlas, pack.source
     import scenes
+    if stream_seed is None:
+        stream_seed = 20
     W, H, nreg, font, outl, lines = CONFIGS[cfg]
     R, P, A = scenes.subtitle_like_scene(stream_seed, W, H, n_regions=nreg,
                                          font_px=font, outline_px=outl, lines=lines)
@@ -126,7 +128,10 @@ def main():
 
     # one independent stream per rank (weak scaling); no data-path collective
     my_streams = streams.streams_of_rank(world, rank, world)
-    W, H, states, atlas, source = load_states(args.config, args.states, 20 + my_streams[0])
+    # N = 1 is BASELINE config 2 (the canonical cfg2 document); N > 1 is config 3:
+    # cfg2 with seeds 20.., one independent stream per GPU
+    stream_seed = 20 + my_streams[0] if world > 1 else None
+    W, H, states, atlas, source = load_states(args.config, args.states, stream_seed)
     n_states = len(states)
     B = args.batch
     frame_bytes = W * H * 4

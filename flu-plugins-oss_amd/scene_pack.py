@@ -71,7 +71,10 @@ def load(path):
 def find_pack(config, stream_seed):
     """bench_data/<config>_seed<seed>.flpk.z, else the seed-less pack, else None."""
     d = os.path.join(ROOT, "bench_data")
-    for name in (f"{config}_seed{stream_seed}.flpk.z", f"{config}.flpk.z"):
+    names = [f"{config}.flpk.z"]
+    if stream_seed is not None:
+        names.insert(0, f"{config}_seed{stream_seed}.flpk.z")
+    for name in names:
         p = os.path.join(d, name)
         if os.path.exists(p):
             return load(p)
