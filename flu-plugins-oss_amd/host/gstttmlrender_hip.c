@@ -66,19 +66,39 @@ enum
 
 /* Pool of page-locked output frames.  Blocks are wrapped as GstMemory; when
  * downstream drops the buffer the block comes back here.  The pool is
- * reference counted because buffers may outlive the element. */
+ * reference counted because buffers may outlive the element.
+ *
+ * Dirty-rectangle read-back: a block is zeroed once, when it is
+ * allocated, and remembers the row bands it was last written in.  A frame is
+ * transparent outside its regions, so only the bands of the new frame's
+ * regions plus the block's previous bands are copied from the device (which
+ * renders the whole frame in HBM anyway): typical subtitles cover a fifth of
+ * the frame, and the 33 MB PCIe copy is what bounds the element.  The memory is
+ * handed out READONLY so that nobody scribbles outside the remembered bands
+ * (a downstream element that wants to write makes its copy, as GStreamer's
+ * writability rules require anyway).  FLUTL_FULL_D2H=1 restores whole-frame
+ * copies into writable memory. */
+#define MAX_BANDS 16
+
+typedef struct
+{
+  gpointer block;
+  guint n_bands;
+  guint32 bands[2 * MAX_BANDS];   /* [y0, y1) pairs, sorted, disjoint */
+} FrameSlot;
+
 typedef struct
 {
   gint refs;
   GMutex lock;
   gsize block_size;
-  GPtrArray *free_blocks;
+  GPtrArray *free_slots;          /* FrameSlot* */
 } FramePool;
 
 typedef struct
 {
   FramePool *pool;
-  gpointer block;
+  FrameSlot *slot;
   gsize size;
 } FrameBlock;
 
@@ -88,8 +108,15 @@ frame_pool_new (void)
   FramePool *p = g_new0 (FramePool, 1);
   p->refs = 1;
   g_mutex_init (&p->lock);
-  p->free_blocks = g_ptr_array_new ();
+  p->free_slots = g_ptr_array_new ();
   return p;
+}
+
+static void
+frame_slot_free (FrameSlot *s)
+{
+  flutl_host_free (s->block);
+  g_free (s);
 }
 
 static void
@@ -97,9 +124,9 @@ frame_pool_unref (FramePool *p)
 {
   if (!g_atomic_int_dec_and_test (&p->refs))
     return;
-  for (guint i = 0; i < p->free_blocks->len; i++)
-    flutl_host_free (g_ptr_array_index (p->free_blocks, i));
-  g_ptr_array_free (p->free_blocks, TRUE);
+  for (guint i = 0; i < p->free_slots->len; i++)
+    frame_slot_free (g_ptr_array_index (p->free_slots, i));
+  g_ptr_array_free (p->free_slots, TRUE);
   g_mutex_clear (&p->lock);
   g_free (p);
 }
@@ -111,41 +138,83 @@ frame_block_release (gpointer data)
   FramePool *p = b->pool;
   g_mutex_lock (&p->lock);
   /* keep at most a few frames, and only of the current size */
-  if (b->size == p->block_size && p->free_blocks->len < 6)
-    g_ptr_array_add (p->free_blocks, b->block);
+  if (b->size == p->block_size && p->free_slots->len < 6)
+    g_ptr_array_add (p->free_slots, b->slot);
   else
-    flutl_host_free (b->block);
+    frame_slot_free (b->slot);
   g_mutex_unlock (&p->lock);
   frame_pool_unref (p);
   g_free (b);
 }
 
 /* A GstBuffer over a recycled page-locked block (system memory as far as
- * downstream is concerned), or NULL if page-locked memory is unavailable. */
+ * downstream is concerned), or NULL if page-locked memory is unavailable.
+ * *slot_out: the block's band memory (all-zero block if n_bands == 0 and fresh). */
 static GstBuffer *
-frame_pool_acquire (FramePool *p, gsize size, gpointer *data)
+frame_pool_acquire (FramePool *p, gsize size, gboolean readonly, FrameSlot **slot_out)
 {
-  gpointer block = NULL;
+  FrameSlot *slot = NULL;
   FrameBlock *b;
   g_mutex_lock (&p->lock);
   if (p->block_size != size) {
-    for (guint i = 0; i < p->free_blocks->len; i++)
-      flutl_host_free (g_ptr_array_index (p->free_blocks, i));
-    g_ptr_array_set_size (p->free_blocks, 0);
+    for (guint i = 0; i < p->free_slots->len; i++)
+      frame_slot_free (g_ptr_array_index (p->free_slots, i));
+    g_ptr_array_set_size (p->free_slots, 0);
     p->block_size = size;
   }
-  if (p->free_blocks->len)
-    block = g_ptr_array_remove_index_fast (p->free_blocks, p->free_blocks->len - 1);
+  if (p->free_slots->len)
+    slot = g_ptr_array_remove_index_fast (p->free_slots, p->free_slots->len - 1);
   g_mutex_unlock (&p->lock);
-  if (!block && flutl_host_alloc (size, &block) != FLUTL_OK)
-    return NULL;
+  if (!slot) {
+    gpointer block = NULL;
+    if (flutl_host_alloc (size, &block) != FLUTL_OK)
+      return NULL;
+    memset (block, 0, size);      /* once per block: the transparent frame */
+    slot = g_new0 (FrameSlot, 1);
+    slot->block = block;
+  }
   b = g_new0 (FrameBlock, 1);
   b->pool = p;
-  b->block = block;
+  b->slot = slot;
   b->size = size;
   g_atomic_int_inc (&p->refs);
-  *data = block;
-  return gst_buffer_new_wrapped_full (0, block, size, 0, size, b, frame_block_release);
+  *slot_out = slot;
+  return gst_buffer_new_wrapped_full (readonly ? GST_MEMORY_FLAG_READONLY : 0, slot->block,
+      size, 0, size, b, frame_block_release);
+}
+
+/* Sort + merge [y0, y1) pairs in place (also bands closer than 8 rows: fewer,
+ * larger copies); more than MAX_BANDS collapse into one.  Returns the count. */
+static guint
+bands_normalise (guint32 *bands, guint n)
+{
+  guint i, j, out = 0;
+  for (i = 1; i < n; i++) {     /* insertion sort by y0: n is small */
+    guint32 a = bands[2 * i], c = bands[2 * i + 1];
+    for (j = i; j > 0 && bands[2 * (j - 1)] > a; j--) {
+      bands[2 * j] = bands[2 * (j - 1)];
+      bands[2 * j + 1] = bands[2 * (j - 1) + 1];
+    }
+    bands[2 * j] = a;
+    bands[2 * j + 1] = c;
+  }
+  for (i = 0; i < n; i++) {
+    if (bands[2 * i] >= bands[2 * i + 1])
+      continue;
+    if (out && bands[2 * i] <= bands[2 * (out - 1) + 1] + 8) {
+      if (bands[2 * i + 1] > bands[2 * (out - 1) + 1])
+        bands[2 * (out - 1) + 1] = bands[2 * i + 1];
+    } else {
+      bands[2 * out] = bands[2 * i];
+      bands[2 * out + 1] = bands[2 * i + 1];
+      out++;
+    }
+  }
+  if (out > MAX_BANDS) {
+    bands[1] = bands[2 * (out - 1) + 1];
+    out = 1;
+  }
+  return out;
 }
 
 /* Device-side state of one element instance. */
@@ -165,6 +234,7 @@ typedef struct
   gboolean ctx_failed;
   FlutlPackWriter *dump;     /* FLUTL_DUMP_PACK=<file>: scene-pack dump */
   gboolean dump_only;        /* FLUTL_DUMP_ONLY=1: record, do not render */
+  gboolean full_d2h;         /* FLUTL_FULL_D2H=1: whole-frame copies, writable memory */
   gboolean timing;           /* FLUTL_TIMING=1: host / device split on stderr at dispose */
   gint64 t_record, t_device;
   guint n_timed;
@@ -1308,12 +1378,35 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
     return NULL;
   {
     GstMapInfo map;
-    gpointer pinned = NULL;
+    FrameSlot *slot = NULL;
     int rc;
-    buffer = frame_pool_acquire (priv->pool, (gsize) width * height * 4, &pinned);
-    if (buffer) {
+    buffer = frame_pool_acquire (priv->pool, (gsize) width * height * 4, !priv->full_d2h,
+        &slot);
+    if (buffer && !priv->full_d2h) {
+      /* rows to read back: this frame's regions + what the block held before */
+      guint32 *bands = g_new (guint32, 2 * (n_rg + slot->n_bands) + 2);
+      guint32 now[2 * MAX_BANDS + 2];
+      guint n = 0, n_now, i;
+      for (i = 0; i < n_rg; i++) {
+        bands[2 * n] = (guint32) CLAMP (rg[i].y0, 0, height);
+        bands[2 * n + 1] = (guint32) CLAMP (rg[i].y1, 0, height);
+        n++;
+      }
+      n_now = bands_normalise (bands, n);
+      memcpy (now, bands, sizeof (guint32) * 2 * n_now);
+      memcpy (bands + 2 * n_now, slot->bands, sizeof (guint32) * 2 * slot->n_bands);
+      n = bands_normalise (bands, n_now + slot->n_bands);
+      if (n == 0)     /* nothing now, nothing before: the block is already the frame */
+        rc = FLUTL_OK;
+      else
+        rc = flutl_render_frame_rows_to_host (priv->ctx, width, height, rg, n_rg, pr, n_pr,
+            slot->block, (size_t) width * 4, bands, n);
+      memcpy (slot->bands, now, sizeof (guint32) * 2 * n_now);
+      slot->n_bands = n_now;
+      g_free (bands);
+    } else if (buffer) {
       rc = flutl_render_frame_to_host (priv->ctx, width, height, rg, n_rg, pr, n_pr,
-          pinned, (size_t) width * 4);
+          slot->block, (size_t) width * 4);
     } else {                    /* no page-locked memory: plain system buffer */
       buffer = gst_buffer_new_and_alloc ((gsize) width * height * 4);
       gst_buffer_map (buffer, &map, GST_MAP_WRITE);
@@ -1593,4 +1686,5 @@ gst_ttmlrender_init (GstTTMLRender *render)
   priv->dump = dump ? flutl_pack_writer_new (dump) : NULL;
   priv->dump_only = g_getenv ("FLUTL_DUMP_ONLY") != NULL;
   priv->timing = g_getenv ("FLUTL_TIMING") != NULL;
+  priv->full_d2h = g_getenv ("FLUTL_FULL_D2H") != NULL;
 }

@@ -48,6 +48,7 @@ EXPORTS = [
     "flutl_list_create", "flutl_list_destroy",
     "flutl_render", "flutl_render_to_host",
     "flutl_host_alloc", "flutl_host_free", "flutl_render_frame_to_host",
+    "flutl_render_frame_rows_to_host",
     "flutl_atlas_put_blurred",
 ]
 
@@ -95,6 +96,8 @@ def lib():
         L.flutl_render.argtypes = [vp, vp, vp, sz]
         L.flutl_render_to_host.argtypes = [vp, vp, vp, sz]
         L.flutl_render_frame_to_host.argtypes = [vp, u32, u32, vp, u32, vp, u32, vp, sz]
+        L.flutl_render_frame_rows_to_host.argtypes = [vp, u32, u32, vp, u32, vp, u32, vp, sz,
+                                                      vp, u32]
         L.flutl_atlas_put_blurred.argtypes = [vp, u32, u32, vp, u32, vp, u32, ctypes.c_int,
                                               ctypes.c_double, u32, u32, vp, vp,
                                               ctypes.POINTER(u32)]
@@ -254,6 +257,17 @@ class Context:
         _check(lib().flutl_render_to_host(self._h, lst, _np_ptr(out), width * 4),
                "flutl_render_to_host")
         return out
+
+    def render_frame_rows_into(self, width, height, regions, prims, out, bands):
+        """dirty-rectangle form: only the row bands [(y0, y1), ...] of `out` (a C-contiguous
+        (height, width) uint32 array) are written"""
+        regions = np.ascontiguousarray(regions, REGION_DTYPE)
+        prims = np.ascontiguousarray(prims, PRIM_DTYPE)
+        b = np.ascontiguousarray(bands, np.uint32).reshape(-1)
+        _check(lib().flutl_render_frame_rows_to_host(
+            self._h, width, height, _np_ptr(regions), len(regions), _np_ptr(prims),
+            len(prims), _np_ptr(out), width * 4, _np_ptr(b) if b.size else None,
+            b.size // 2), "flutl_render_frame_rows_to_host")
 
     def render_frame_to_host(self, width, height, regions, prims, pinned=True):
         """the element's per-buffer call; with pinned=True the frame lands in

@@ -253,6 +253,17 @@ int  flutl_render_frame_to_host (flutl_ctx *ctx, uint32_t width, uint32_t height
     const flutl_region *regions, uint32_t n_regions,
     const flutl_prim *prims, uint32_t n_prims,
     void *dst_host, size_t dst_stride_bytes);
+/* The same, copying back only the rows [row_bands[2i], row_bands[2i+1]) of the
+ * frame (n_bands pairs, inside [0, height)): the "dirty-rect D2H into
+ * pre-zeroed buffers" of a pooled output frame -- rows outside every region
+ * are transparent, so a buffer that was zero there stays right without being
+ * copied.  The caller must include the rows its buffer was written in before.
+ * n_bands == 0 copies the whole frame. */
+int  flutl_render_frame_rows_to_host (flutl_ctx *ctx, uint32_t width, uint32_t height,
+    const flutl_region *regions, uint32_t n_regions,
+    const flutl_prim *prims, uint32_t n_prims,
+    void *dst_host, size_t dst_stride_bytes,
+    const uint32_t *row_bands, uint32_t n_bands);
 
 /* Page-locked host memory for output frames: a D2H copy into it is a true
  * asynchronous DMA at PCIe rate (pageable memory goes through a bounce buffer

@@ -270,3 +270,23 @@ def test_context_render_frame_to_host_pinned_and_pageable(gpu):
         with pytest.raises(F.FlutlError):
             bad = P2.copy(); bad["op"][0] = 99
             ctx.render_frame_to_host(W, H, R2, bad)
+
+
+def test_context_row_band_copy_leaves_other_rows_alone(gpu):
+    """flutl_render_frame_rows_to_host: only the requested bands of the host frame are
+    written, and they hold the frame's rows."""
+    W, H = 320, 180
+    R, P, A = scenes.random_scene(5, W, H, n_regions=5)
+    exp = O.render(W, H, R, P, A)
+    with F.Context(0) as ctx:
+        ctx.atlas_put(A[F.ATLAS_SLACK:])
+        out = np.full((H, W), 0xDEADBEEF, np.uint32)
+        bands = [(3, 40), (41, 42), (100, 180)]
+        ctx.render_frame_rows_into(W, H, R, P, out, bands)
+        inside = np.zeros(H, bool)
+        for y0, y1 in bands:
+            inside[y0:y1] = True
+        assert np.array_equal(out[inside], exp[inside])
+        assert (out[~inside] == 0xDEADBEEF).all()
+        ctx.render_frame_rows_into(W, H, R, P, out, [])       # no bands: whole frame
+        assert np.array_equal(out, exp)
