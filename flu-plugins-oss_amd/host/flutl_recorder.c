@@ -1029,12 +1029,29 @@ stroke_rasterise (FlutlRecorder *rec, StrokeEntry *e, int fill)
   for (int y = by0; y < by1; y++) {
     const uint8_t *row = data + (size_t) y * stride;
     int first = -1, last = -1;
-    for (int x = bx0; x < bx1; x++)
-      if (row[x]) {
-        if (first < 0)
-          first = x;
-        last = x;
+    /* first / last covered pixel of the row, 8 bytes at a time (most of a
+     * text line's bounding box is empty) */
+    int x = bx0, xe = bx1;
+    while (x < xe && ((uintptr_t) (row + x) & 7) && !row[x])
+      x++;
+    if (x < xe && !row[x]) {
+      while (x + 8 <= xe && *(const uint64_t *) (row + x) == 0)
+        x += 8;
+      while (x < xe && !row[x])
+        x++;
+    }
+    if (x < xe) {
+      first = x;
+      while (xe > first && ((uintptr_t) (row + xe) & 7) && !row[xe - 1])
+        xe--;
+      if (!row[xe - 1]) {
+        while (xe - 8 > first && *(const uint64_t *) (row + xe - 8) == 0)
+          xe -= 8;
+        while (!row[xe - 1])
+          xe--;
       }
+      last = xe - 1;
+    }
     if (first >= 0) {
       if (first < tx0) tx0 = first;
       if (last > tx1) tx1 = last;
