@@ -290,3 +290,33 @@ def test_context_row_band_copy_leaves_other_rows_alone(gpu):
         assert (out[~inside] == 0xDEADBEEF).all()
         ctx.render_frame_rows_into(W, H, R, P, out, [])       # no bands: whole frame
         assert np.array_equal(out, exp)
+
+
+def test_contexts_on_concurrent_threads(gpu):
+    """One context per element instance, several instances in a process, each on its own
+    streaming thread (SURVEY 8b threading): results must not interfere."""
+    import threading
+    W, H = 320, 180
+    jobs = [scenes.random_scene(4000 + i, W, H, n_regions=6) for i in range(4)]
+    exp = [O.render(W, H, R, P, A) for (R, P, A) in jobs]
+    errors = []
+
+    def worker(i):
+        try:
+            R, P, A = jobs[i]
+            with F.Context(0) as ctx:
+                ctx.atlas_put(A[F.ATLAS_SLACK:])
+                for _ in range(20):
+                    got = ctx.render_frame_to_host(W, H, R, P, pinned=(i % 2 == 0))
+                    if not np.array_equal(got, exp[i]):
+                        errors.append((i, int((got != exp[i]).sum())))
+                        return
+        except Exception as e:      # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
