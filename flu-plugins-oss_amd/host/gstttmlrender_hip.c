@@ -239,6 +239,8 @@ typedef struct
   gint64 t_record, t_device;
   guint n_timed;
   GHashTable *images;        /* id -> cairo_surface_t (decoded PNGs) */
+  GHashTable *layouts;       /* layout cache: key string -> PangoLayout, per document */
+  gboolean no_layout_cache;  /* FLUTL_NO_LAYOUT_CACHE=1 */
 } GstTTMLRenderPrivate;
 
 static GstStaticPadTemplate ttmlrender_src_template =
@@ -771,15 +773,67 @@ background_region (gpointer key, gpointer value, gpointer user_data)
   }
 }
 
+/* Layout cache: the reference rebuilds every PangoLayout -- markup
+ * parse, itemisation, HarfBuzz shaping, line breaking -- for every buffer
+ * (:1462-1472), although consecutive scene states mostly differ in one
+ * attribute of one region.  A layout is a function of the paragraph's markup,
+ * its extra attributes and a few numbers; layouts are kept per document under
+ * that key and shared (they are never modified after creation).  Returns FALSE
+ * for paragraphs whose attributes are not plain data (anamorphic shapes). */
+static gboolean
+layout_cache_key (GString *key, PangoContext *ctx, HipRegion *r, gint w, gint h,
+    gboolean wrap, PangoAlignment align, gint spacing)
+{
+  /* (the context's gravity is part of the key: the reference sets it for the
+   * vertical writing modes and never sets it back, and so do we) */
+  g_string_append_printf (key, "%d,%d,%d,%d,%d,%d,%d,%d|", w, h, wrap, (int) align, spacing,
+      (int) r->writing_mode, (int) pango_context_get_base_gravity (ctx),
+      (int) pango_context_get_gravity_hint (ctx));
+  if (r->par_attrs) {
+    PangoAttrIterator *it = pango_attr_list_get_iterator (r->par_attrs);
+    gboolean plain = TRUE;
+    do {
+      GSList *l, *attrs = pango_attr_iterator_get_attrs (it);
+      for (l = attrs; l; l = l->next) {
+        PangoAttribute *at = l->data;
+        if (plain) {
+          if (at->klass->type == PANGO_ATTR_FOREGROUND ||
+              at->klass->type == PANGO_ATTR_BACKGROUND) {
+            const PangoColor *c = &((PangoAttrColor *) at)->color;
+            g_string_append_printf (key, "c%d:%u-%u:%u,%u,%u;", (int) at->klass->type,
+                at->start_index, at->end_index, c->red, c->green, c->blue);
+          } else if (at->klass >= &hip_attr_klass[0] &&
+              at->klass < &hip_attr_klass[HIP_ATTR_LAST]) {
+            g_string_append_printf (key, "h%d:%u-%u:%d;", (int) (at->klass - hip_attr_klass),
+                at->start_index, at->end_index, ((PangoAttrInt *) at)->value);
+          } else {
+            plain = FALSE;
+          }
+        }
+        pango_attribute_destroy (at);
+      }
+      g_slist_free (attrs);
+    } while (pango_attr_iterator_next (it));
+    pango_attr_iterator_destroy (it);
+    if (!plain)
+      return FALSE;
+  }
+  g_string_append_c (key, '|');
+  g_string_append_len (key, r->par->str, r->par->len);
+  return TRUE;
+}
+
 /* Paragraph -> PangoLayout (reference :199-289). */
 static void
 region_flush_paragraph (GstTTMLRender *render, HipRegion *r)
 {
-  PangoLayout *layout = pango_layout_new (render->pango_context);
+  GstTTMLRenderPrivate *priv = get_priv (render);
+  PangoLayout *layout;
   GstTTMLAttribute *a;
-  gint w = r->pex, h = r->pey;
+  gint w = r->pex, h = r->pey, spacing = -1;
   GstTTMLWrapOption wrap = GST_TTML_WRAP_OPTION_YES;
   PangoAlignment align = PANGO_ALIGN_LEFT;
+  GString *key = NULL;
 
   if (r->writing_mode > GST_TTML_WRITING_MODE_RLTB) {
     w = r->pey;
@@ -788,10 +842,6 @@ region_flush_paragraph (GstTTMLRender *render, HipRegion *r)
   a = gst_ttml_style_get_attr (&r->par_style, GST_TTML_ATTR_WRAP_OPTION);
   if (a)
     wrap = a->value.wrap_option;
-  if (wrap == GST_TTML_WRAP_OPTION_YES)
-    pango_layout_set_width (layout, w * PANGO_SCALE);
-  pango_layout_set_height (layout, h * PANGO_SCALE);
-
   a = gst_ttml_style_get_attr (&r->par_style, GST_TTML_ATTR_TEXT_ALIGN);
   switch (a ? a->value.text_align : render->default_text_align) {
     case GST_TTML_TEXT_ALIGN_RIGHT:
@@ -804,15 +854,37 @@ region_flush_paragraph (GstTTMLRender *render, HipRegion *r)
     default:
       break;
   }
-  pango_layout_set_alignment (layout, align);
-
   /* reference: lineHeight is smuggled to the draw loop as the layout spacing;
    * -1 means "use the line's own extents" */
   a = gst_ttml_style_get_attr (&r->par_style, GST_TTML_ATTR_LINE_HEIGHT);
   if (a && gst_ttml_attribute_is_length_present (a, 0))
-    pango_layout_set_spacing (layout, norm_len (render, a, 0, 1));
-  else
-    pango_layout_set_spacing (layout, -1);
+    spacing = norm_len (render, a, 0, 1);
+
+  if (!priv->no_layout_cache) {
+    key = g_string_new (NULL);
+    if (!layout_cache_key (key, render->pango_context, r, w, h,
+            wrap == GST_TTML_WRAP_OPTION_YES, align, spacing)) {
+      g_string_free (key, TRUE);
+      key = NULL;
+    }
+  }
+  layout = key && priv->layouts ? g_hash_table_lookup (priv->layouts, key->str) : NULL;
+  if (layout) {
+    g_object_ref (layout);
+    g_string_free (key, TRUE);
+    if (r->par_attrs) {
+      pango_attr_list_unref (r->par_attrs);
+      r->par_attrs = NULL;
+    }
+    goto done;
+  }
+
+  layout = pango_layout_new (render->pango_context);
+  if (wrap == GST_TTML_WRAP_OPTION_YES)
+    pango_layout_set_width (layout, w * PANGO_SCALE);
+  pango_layout_set_height (layout, h * PANGO_SCALE);
+  pango_layout_set_alignment (layout, align);
+  pango_layout_set_spacing (layout, spacing);
 
   pango_layout_set_markup (layout, r->par->str, -1);
 
@@ -831,6 +903,16 @@ region_flush_paragraph (GstTTMLRender *render, HipRegion *r)
     r->par_attrs = NULL;
   }
 
+  if (key) {
+    if (!priv->layouts)
+      priv->layouts = g_hash_table_new_full (g_str_hash, g_str_equal, g_free,
+          g_object_unref);
+    if (g_hash_table_size (priv->layouts) >= 512)   /* bound it: start over */
+      g_hash_table_remove_all (priv->layouts);
+    g_hash_table_insert (priv->layouts, g_string_free (key, FALSE), g_object_ref (layout));
+  }
+
+done:
   r->layouts = g_list_append (r->layouts, layout);
   g_string_free (r->par, TRUE);
   r->par = NULL;
@@ -1538,6 +1620,10 @@ gst_ttmlrender_reset (GstTTMLBase *base)
     g_hash_table_unref (priv->images);
     priv->images = NULL;
   }
+  if (priv->layouts) {
+    g_hash_table_unref (priv->layouts);
+    priv->layouts = NULL;
+  }
   if (priv->rec)
     flutl_recorder_reset (priv->rec);
   if (priv->sub)
@@ -1687,4 +1773,5 @@ gst_ttmlrender_init (GstTTMLRender *render)
   priv->dump_only = g_getenv ("FLUTL_DUMP_ONLY") != NULL;
   priv->timing = g_getenv ("FLUTL_TIMING") != NULL;
   priv->full_d2h = g_getenv ("FLUTL_FULL_D2H") != NULL;
+  priv->no_layout_cache = g_getenv ("FLUTL_NO_LAYOUT_CACHE") != NULL;
 }
