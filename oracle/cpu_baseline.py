@@ -38,6 +38,10 @@ def measure(config, W, H, states, atlas):
         r = ref_runner.measure_reference(config, W, H)
         if r is not None:
             r["port"] = measure_port(W, H, states, atlas, budget_s=6.0)
+            try:    # one instance is the baseline; all cores is reported beside it
+                r["all_cores"] = ref_runner.measure_reference_all_cores(config, W, H)
+            except Exception as e:      # noqa: BLE001
+                print(f"cpu_baseline: all-cores leg failed ({e!r})", file=sys.stderr)
             return r
     except Exception as e:  # the reference leg is optional; the port is not
         print(f"cpu_baseline: reference leg unavailable ({e!r}); using the port",

@@ -84,6 +84,28 @@ def measure_reference(config, W, H, plugin_dir=None):
                       f"start-up excluded)"}
 
 
+def measure_reference_all_cores(config, W, H, n_procs=None):
+    """The reference is single threaded per element: its "all host cores" figure
+     is n concurrent pipelines, one per core; frames/s are summed."""
+    import concurrent.futures
+    import gstenv
+    cfg = CFG_OF.get(config, config)
+    ttml = os.path.join(ROOT, "bench_data", cfg + ".ttml")
+    if not (gstenv.available(gstenv.REF_PLUGIN_DIR) and os.path.exists(ttml)):
+        return None
+    n = n_procs or max(1, min(len(os.sched_getaffinity(0)), 32))
+    with concurrent.futures.ThreadPoolExecutor(n) as ex:
+        runs = list(ex.map(lambda _: _push_times(gstenv.REF_PLUGIN_DIR, ttml, W, H), range(n)))
+    runs = [t for t in runs if len(t) >= 3]
+    if not runs:
+        return None
+    fps = sum((len(t) - 1) / max(t[-1] - t[0], 1e-9) for t in runs)
+    return {"value": round(fps, 3), "unit": "frames/s", "cores": len(runs),
+            "kind": "reference",
+            "sample": f"{len(runs)} concurrent reference pipelines (one per core) over "
+                      f"bench_data/{cfg}.ttml at {W}x{H}, frames/s summed"}
+
+
 if __name__ == "__main__":
     import gstenv
     which = sys.argv[4] if len(sys.argv) > 4 else "ref"
