@@ -79,6 +79,7 @@ struct FlutlRecorder
   FlutlRecorder *parent;      /* child recorders put their masks in the parent's atlas */
   int width, height;
   cairo_surface_t *scratch;   /* A8, width x height */
+  int no_line_split;          /* FLUTL_NO_LINE_SPLIT=1: one mask per stroke, as drawn */
   cairo_t *cr;
 
   flutl_prim *prims;
@@ -319,6 +320,7 @@ flutl_recorder_new (void)
   if (!rec)
     abort ();
   rec->atlas_size = ATLAS_SLACK;
+  rec->no_line_split = g_getenv ("FLUTL_NO_LINE_SPLIT") != NULL;
   return rec;
 }
 
@@ -971,11 +973,23 @@ stroke_emit (FlutlRecorder *rec, const StrokeEntry *e, int dx, int dy)
   p->d = oy;
 }
 
-/* Build the pending path for real, stroke it and cut the coverage out of the
- * scratch surface.  Returns 0 if the stroke touched the surface borders (the
- * mask is then only valid at this very position). */
-static int
-stroke_rasterise (FlutlRecorder *rec, StrokeEntry *e, int fill)
+/* ---- rasterisation of a path into an A8 mask, in three steps ------------------
+ * prepare: the pending ops become a real Cairo path on rec->cr; its (generous)
+ *          device extents give the box to look at and tell whether the stroke
+ *          stays clear of the frame borders (then the mask is valid under any
+ *          integer translation);
+ * draw:    Cairo's stroker / filler + scan converter write coverage into the
+ *          scratch surface -- on the streaming thread, or, for the row-disjoint
+ *          lines of one stroke, on worker threads (below);
+ * crop:    the covered part of the box moves into the atlas. */
+typedef struct
+{
+  int bx0, by0, bx1, by1;       /* box to look at; empty: nothing to draw */
+  int inside;
+} RasterBox;
+
+static void
+raster_prepare (FlutlRecorder *rec, int fill, RasterBox *rb)
 {
   cairo_t *cr = rec->cr;
   cairo_new_path (cr);
@@ -1005,23 +1019,17 @@ stroke_rasterise (FlutlRecorder *rec, StrokeEntry *e, int fill)
   else
     cairo_stroke_extents (cr, &ex1, &ey1, &ex2, &ey2);
   cairo_restore (cr);
-  int inside = ex1 >= 3 && ey1 >= 3 && ex2 <= rec->width - 3 && ey2 <= rec->height - 3;
-  int bx0 = imax ((int) floor (ex1) - 2, 0), by0 = imax ((int) floor (ey1) - 2, 0);
-  int bx1 = imin ((int) ceil (ex2) + 2, rec->width);
-  int by1 = imin ((int) ceil (ey2) + 2, rec->height);
-  e->w = e->h = 0;
-  if (bx1 <= bx0 || by1 <= by0) {
-    cairo_new_path (cr);
-    return inside;
-  }
-  /* coverage = what the stroker + scan converter hand to the span renderer */
-  cairo_save (cr);
-  cairo_set_source_rgba (cr, 1, 1, 1, 1);
-  if (fill)
-    cairo_fill (cr);
-  else
-    cairo_stroke (cr);
-  cairo_restore (cr);
+  rb->inside = ex1 >= 3 && ey1 >= 3 && ex2 <= rec->width - 3 && ey2 <= rec->height - 3;
+  rb->bx0 = imax ((int) floor (ex1) - 2, 0);
+  rb->by0 = imax ((int) floor (ey1) - 2, 0);
+  rb->bx1 = imin ((int) ceil (ex2) + 2, rec->width);
+  rb->by1 = imin ((int) ceil (ey2) + 2, rec->height);
+}
+
+static void
+raster_crop (FlutlRecorder *rec, StrokeEntry *e, const RasterBox *rb)
+{
+  const int bx0 = rb->bx0, by0 = rb->by0, bx1 = rb->bx1, by1 = rb->by1;
   cairo_surface_flush (rec->scratch);
   uint8_t *data = cairo_image_surface_get_data (rec->scratch);
   int stride = cairo_image_surface_get_stride (rec->scratch);
@@ -1060,7 +1068,7 @@ stroke_rasterise (FlutlRecorder *rec, StrokeEntry *e, int fill)
     }
   }
   if (tx1 < tx0)
-    return inside;
+    return;
   int w = tx1 - tx0 + 1, h = ty1 - ty0 + 1;
   uint8_t *tight = malloc ((size_t) w * h);
   if (!tight)
@@ -1076,10 +1084,389 @@ stroke_rasterise (FlutlRecorder *rec, StrokeEntry *e, int fill)
   e->y = ty0;
   e->w = w;
   e->h = h;
-  return inside;
 }
 
-static void path_to_mask (FlutlRecorder *rec, int fill);
+/* Build the pending path for real, stroke it and cut the coverage out of the
+ * scratch surface.  Returns 0 if the stroke touched the surface borders (the
+ * mask is then only valid at this very position). */
+static int
+stroke_rasterise (FlutlRecorder *rec, StrokeEntry *e, int fill)
+{
+  cairo_t *cr = rec->cr;
+  RasterBox rb;
+  raster_prepare (rec, fill, &rb);
+  e->w = e->h = 0;
+  if (rb.bx1 <= rb.bx0 || rb.by1 <= rb.by0) {
+    cairo_new_path (cr);
+    return rb.inside;
+  }
+  /* coverage = what the stroker + scan converter hand to the span renderer */
+  cairo_save (cr);
+  cairo_set_source_rgba (cr, 1, 1, 1, 1);
+  if (fill)
+    cairo_fill (cr);
+  else
+    cairo_stroke (cr);
+  cairo_restore (cr);
+  raster_crop (rec, e, &rb);
+  return rb.inside;
+}
+
+/* ---- the lines of one stroke on worker threads ---------------------------------
+ * Each job strokes a copied path (device coordinates: no font or Pango object
+ * leaves the streaming thread) into its own cairo surface over its own rows of
+ * the scratch memory; the rows of different jobs do not overlap.
+ * FLUTL_RASTER_THREADS=n (1 = everything on the streaming thread). */
+typedef struct
+{
+  cairo_path_t *path;
+  double line_width;
+  uint8_t *data;
+  int stride, width;
+  int y0, y1;
+  GMutex *lock;
+  GCond *cond;
+  int *pending;
+} LineJob;
+
+static void
+line_job_run (gpointer data, gpointer user_data)
+{
+  LineJob *j = data;
+  /* The surface starts at row 0 of the scratch memory, NOT at the job's first
+   * row with a device offset: the stroker flattens curves in absolute double
+   * coordinates, and a translated copy differs by +-1 in a few pixels per
+   * frame (measured).  Surfaces of different jobs therefore alias memory, but
+   * a job only writes the pixels its stroke covers, which lie in its own rows. */
+  cairo_surface_t *s = cairo_image_surface_create_for_data (
+      j->data, CAIRO_FORMAT_A8, j->width, j->y1, j->stride);
+  cairo_t *cr;
+  cr = cairo_create (s);
+  cairo_append_path (cr, j->path);
+  cairo_set_source_rgba (cr, 1, 1, 1, 1);
+  cairo_set_line_width (cr, j->line_width);
+  cairo_stroke (cr);
+  cairo_destroy (cr);
+  cairo_surface_finish (s);
+  cairo_surface_destroy (s);
+  if (j->lock) {
+    g_mutex_lock (j->lock);
+    if (--*j->pending == 0)
+      g_cond_signal (j->cond);
+    g_mutex_unlock (j->lock);
+  }
+  (void) user_data;
+}
+
+static GThreadPool *raster_pool;
+static int raster_threads = -1;
+static GMutex raster_pool_lock;
+
+static int
+raster_thread_count (void)
+{
+  g_mutex_lock (&raster_pool_lock);
+  if (raster_threads < 0) {
+    const char *e = g_getenv ("FLUTL_RASTER_THREADS");
+    int n = e ? atoi (e) : (int) g_get_num_processors ();
+    raster_threads = n < 1 ? 1 : (n > 8 ? 8 : n);
+    if (raster_threads > 1)
+      raster_pool = g_thread_pool_new (line_job_run, NULL, raster_threads - 1, TRUE, NULL);
+    if (!raster_pool)
+      raster_threads = 1;
+  }
+  g_mutex_unlock (&raster_pool_lock);
+  return raster_threads;
+}
+
+/* The cache entry of one stroke / fill of the ops [rec->ops, rec->ops + rec->n_ops).
+ * *dx, *dy = where the mask goes relative to where it was made.  A new entry
+ * (*is_new) has no mask yet: the caller rasterises.  (The pointer is valid
+ * until the next call.) */
+static StrokeEntry *
+ops_find_mask (FlutlRecorder *rec, int fill, int *dx, int *dy, int *is_new)
+{
+  /* a fill does not depend on the line width: key it with a marker instead */
+  double lw = fill ? -1.0 : cairo_get_line_width (rec->cr);
+  int base_x = (int) floor (rec->ops[0].m.x0), base_y = (int) floor (rec->ops[0].m.y0);
+  uint8_t *key;
+  size_t key_len = stroke_key (rec, lw, base_x, base_y, &key);
+  uint64_t h = hash_bytes (key, key_len);
+  *is_new = 0;
+  for (uint32_t i = 0; i < rec->n_strokes; i++) {
+    StrokeEntry *e = &rec->strokes[i];
+    if (e->hash == h && e->key_len == key_len && memcmp (e->key, key, key_len) == 0 &&
+        (e->translatable || (e->base_x == base_x && e->base_y == base_y))) {
+      free (key);
+      *dx = base_x - e->base_x;
+      *dy = base_y - e->base_y;
+      return e;
+    }
+  }
+  if (rec->n_strokes == rec->cap_strokes) {
+    rec->cap_strokes = rec->cap_strokes ? rec->cap_strokes * 2 : 32;
+    rec->strokes = xrealloc (rec->strokes, rec->cap_strokes * sizeof (StrokeEntry));
+  }
+  StrokeEntry *e = &rec->strokes[rec->n_strokes++];
+  memset (e, 0, sizeof *e);
+  e->hash = h;
+  e->key = key;
+  e->key_len = key_len;
+  e->base_x = base_x;
+  e->base_y = base_y;
+  *dx = *dy = 0;
+  *is_new = 1;
+  return e;
+}
+
+static StrokeEntry *
+ops_get_mask (FlutlRecorder *rec, int fill, int *dx, int *dy)
+{
+  int is_new;
+  StrokeEntry *e = ops_find_mask (rec, fill, dx, dy, &is_new);
+  if (is_new)
+    e->translatable = stroke_rasterise (rec, e, fill);
+  return e;
+}
+
+static void
+ops_to_mask (FlutlRecorder *rec, int fill)
+{
+  int dx, dy;
+  StrokeEntry *e = ops_get_mask (rec, fill, &dx, &dy);
+  stroke_emit (rec, e, dx, dy);
+}
+
+/* Device rows an op's stroke can touch: its outline's bounding box under the
+ * op's matrix, grown by what the pen can reach (half the line width times
+ * Cairo's default miter limit of 10) and 2 px of antialiasing. */
+static int
+op_row_range (const PathOp *op, double reach, double *lo, double *hi)
+{
+  double x0, y0, x1, y1;
+  if (op->sfont)
+    return 0;
+  if (op->font) {
+    PangoRectangle ink;
+    pango_font_get_glyph_extents (op->font, op->gi.glyph, &ink, NULL);
+    x0 = (ink.x + op->gi.geometry.x_offset) / (double) PANGO_SCALE;
+    y0 = (ink.y + op->gi.geometry.y_offset) / (double) PANGO_SCALE;
+    x1 = x0 + ink.width / (double) PANGO_SCALE;
+    y1 = y0 + ink.height / (double) PANGO_SCALE;
+    /* hinted outlines may exceed the unhinted ink box by a pixel */
+    x0 -= 1.0; y0 -= 1.0; x1 += 1.0; y1 += 1.0;
+  } else {
+    x0 = op->x; y0 = op->y; x1 = op->x + op->w; y1 = op->y + op->h;
+  }
+  double ys[4] = { op->m.yx * x0 + op->m.yy * y0, op->m.yx * x1 + op->m.yy * y0,
+    op->m.yx * x0 + op->m.yy * y1, op->m.yx * x1 + op->m.yy * y1 };
+  *lo = *hi = ys[0];
+  for (int k = 1; k < 4; k++) {
+    if (ys[k] < *lo) *lo = ys[k];
+    if (ys[k] > *hi) *hi = ys[k];
+  }
+  *lo += op->m.y0 - reach;
+  *hi += op->m.y0 + reach;
+  return 1;
+}
+
+/* cairo_stroke / cairo_fill of the pending path.  A stroke whose contours fall
+ * into groups of DISJOINT device rows (the lines of a paragraph) is rasterised
+ * and cached group by group: a line that reappears in the next cue (roll-up
+ * captions, a changed second line) is then found in the cache.  This is exact
+ * because Cairo's coverage of a pixel row depends only on the edges in that
+ * row -- PROVIDED the groups' strokes really are row-disjoint, miter spikes
+ * included.  That is not predicted but checked on the rasterised masks (their
+ * covered rows, +-1); if they touch, the stroke is redone in one piece.  All
+ * masks of one stroke use the same blend rule (decided before the target is
+ * marked as painted). */
+static void
+path_to_mask (FlutlRecorder *rec, int fill)
+{
+  if (rec->n_ops == 0)
+    return;
+  if (rec->color_clear) {
+    path_ops_clear (rec);
+    return;
+  }
+  uint32_t n = rec->n_ops;
+  int split = !fill && n >= 2 && !rec->no_line_split;
+  double *lo = NULL, *hi = NULL;
+  uint32_t *grp = NULL;
+  uint32_t n_groups = 1;
+  if (split) {
+    /* tentative grouping: pen radius + antialiasing, no miter allowance */
+    const double reach = cairo_get_line_width (rec->cr) * 0.5 + 2.0;
+    lo = malloc (sizeof (double) * n * 2);
+    grp = malloc (sizeof (uint32_t) * n);
+    if (!lo || !grp)
+      abort ();
+    hi = lo + n;
+    for (uint32_t i = 0; i < n && split; i++)
+      split = op_row_range (&rec->ops[i], reach, &lo[i], &hi[i]);
+  }
+  if (split) {
+    /* connected components of overlapping row ranges (n is small: O(n^2)) */
+    for (uint32_t i = 0; i < n; i++)
+      grp[i] = i;
+    for (int changed = 1; changed;) {
+      changed = 0;
+      for (uint32_t i = 0; i < n; i++)
+        for (uint32_t j = i + 1; j < n; j++)
+          if (grp[i] != grp[j] && lo[i] <= hi[j] && lo[j] <= hi[i]) {
+            /* merge: both take the smaller label and the union of the ranges */
+            uint32_t a = grp[i] < grp[j] ? grp[i] : grp[j], b = grp[i] ^ grp[j] ^ a;
+            double l = lo[i] < lo[j] ? lo[i] : lo[j], h = hi[i] > hi[j] ? hi[i] : hi[j];
+            for (uint32_t k = 0; k < n; k++)
+              if (grp[k] == b || grp[k] == a) {
+                grp[k] = a;
+                if (lo[k] > l) lo[k] = l;
+                if (hi[k] < h) hi[k] = h;
+              }
+            changed = 1;
+          }
+    }
+    n_groups = 0;
+    for (uint32_t i = 0; i < n; i++)
+      if (grp[i] == i)
+        n_groups++;
+  }
+  if (n_groups <= 1) {
+    ops_to_mask (rec, fill);
+  } else {
+    /* stable partition by group label, then one mask per group */
+    PathOp *all = rec->ops, *sorted = malloc (sizeof (PathOp) * n);
+    uint32_t *idx = malloc (sizeof (uint32_t) * n_groups);   /* entry indices: the */
+    int *off = malloc (sizeof (int) * 2 * n_groups);         /* array may be moved  */
+    if (!sorted || !idx || !off)
+      abort ();
+    uint32_t pos = 0, k = 0;
+    /* pass 1: cache lookups; a miss gets its entry, its path (copied) and its
+     * box, but is not drawn yet */
+    StrokeEntry **miss = calloc (n_groups, sizeof *miss);
+    RasterBox *mbox = calloc (n_groups, sizeof *mbox);
+    cairo_path_t **mpath = calloc (n_groups, sizeof *mpath);
+    if (!miss || !mbox || !mpath)
+      abort ();
+    for (uint32_t g = 0; g < n; g++) {
+      if (grp[g] != g)
+        continue;
+      uint32_t first = pos;
+      for (uint32_t i = 0; i < n; i++)
+        if (grp[i] == g)
+          sorted[pos++] = all[i];
+      rec->ops = sorted + first;
+      rec->n_ops = pos - first;
+      int is_new = 0;
+      StrokeEntry *e = ops_find_mask (rec, fill, &off[2 * k], &off[2 * k + 1], &is_new);
+      idx[k] = (uint32_t) (e - rec->strokes);
+      if (is_new) {
+        raster_prepare (rec, fill, &mbox[k]);
+        e->w = e->h = 0;
+        e->translatable = mbox[k].inside;
+        if (mbox[k].bx1 > mbox[k].bx0 && mbox[k].by1 > mbox[k].by0) {
+          cairo_save (rec->cr);
+          cairo_identity_matrix (rec->cr);      /* copy in device coordinates */
+          mpath[k] = cairo_copy_path (rec->cr);
+          cairo_restore (rec->cr);
+          miss[k] = e;                          /* (index kept in idx[k]) */
+        }
+        cairo_new_path (rec->cr);
+      }
+      k++;
+    }
+    /* pass 2: draw the misses -- in parallel if their boxes (generous: Cairo's
+     * stroke extents include the miter allowance) are apart in rows, else one
+     * after the other on this thread */
+    {
+      uint32_t n_miss = 0;
+      int parallel = raster_thread_count () > 1;
+      for (uint32_t i = 0; i < n_groups; i++)
+        if (miss[i]) {
+          n_miss++;
+          for (uint32_t j = i + 1; j < n_groups; j++)
+            if (miss[j] && mbox[i].by0 < mbox[j].by1 && mbox[j].by0 < mbox[i].by1)
+              parallel = 0;
+          if (!mpath[i] || mpath[i]->status != CAIRO_STATUS_SUCCESS)
+            abort ();
+        }
+      if (n_miss) {
+        cairo_surface_flush (rec->scratch);
+        uint8_t *data = cairo_image_surface_get_data (rec->scratch);
+        int stride = cairo_image_surface_get_stride (rec->scratch);
+        GMutex lock;
+        GCond cond;
+        int pending = (int) n_miss;
+        LineJob *jobs = calloc (n_groups, sizeof *jobs);
+        if (!jobs)
+          abort ();
+        parallel = parallel && n_miss > 1;
+        g_mutex_init (&lock);
+        g_cond_init (&cond);
+        uint32_t last = 0;
+        for (uint32_t i = 0; i < n_groups; i++)
+          if (miss[i]) {
+            jobs[i] = (LineJob) { mpath[i], cairo_get_line_width (rec->cr), data, stride,
+              rec->width, mbox[i].by0, mbox[i].by1, parallel ? &lock : NULL, &cond, &pending };
+            last = i;
+          }
+        for (uint32_t i = 0; i < n_groups; i++)
+          if (miss[i]) {
+            if (parallel && i != last)
+              g_thread_pool_push (raster_pool, &jobs[i], NULL);
+            else
+              line_job_run (&jobs[i], NULL);    /* this thread takes one too */
+          }
+        if (parallel) {
+          g_mutex_lock (&lock);
+          while (pending > 0)
+            g_cond_wait (&cond, &lock);
+          g_mutex_unlock (&lock);
+        }
+        g_mutex_clear (&lock);
+        g_cond_clear (&cond);
+        free (jobs);
+        for (uint32_t i = 0; i < n_groups; i++)
+          if (miss[i]) {
+            cairo_surface_mark_dirty_rectangle (rec->scratch, 0, mbox[i].by0, rec->width,
+                mbox[i].by1 - mbox[i].by0);
+            raster_crop (rec, &rec->strokes[idx[i]], &mbox[i]);
+            cairo_path_destroy (mpath[i]);
+          }
+      }
+    }
+    free (miss);
+    free (mbox);
+    free (mpath);
+    memcpy (all, sorted, sizeof (PathOp) * n);    /* same refs, new order */
+    free (sorted);
+    rec->ops = all;
+    rec->n_ops = n;
+    /* the check: covered rows of the masks, one row of margin, pairwise apart */
+    int disjoint = 1;
+    for (uint32_t i = 0; i < n_groups && disjoint; i++)
+      for (uint32_t j = i + 1; j < n_groups && disjoint; j++) {
+        const StrokeEntry *a = &rec->strokes[idx[i]], *b = &rec->strokes[idx[j]];
+        if (a->w == 0 || b->w == 0)
+          continue;
+        int a0 = a->y + off[2 * i + 1] - 1, a1 = a->y + off[2 * i + 1] + a->h + 1;
+        int b0 = b->y + off[2 * j + 1] - 1, b1 = b->y + off[2 * j + 1] + b->h + 1;
+        if (a0 < b1 && b0 < a1)
+          disjoint = 0;
+      }
+    if (disjoint)
+      for (uint32_t i = 0; i < n_groups; i++)
+        stroke_emit (rec, &rec->strokes[idx[i]], off[2 * i], off[2 * i + 1]);
+    else
+      ops_to_mask (rec, fill);                    /* one piece, as drawn */
+    free (idx);
+    free (off);
+  }
+  free (lo);
+  free (grp);
+  target_touched (rec);
+  path_ops_clear (rec);
+}
 
 void
 flutl_recorder_stroke (FlutlRecorder *rec)
@@ -1093,50 +1480,6 @@ void
 flutl_recorder_fill (FlutlRecorder *rec)
 {
   path_to_mask (rec, 1);
-}
-
-static void
-path_to_mask (FlutlRecorder *rec, int fill)
-{
-  if (rec->n_ops == 0)
-    return;
-  if (rec->color_clear) {
-    path_ops_clear (rec);
-    return;
-  }
-  /* a fill does not depend on the line width: key it with a marker instead */
-  double lw = fill ? -1.0 : cairo_get_line_width (rec->cr);
-  int base_x = (int) floor (rec->ops[0].m.x0), base_y = (int) floor (rec->ops[0].m.y0);
-  uint8_t *key;
-  size_t key_len = stroke_key (rec, lw, base_x, base_y, &key);
-  uint64_t h = hash_bytes (key, key_len);
-  StrokeEntry *hit = NULL;
-  for (uint32_t i = 0; i < rec->n_strokes && !hit; i++) {
-    StrokeEntry *e = &rec->strokes[i];
-    if (e->hash == h && e->key_len == key_len && memcmp (e->key, key, key_len) == 0 &&
-        (e->translatable || (e->base_x == base_x && e->base_y == base_y)))
-      hit = e;
-  }
-  if (hit) {
-    free (key);
-    stroke_emit (rec, hit, base_x - hit->base_x, base_y - hit->base_y);
-  } else {
-    if (rec->n_strokes == rec->cap_strokes) {
-      rec->cap_strokes = rec->cap_strokes ? rec->cap_strokes * 2 : 32;
-      rec->strokes = xrealloc (rec->strokes, rec->cap_strokes * sizeof (StrokeEntry));
-    }
-    StrokeEntry *e = &rec->strokes[rec->n_strokes++];
-    memset (e, 0, sizeof *e);
-    e->hash = h;
-    e->key = key;
-    e->key_len = key_len;
-    e->base_x = base_x;
-    e->base_y = base_y;
-    e->translatable = stroke_rasterise (rec, e, fill);
-    stroke_emit (rec, e, 0, 0);
-  }
-  target_touched (rec);
-  path_ops_clear (rec);
 }
 
 /* ---- images ---------------------------------------------------------------- */
