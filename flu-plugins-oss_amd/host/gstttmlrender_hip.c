@@ -33,6 +33,8 @@
 #include <string.h>
 
 #include <gst/gst.h>
+#include <gst/video/video.h>
+#include <gst/video/video-overlay-composition.h>
 #include <pango/pangocairo.h>
 
 #include "gstttmlbase.h"
@@ -234,6 +236,10 @@ typedef struct
   gboolean ctx_failed;
   FlutlPackWriter *dump;     /* FLUTL_DUMP_PACK=<file>: scene-pack dump */
   gboolean dump_only;        /* FLUTL_DUMP_ONLY=1: record, do not render */
+  gboolean overlay_meta;     /* FLUTL_OVERLAY_COMPOSITION=1: also attach the frame as a
+                              * GstVideoOverlayCompositionMeta (the reference has none,
+                              * SURVEY D1/D2; an environment knob, not a property, so
+                              * that the element's property surface stays identical) */
   gboolean full_d2h;         /* FLUTL_FULL_D2H=1: whole-frame copies, writable memory */
   gboolean timing;           /* FLUTL_TIMING=1: host / device split on stderr at dispose */
   gint64 t_record, t_device;
@@ -1503,6 +1509,23 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
       return NULL;
     }
   }
+  if (priv->overlay_meta) {
+    /* the rectangle shares the frame's memory; ARGB in the composition's terms
+     * is B,G,R,A in memory on little endian, i.e. what the frame holds */
+    GstBuffer *pix = gst_buffer_copy_region (buffer, GST_BUFFER_COPY_MEMORY, 0, -1);
+    GstVideoOverlayRectangle *rect;
+    GstVideoOverlayComposition *comp;
+    gst_buffer_add_video_meta (pix, GST_VIDEO_FRAME_FLAG_NONE,
+        GST_VIDEO_OVERLAY_COMPOSITION_FORMAT_RGB, width, height);
+    rect = gst_video_overlay_rectangle_new_raw (pix, 0, 0, width, height,
+        GST_VIDEO_OVERLAY_FORMAT_FLAG_PREMULTIPLIED_ALPHA);
+    comp = gst_video_overlay_composition_new (rect);
+    gst_buffer_add_video_overlay_composition_meta (buffer, comp);
+    gst_video_overlay_composition_unref (comp);
+    gst_video_overlay_rectangle_unref (rect);
+    gst_buffer_unref (pix);
+    GST_LOG_OBJECT (render, "attached a %dx%d overlay composition", width, height);
+  }
   if (priv->timing) {
     gint64 t_end = g_get_monotonic_time ();
     priv->t_record += t_recorded - t_start;
@@ -1773,5 +1796,6 @@ gst_ttmlrender_init (GstTTMLRender *render)
   priv->dump_only = g_getenv ("FLUTL_DUMP_ONLY") != NULL;
   priv->timing = g_getenv ("FLUTL_TIMING") != NULL;
   priv->full_d2h = g_getenv ("FLUTL_FULL_D2H") != NULL;
+  priv->overlay_meta = g_getenv ("FLUTL_OVERLAY_COMPOSITION") != NULL;
   priv->no_layout_cache = g_getenv ("FLUTL_NO_LAYOUT_CACHE") != NULL;
 }

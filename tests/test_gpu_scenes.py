@@ -70,3 +70,17 @@ def test_element_end_to_end_in_a_gstreamer_pipeline(gpu, path):
     raw = gstenv.render(gstenv.HIP_PLUGIN_DIR, path[:-4] + ".ttml", W, H)
     got = np.frombuffer(raw, np.uint32).reshape(-1, H, W)
     assert np.array_equal(got, z["frames"])
+
+
+@pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
+                    reason="fluttml-hip plugin / GStreamer runtime not present")
+def test_element_overlay_composition_knob_keeps_the_frames(gpu):
+    """FLUTL_OVERLAY_COMPOSITION=1 attaches a GstVideoOverlayCompositionMeta (an
+    extension; the reference has none): the pushed frames must not change."""
+    path = SCENES[0]
+    z = np.load(path)
+    W, H = int(z["width"]), int(z["height"])
+    raw = gstenv.render(gstenv.HIP_PLUGIN_DIR, path[:-4] + ".ttml", W, H,
+                        extra_env={"FLUTL_OVERLAY_COMPOSITION": "1"})
+    got = np.frombuffer(raw, np.uint32).reshape(-1, H, W)
+    assert np.array_equal(got, z["frames"])
