@@ -236,6 +236,7 @@ typedef struct
   gboolean ctx_failed;
   FlutlPackWriter *dump;     /* FLUTL_DUMP_PACK=<file>: scene-pack dump */
   gboolean dump_only;        /* FLUTL_DUMP_ONLY=1: record, do not render */
+  gsize atlas_limit;         /* FLUTL_ATLAS_LIMIT_MB (default 256): see gen_buffer */
   gboolean overlay_meta;     /* FLUTL_OVERLAY_COMPOSITION=1: also attach the frame as a
                               * GstVideoOverlayCompositionMeta (the reference has none,
                               * SURVEY D1/D2; an environment knob, not a property, so
@@ -1120,6 +1121,26 @@ walk_layout (GstTTMLRender *render, FlutlRecorder *rec, PangoLayout *layout,
 static gboolean flush_atlas (GstTTMLRender *render);
 static gboolean ensure_ctx (GstTTMLRender *render);
 
+/* Glyph / outline / blurred-image masks, host copy and HBM: everything that is
+ * re-made on demand. */
+static void
+caches_drop (GstTTMLRender *render)
+{
+  GstTTMLRenderPrivate *priv = get_priv (render);
+  if (priv->rec)
+    flutl_recorder_reset (priv->rec);
+  if (priv->sub)
+    flutl_recorder_reset (priv->sub);
+  if (priv->blurred) {
+    g_hash_table_unref (priv->blurred);
+    priv->blurred = NULL;
+  }
+  if (priv->ctx) {
+    flutl_ctx_sync (priv->ctx);
+    flutl_atlas_reset (priv->ctx);
+  }
+}
+
 /* Blurred text outline (reference :1193-1229 + gstttmlblur.c): the outline is
  * stroked onto a cleared temporary ARGB32 surface, that surface is blurred,
  * and the result is blitted under the text.  Here: a child recorder records
@@ -1426,6 +1447,18 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
 
   /* ---- host: scene state -> display list -------------------------------- */
   t_start = priv->timing ? g_get_monotonic_time () : 0;
+  {
+    /* The mask caches live as long as the document (reset vfunc).  A live
+     * stream is one endless document with new text in every cue: bound the
+     * atlas by starting over (masks are re-made on demand) at a frame boundary. */
+    size_t atlas_bytes = 0;
+    (void) flutl_recorder_atlas (rec, &atlas_bytes);
+    if (atlas_bytes > priv->atlas_limit && !priv->dump) {   /* (a dump keeps one atlas) */
+      GST_INFO_OBJECT (render, "atlas at %" G_GSIZE_FORMAT " bytes: dropping the mask caches",
+          atlas_bytes);
+      caches_drop (render);
+    }
+  }
   flutl_recorder_begin_frame (rec, width, height);
   if (base->state.saved_region_attr_stacks) {
     gpointer ctx[2] = { render, &regions };
@@ -1638,7 +1671,7 @@ gst_ttmlrender_reset (GstTTMLBase *base)
 {
   GstTTMLRender *render = GST_TTMLRENDER (base);
   GstTTMLRenderPrivate *priv = get_priv (render);
-  /* per-document caches: decoded images, glyph/outline atlas (host + HBM) */
+  /* per-document caches: decoded images, layouts, glyph/outline atlas (host + HBM) */
   if (priv->images) {
     g_hash_table_unref (priv->images);
     priv->images = NULL;
@@ -1647,18 +1680,7 @@ gst_ttmlrender_reset (GstTTMLBase *base)
     g_hash_table_unref (priv->layouts);
     priv->layouts = NULL;
   }
-  if (priv->rec)
-    flutl_recorder_reset (priv->rec);
-  if (priv->sub)
-    flutl_recorder_reset (priv->sub);
-  if (priv->blurred) {
-    g_hash_table_unref (priv->blurred);
-    priv->blurred = NULL;
-  }
-  if (priv->ctx) {
-    flutl_ctx_sync (priv->ctx);
-    flutl_atlas_reset (priv->ctx);
-  }
+  caches_drop (render);
   if (priv->dump)
     flutl_pack_writer_flush (priv->dump);
 }
@@ -1796,6 +1818,10 @@ gst_ttmlrender_init (GstTTMLRender *render)
   priv->dump_only = g_getenv ("FLUTL_DUMP_ONLY") != NULL;
   priv->timing = g_getenv ("FLUTL_TIMING") != NULL;
   priv->full_d2h = g_getenv ("FLUTL_FULL_D2H") != NULL;
+  priv->atlas_limit = (gsize) (g_getenv ("FLUTL_ATLAS_LIMIT_MB")
+      ? MAX (1, atoi (g_getenv ("FLUTL_ATLAS_LIMIT_MB"))) : 256) << 20;
+  if (g_getenv ("FLUTL_ATLAS_LIMIT_BYTES"))     /* tests: force the start-over path */
+    priv->atlas_limit = (gsize) g_ascii_strtoull (g_getenv ("FLUTL_ATLAS_LIMIT_BYTES"), NULL, 10);
   priv->overlay_meta = g_getenv ("FLUTL_OVERLAY_COMPOSITION") != NULL;
   priv->no_layout_cache = g_getenv ("FLUTL_NO_LAYOUT_CACHE") != NULL;
 }

@@ -84,3 +84,18 @@ def test_element_overlay_composition_knob_keeps_the_frames(gpu):
                         extra_env={"FLUTL_OVERLAY_COMPOSITION": "1"})
     got = np.frombuffer(raw, np.uint32).reshape(-1, H, W)
     assert np.array_equal(got, z["frames"])
+
+
+@pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
+                    reason="fluttml-hip plugin / GStreamer runtime not present")
+@pytest.mark.parametrize("name", ["k06_animation", "k08_images", "g02_blur_fractional"])
+def test_element_survives_dropping_its_mask_caches(gpu, name):
+    """A live stream is one endless document: the element bounds its atlas by dropping
+    the mask caches at a frame boundary.  Forced here before every frame."""
+    path = [s for s in SCENES if name in s][0]
+    z = np.load(path)
+    W, H = int(z["width"]), int(z["height"])
+    raw = gstenv.render(gstenv.HIP_PLUGIN_DIR, path[:-4] + ".ttml", W, H,
+                        extra_env={"FLUTL_ATLAS_LIMIT_BYTES": "64"})
+    got = np.frombuffer(raw, np.uint32).reshape(-1, H, W)
+    assert np.array_equal(got, z["frames"])
