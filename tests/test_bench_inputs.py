@@ -1,0 +1,51 @@
+"""CPU checks of what bench.py feeds the GPU: every committed scene pack loads, validates
+against its atlas and has the geometry of its BASELINE config; the profiled-traffic lookup
+finds the committed rocprof summary of the default command."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "flu-plugins-oss_amd"))
+import pyflutl as F  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not os.path.exists(F.LIB_PATH),
+                                reason="libflutl.so not built (run __graft_entry__.build())")
+
+
+def _bench():
+    import importlib
+    return importlib.import_module("bench")
+
+
+@pytest.mark.parametrize("cfg,seed", [("cfg1_1080p_4regions", None), ("cfg2_2160p_8regions_outline", None),
+                                      ("cfg4_4320p_16regions", None)] +
+                         [("cfg2_2160p_8regions_outline", s) for s in range(20, 28)])
+def test_scene_packs_are_valid_display_lists(cfg, seed):
+    b = _bench()
+    W, H, states, atlas, source = b.load_states(cfg, 32, seed)
+    assert (W, H) == b.CONFIGS[cfg][:2]
+    assert source.endswith(".flpk.z"), source
+    if seed is not None:
+        assert f"seed{seed}" in source
+    assert len(states) >= 16
+    assert not atlas[:F.ATLAS_SLACK].any(), "the leading atlas slack must be zero"
+    nreg = b.CONFIGS[cfg][2]
+    for R, P in states:
+        assert F.validate(W, H, R, P, atlas.size) == 0
+        assert 1 <= len(R) <= nreg
+        assert len(P) > 0
+
+
+def test_profiled_traffic_of_the_default_command_is_committed():
+    b = _bench()
+    import inspect
+    default_batch = inspect.signature(b.main).parameters  # noqa: F841  (main takes no args)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    import re
+    batch = int(re.search(r'"--batch", type=int, default=(\d+)', src).group(1))
+    t = b.profiled_traffic("cfg2_2160p_8regions_outline", batch)
+    assert t is not None and t > batch * 3840 * 2160 * 4 * 0.99
