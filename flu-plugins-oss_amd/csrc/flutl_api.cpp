@@ -284,10 +284,11 @@ static int upload_list (flutl_ctx *c, const flutl_region *regions, uint32_t n_re
 extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
     const flutl_region *regions, uint32_t n_regions, const flutl_prim *prims,
     uint32_t n_prims, int radius, double sigma, uint32_t distx, uint32_t disty,
-    const int32_t *box, void *host_copy, uint32_t *offset_out)
+    const int32_t *box, int rotate_cw, void *host_copy, uint32_t *offset_out)
 {
   if (!c || !offset_out || w == 0 || h == 0 || w > 32766 || h > 32766 || radius < 0 ||
-      radius > 128 || distx > 127 || disty > 127)
+      radius > 128 || distx > 127 || disty > 127 ||
+      (rotate_cw && (distx || disty || box)))
     return FLUTL_EINVAL;
   int rc = flutl_list_validate (w, h, regions, n_regions, prims, n_prims,
       c->atlas_used + kAtlasSlack);
@@ -297,7 +298,10 @@ extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
   // a fractional blit position: the entry is the blurred surface resampled by
   // the constant bilinear weights, one pixel wider and higher
   const bool resample = distx != 0 || disty != 0 || box != nullptr;
-  const uint32_t ew = resample ? w + 1 : w, eh = resample ? h + 1 : h;
+  // the 90-degree CTM of the vertical writing modes: the entry is the blurred
+  // surface turned clockwise, h x w
+  const uint32_t ew = rotate_cw ? h : (resample ? w + 1 : w);
+  const uint32_t eh = rotate_cw ? w : (resample ? h + 1 : h);
   const size_t tight = (size_t) w * 4, bytes = tight * h;
   const size_t etight = (size_t) ew * 4, ebytes = etight * eh;
   // reserve the atlas entry first: growing the atlas moves it
@@ -309,7 +313,7 @@ extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
     return rc;
   // temporary surface (and, when resampling, the blurred one) in the
   // context's staging frame
-  const size_t need = resample ? 2 * bytes : bytes;
+  const size_t need = (resample || rotate_cw) ? 2 * bytes : bytes;
   if (need > c->frame_cap) {
     if (c->frame) {
       (void) hipStreamSynchronize (c->stream);
@@ -336,7 +340,8 @@ extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
   int32_t *wdev = nullptr;
   if (!hip_ok (hipMalloc (reinterpret_cast<void **> (&wdev), wbytes)))
     return FLUTL_ENOMEM;
-  uint8_t *blurred = resample ? static_cast<uint8_t *> (c->frame) + bytes : c->atlas + off;
+  uint8_t *blurred = (resample || rotate_cw)
+      ? static_cast<uint8_t *> (c->frame) + bytes : c->atlas + off;
   bool ok = hip_ok (hipMemcpyAsync (wdev, weights.data (), wbytes, hipMemcpyHostToDevice, c->stream));
   if (ok)
     ok = flutl_launch_blur (c->stream, c->frame, blurred, w, h, tight, wdev,
@@ -344,6 +349,9 @@ extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
   if (ok && resample)
     ok = flutl_launch_resample (c->stream, blurred, c->atlas + off, w, h, tight, etight,
         distx, disty, box) == FLUTL_OK;
+  if (ok && rotate_cw)
+    ok = flutl_launch_rotate_cw (c->stream, blurred, c->atlas + off, w, h, tight,
+        etight) == FLUTL_OK;
   if (ok && host_copy)
     ok = hip_ok (hipMemcpyAsync (host_copy, c->atlas + off, ebytes, hipMemcpyDeviceToHost,
         c->stream));

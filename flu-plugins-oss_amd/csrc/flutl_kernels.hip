@@ -936,6 +936,21 @@ __global__ __launch_bounds__ (256) void flutl_resample_kernel_dev (
   dst[(size_t) j * dst_stride_px + i] = r;
 }
 
+// Quarter turn clockwise of an ARGB32 image (w x h -> h x w): a surface painted
+// through the 90-degree CTM of the vertical writing modes (gstttmlrender.c:
+// 1313-1340) at an integer device position is sampled with the NEAREST filter,
+// i.e. it is a permutation of its pixels: dst (row i, column h-1-j) = src (j, i).
+__global__ __launch_bounds__ (256) void flutl_rotate_cw_kernel_dev (
+    const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int w, int h,
+    int src_stride_px, int dst_stride_px)
+{
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);   // dst column, < h
+  const int r = blockIdx.y * 4 + (threadIdx.x >> 6);    // dst row, < w
+  if (c >= h || r >= w)
+    return;
+  dst[(size_t) r * dst_stride_px + c] = src[(size_t) (h - 1 - c) * src_stride_px + r];
+}
+
 int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst,
     const void *video, size_t stride, const flutl_frame_desc *frames, uint32_t n_frames,
     uint32_t region_first, uint32_t region_count, const flutl_region *regions,
@@ -1071,5 +1086,19 @@ extern "C" int flutl_launch_resample (void *stream, const void *src, void *dst,
       static_cast<hipStream_t> (stream), static_cast<const uint32_t *> (src),
       static_cast<uint32_t *> (dst), (int) w, (int) h, (int) (src_stride_bytes / 4),
       (int) (dst_stride_bytes / 4), distx, disty, b);
+  return hipGetLastError () == hipSuccess ? FLUTL_OK : FLUTL_ENODEV;
+}
+
+extern "C" int flutl_launch_rotate_cw (void *stream, const void *src, void *dst,
+    uint32_t w, uint32_t h, size_t src_stride_bytes, size_t dst_stride_bytes)
+{
+  if (!src || !dst || w == 0 || h == 0 || w > 32767 || h > 32767 ||
+      (src_stride_bytes & 3) || (dst_stride_bytes & 3) ||
+      src_stride_bytes < (size_t) w * 4 || dst_stride_bytes < (size_t) h * 4)
+    return FLUTL_EINVAL;
+  hipLaunchKernelGGL (flutl_rotate_cw_kernel_dev, dim3 ((h + 63) / 64, (w + 3) / 4),
+      dim3 (256), 0, static_cast<hipStream_t> (stream), static_cast<const uint32_t *> (src),
+      static_cast<uint32_t *> (dst), (int) w, (int) h, (int) (src_stride_bytes / 4),
+      (int) (dst_stride_bytes / 4));
   return hipGetLastError () == hipSuccess ? FLUTL_OK : FLUTL_ENODEV;
 }

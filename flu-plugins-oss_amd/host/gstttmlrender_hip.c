@@ -21,8 +21,8 @@
  * the odd ones; each is marked "reference:" below.
  *
  * Not implemented yet (counted and logged, never silently approximated):
- * blurred outlines under a rotated CTM or with a blur above 64 px, unknown-glyph
- * boxes.
+ * blurred outlines at a fractional position in a vertical writing mode or with
+ * a blur above 64 px, unknown-glyph boxes.
  */
 #ifdef HAVE_CONFIG_H
 #include "config.h"
@@ -1166,21 +1166,41 @@ blurred_outline (GstTTMLRender *render, HipRegion *r, PangoLayout *layout, guint
   double sigma = r->outline.length[1].f;
   int tw, th, dst_x, dst_y;
   guint32 distx, disty;
-  gboolean fractional;
+  gboolean fractional, rotated;
   int32_t box[4] = { 0, 0, 0, 0 };
 
   pango_layout_get_pixel_extents (layout, NULL, &rect);
   tw = rect.width + 2 * br;
   th = rect.height + 2 * br;
   cairo_get_matrix (flutl_recorder_cairo (rec), &m);
-  if (m.xx != 1.0 || m.yy != 1.0 || m.xy != 0.0 || m.yx != 0.0 || radius > 128 ||
-      radius < 0 || !(sigma > 0.0) || tw <= 0 || th <= 0 || tw > 32766 || th > 32766 ||
-      fabs (m.x0) > 30000.0 || fabs (m.y0) > 30000.0) {
-    GST_FIXME_OBJECT (render, "blurred textOutline under a rotated CTM (vertical "
-        "writing modes), or with a blur length above 64 px, is not implemented; "
-        "outline of region '%s' not drawn", r->id);
+  /* the vertical writing modes paint through a quarter-turn CTM (:1313-1340;
+   * cos (pi/2) is 6e-17 there, not 0) */
+  rotated = fabs (m.xx) < 1e-9 && fabs (m.yy) < 1e-9 && m.xy == -1.0 && m.yx == 1.0;
+  if ((!rotated && (m.xx != 1.0 || m.yy != 1.0 || m.xy != 0.0 || m.yx != 0.0)) ||
+      radius > 128 || radius < 0 || !(sigma > 0.0) || tw <= 0 || th <= 0 || tw > 32766 ||
+      th > 32766 || fabs (m.x0) > 30000.0 || fabs (m.y0) > 30000.0) {
+    GST_FIXME_OBJECT (render, "blurred textOutline under this CTM, or with a blur length "
+        "above 64 px, is not implemented; outline of region '%s' not drawn", r->id);
     return;
   }
+  if (rotated) {
+    /* device (x, y) = (x0 - user_y, y0 + user_x): source pixel (i, j) of the
+     * surface set at user (px, py) lands on device pixel (x0 - py - j - 1,
+     * y0 + px + i).  At an integer position Cairo samples with NEAREST: the
+     * blit is the surface turned a quarter clockwise.  (A fractional position
+     * would be a bilinear resample along turned axes: not implemented.) */
+    const double X0 = m.x0 - (rect.y - br) - th, Y0 = m.y0 + (rect.x - br);
+    if (fabs (X0 - floor (X0 + 0.5)) > 1e-6 || fabs (Y0 - floor (Y0 + 0.5)) > 1e-6) {
+      GST_FIXME_OBJECT (render, "blurred textOutline at a fractional position in a "
+          "vertical writing mode is not implemented; outline of region '%s' not drawn",
+          r->id);
+      return;
+    }
+    dst_x = (int) floor (X0 + 0.5);
+    dst_y = (int) floor (Y0 + 0.5);
+    fractional = FALSE;
+    distx = disty = 0;
+  } else
   /* reference :1219-1224: the blurred surface is set as source at the INTEGER
    * user position (rect.x - br, rect.y - br) and a rectangle of its extent is
    * filled under the CTM.  If the CTM offset is fractional (e.g. displayAlign
@@ -1239,6 +1259,7 @@ blurred_outline (GstTTMLRender *render, HipRegion *r, PangoLayout *layout, guint
   g_checksum_update (sum, (const guchar *) &distx, sizeof distx);
   g_checksum_update (sum, (const guchar *) &disty, sizeof disty);
   g_checksum_update (sum, (const guchar *) box, sizeof box);
+  g_checksum_update (sum, (const guchar *) &rotated, sizeof rotated);
   key = g_strdup (g_checksum_get_string (sum));
   g_checksum_free (sum);
   if (!priv->blurred)
@@ -1248,7 +1269,8 @@ blurred_outline (GstTTMLRender *render, HipRegion *r, PangoLayout *layout, guint
     g_free (key);
   } else {
     guint32 dev_off = 0, host_off;
-    const int ew = tw + (fractional ? 1 : 0), eh = th + (fractional ? 1 : 0);
+    const int ew = rotated ? th : tw + (fractional ? 1 : 0);
+    const int eh = rotated ? tw : th + (fractional ? 1 : 0);
     guint8 *copy = g_malloc ((gsize) ew * eh * 4);
     int rc;
     if (!flush_atlas (render)) {          /* the sub list's masks must be in HBM */
@@ -1257,7 +1279,7 @@ blurred_outline (GstTTMLRender *render, HipRegion *r, PangoLayout *layout, guint
       return;
     }
     rc = flutl_atlas_put_blurred (priv->ctx, tw, th, rg, n_rg, pr, n_pr, radius, sigma,
-        distx, disty, fractional ? box : NULL, copy, &dev_off);
+        distx, disty, fractional ? box : NULL, rotated, copy, &dev_off);
     if (rc != FLUTL_OK) {
       GST_ERROR_OBJECT (render, "flutl_atlas_put_blurred: %s", flutl_strerror (rc));
       g_free (copy);

@@ -43,6 +43,7 @@ EXPORTS = [
     "flutl_list_validate", "flutl_launch_frame", "flutl_launch_batch",
     "flutl_launch_batch_over",
     "flutl_launch_blur", "flutl_blur_kernel", "flutl_launch_resample",
+    "flutl_launch_rotate_cw",
     "flutl_ctx_create", "flutl_ctx_destroy", "flutl_ctx_sync",
     "flutl_atlas_put", "flutl_atlas_reset", "flutl_atlas_size",
     "flutl_list_create", "flutl_list_destroy",
@@ -99,8 +100,9 @@ def lib():
         L.flutl_render_frame_rows_to_host.argtypes = [vp, u32, u32, vp, u32, vp, u32, vp, sz,
                                                       vp, u32]
         L.flutl_atlas_put_blurred.argtypes = [vp, u32, u32, vp, u32, vp, u32, ctypes.c_int,
-                                              ctypes.c_double, u32, u32, vp, vp,
-                                              ctypes.POINTER(u32)]
+                                              ctypes.c_double, u32, u32, vp, ctypes.c_int,
+                                              vp, ctypes.POINTER(u32)]
+        L.flutl_launch_rotate_cw.argtypes = [vp, vp, vp, u32, u32, sz, sz]
         L.flutl_launch_resample.argtypes = [vp, vp, vp, u32, u32, sz, sz, u32, u32, vp]
         L.flutl_host_alloc.argtypes = [sz, ctypes.POINTER(vp)]
         L.flutl_host_free.argtypes = [vp]
@@ -218,19 +220,19 @@ class Context:
         return off.value
 
     def atlas_put_blurred(self, w, h, regions, prims, radius, sigma, distx=0, disty=0,
-                          box=None):
+                          box=None, rotate_cw=False):
         """returns (atlas offset, host copy of the entry: the blurred w x h ARGB32
         image, or -- distx/disty != 0 -- its (h+1) x (w+1) bilinear resample)"""
         regions = np.ascontiguousarray(regions, REGION_DTYPE)
         prims = np.ascontiguousarray(prims, PRIM_DTYPE)
         grow = 1 if (distx or disty or box is not None) else 0
         b = None if box is None else np.ascontiguousarray(box, np.int32)
-        out = np.empty((h + grow, w + grow), np.uint32)
+        out = np.empty((w, h) if rotate_cw else (h + grow, w + grow), np.uint32)
         off = ctypes.c_uint32()
         _check(lib().flutl_atlas_put_blurred(
             self._h, w, h, _np_ptr(regions), len(regions), _np_ptr(prims), len(prims),
             radius, float(sigma), distx, disty, None if b is None else _np_ptr(b),
-            _np_ptr(out), ctypes.byref(off)),
+            1 if rotate_cw else 0, _np_ptr(out), ctypes.byref(off)),
             "flutl_atlas_put_blurred")
         return off.value, out
 

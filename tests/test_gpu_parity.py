@@ -320,3 +320,24 @@ def test_contexts_on_concurrent_threads(gpu):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_context_blurred_atlas_entries(gpu):
+    """flutl_atlas_put_blurred: sub-list composited on the device, pixman blur, then --
+    by the blit position -- as is, bilinear-resampled with edge coverage, or turned a
+    quarter clockwise (vertical writing modes); each against the oracle chain."""
+    W, H = 96, 40
+    R, P, A = scenes.random_scene(31, W, H, n_regions=3, prims_per_region=10)
+    surf = O.render(W, H, R, P, A)
+    radius, sigma = 3, 1.5
+    blurred = O.blur(surf, O.blur_kernel(radius, sigma), radius)
+    with F.Context(0) as ctx:
+        ctx.atlas_put(A[F.ATLAS_SLACK:])
+        off0, plain = ctx.atlas_put_blurred(W, H, R, P, radius, sigma)
+        assert np.array_equal(plain, blurred)
+        box = [128, 64, 128 + W * 256, 64 + H * 256]
+        off1, res = ctx.atlas_put_blurred(W, H, R, P, radius, sigma, distx=64, disty=96, box=box)
+        assert np.array_equal(res, O.resample(blurred, 64, 96, box))
+        off2, rot = ctx.atlas_put_blurred(W, H, R, P, radius, sigma, rotate_cw=True)
+        assert rot.shape == (W, H) and np.array_equal(rot, np.rot90(blurred, -1))
+        assert off0 < off1 < off2
