@@ -121,9 +121,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    # FLUTL_BENCH_REHEARSAL=1: walk the N>1 control flow on a box with fewer GPUs
+    # than ranks (all ranks share the visible devices, gloo instead of RCCL)
+    rehearsal = bool(os.environ.get("FLUTL_BENCH_REHEARSAL"))
+    if rehearsal:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus or world == 1
 
     # one independent stream per rank (weak scaling); no data-path collective
@@ -207,7 +215,7 @@ def main():
         step(args.warmup + s)
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = streams.max_over_ranks(elapsed, torch.device("cuda"))
+    elapsed = streams.max_over_ranks(elapsed, torch.device("cpu" if rehearsal else "cuda"))
 
     # ---- per-launch kernel duration (HIP events on the launch stream) ------
     kern_ms = None
