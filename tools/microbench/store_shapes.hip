@@ -70,6 +70,39 @@ static void run_var (const char *name, uint8_t *buf, int frames, int grid_waves)
   printf ("%-28s: %.2f us / frame, %.0f GB/s\n", name, ms * 1e3 / reps / frames, fb * (double) frames * reps / (ms * 1e-3) / 1e9);
 }
 
+// linear: a wave writes CHUNK contiguous bytes (memset-like); THREADS per workgroup
+template <int THREADS, int ITER>
+__global__ __launch_bounds__ (THREADS) void fill_linear (uint8_t *dst, size_t total)
+{
+  const size_t base = ((size_t) blockIdx.x * THREADS * ITER + threadIdx.x) * 16;
+  const u32x4 v = { 0u, 0u, 0u, 0u };
+#pragma unroll
+  for (int r = 0; r < ITER; r++) {
+    const size_t o = base + (size_t) r * THREADS * 16;
+    if (o < total)
+      __builtin_nontemporal_store (v, reinterpret_cast<u32x4 *> (dst + o));
+  }
+}
+
+template <int THREADS, int ITER>
+static void run_linear (const char *name, uint8_t *buf, int frames)
+{
+  const size_t total = (size_t) 3840 * 2160 * 4 * frames;
+  const unsigned grid = (unsigned) ((total / 16 + (size_t) THREADS * ITER - 1) / ((size_t) THREADS * ITER));
+  hipEvent_t a, b;
+  hipEventCreate (&a); hipEventCreate (&b);
+  for (int it = 0; it < 3; it++)
+    hipLaunchKernelGGL ((fill_linear<THREADS, ITER>), dim3 (grid), dim3 (THREADS), 0, 0, buf, total);
+  hipEventRecord (a);
+  const int reps = 20;
+  for (int it = 0; it < reps; it++)
+    hipLaunchKernelGGL ((fill_linear<THREADS, ITER>), dim3 (grid), dim3 (THREADS), 0, 0, buf, total);
+  hipEventRecord (b);
+  hipEventSynchronize (b);
+  float ms; hipEventElapsedTime (&ms, a, b);
+  printf ("%-28s: %.0f GB/s\n", name, total * (double) reps / (ms * 1e-3) / 1e9);
+}
+
 template <int LANES_X>
 static void run (const char *name, uint8_t *buf, int frames)
 {
@@ -104,6 +137,10 @@ int main ()
   run_var<1> ("64x16 nt, 8192 persistent", buf, frames, 8192);
   run_var<1> ("64x16 nt, 16384 persistent", buf, frames, 16384);
   run_var<2> ("64x16 plain, 8192 persistent", buf, frames, 8192);
+  run_linear<64, 4> ("linear 4 KB per wave", buf, frames);
+  run_linear<64, 16> ("linear 16 KB per wave", buf, frames);
+  run_linear<256, 4> ("linear 16 KB per 4-wave WG", buf, frames);
+  run_linear<256, 16> ("linear 64 KB per 4-wave WG", buf, frames);
   // plain memset for comparison
   hipEvent_t a, b; hipEventCreate (&a); hipEventCreate (&b);
   hipMemsetAsync (buf, 0, (size_t) 3840 * 2160 * 4 * frames, 0);
