@@ -287,8 +287,7 @@ extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
     const int32_t *box, int rotate_cw, void *host_copy, uint32_t *offset_out)
 {
   if (!c || !offset_out || w == 0 || h == 0 || w > 32766 || h > 32766 || radius < 0 ||
-      radius > 128 || distx > 127 || disty > 127 ||
-      (rotate_cw && (distx || disty || box)))
+      radius > 128 || distx > 127 || disty > 127)
     return FLUTL_EINVAL;
   int rc = flutl_list_validate (w, h, regions, n_regions, prims, n_prims,
       c->atlas_used + kAtlasSlack);
@@ -297,11 +296,15 @@ extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
   (void) hipSetDevice (c->device);
   // a fractional blit position: the entry is the blurred surface resampled by
   // the constant bilinear weights, one pixel wider and higher
+  // a fractional blit position: the entry is the blurred surface resampled by
+  // the constant bilinear weights, one pixel wider and higher, IN the box's
+  // edge coverage.  rotate_cw: the 90-degree CTM of the vertical writing
+  // modes; the entry is turned a quarter clockwise -- after the resample, which
+  // is then in the surface's own axes, and before the box, which is in device
+  // space.
   const bool resample = distx != 0 || disty != 0 || box != nullptr;
-  // the 90-degree CTM of the vertical writing modes: the entry is the blurred
-  // surface turned clockwise, h x w
-  const uint32_t ew = rotate_cw ? h : (resample ? w + 1 : w);
-  const uint32_t eh = rotate_cw ? w : (resample ? h + 1 : h);
+  const uint32_t rw = resample ? w + 1 : w, rh = resample ? h + 1 : h;   // before turning
+  const uint32_t ew = rotate_cw ? rh : rw, eh = rotate_cw ? rw : rh;
   const size_t tight = (size_t) w * 4, bytes = tight * h;
   const size_t etight = (size_t) ew * 4, ebytes = etight * eh;
   // reserve the atlas entry first: growing the atlas moves it
@@ -313,7 +316,11 @@ extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
     return rc;
   // temporary surface (and, when resampling, the blurred one) in the
   // context's staging frame
-  const size_t need = (resample || rotate_cw) ? 2 * bytes : bytes;
+  // staging: [0] the composited surface, [1] its blur, [0] again the resample
+  // when a turn follows (the composite is no longer needed then)
+  const size_t rbytes = (size_t) rw * 4 * rh;
+  const size_t need = (resample || rotate_cw) ? (rbytes > bytes ? rbytes : bytes) + bytes
+                                              : bytes;
   if (need > c->frame_cap) {
     if (c->frame) {
       (void) hipStreamSynchronize (c->stream);
@@ -340,18 +347,27 @@ extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
   int32_t *wdev = nullptr;
   if (!hip_ok (hipMalloc (reinterpret_cast<void **> (&wdev), wbytes)))
     return FLUTL_ENOMEM;
+  const size_t slot0 = rbytes > bytes ? rbytes : bytes;
   uint8_t *blurred = (resample || rotate_cw)
-      ? static_cast<uint8_t *> (c->frame) + bytes : c->atlas + off;
+      ? static_cast<uint8_t *> (c->frame) + slot0 : c->atlas + off;
   bool ok = hip_ok (hipMemcpyAsync (wdev, weights.data (), wbytes, hipMemcpyHostToDevice, c->stream));
   if (ok)
     ok = flutl_launch_blur (c->stream, c->frame, blurred, w, h, tight, wdev,
         radius) == FLUTL_OK;
-  if (ok && resample)
+  if (ok && resample && !rotate_cw)
     ok = flutl_launch_resample (c->stream, blurred, c->atlas + off, w, h, tight, etight,
         distx, disty, box) == FLUTL_OK;
-  if (ok && rotate_cw)
-    ok = flutl_launch_rotate_cw (c->stream, blurred, c->atlas + off, w, h, tight,
-        etight) == FLUTL_OK;
+  if (ok && rotate_cw) {
+    const uint8_t *turn_src = blurred;
+    if (resample) {         // resample (no box) into staging slot 0, then turn that
+      ok = flutl_launch_resample (c->stream, blurred, c->frame, w, h, tight, (size_t) rw * 4,
+          distx, disty, nullptr) == FLUTL_OK;
+      turn_src = static_cast<const uint8_t *> (c->frame);
+    }
+    if (ok)
+      ok = flutl_launch_rotate_cw (c->stream, turn_src, c->atlas + off, rw, rh,
+          (size_t) rw * 4, etight, box) == FLUTL_OK;
+  }
   if (ok && host_copy)
     ok = hip_ok (hipMemcpyAsync (host_copy, c->atlas + off, ebytes, hipMemcpyDeviceToHost,
         c->stream));

@@ -940,15 +940,28 @@ __global__ __launch_bounds__ (256) void flutl_resample_kernel_dev (
 // through the 90-degree CTM of the vertical writing modes (gstttmlrender.c:
 // 1313-1340) at an integer device position is sampled with the NEAREST filter,
 // i.e. it is a permutation of its pixels: dst (row i, column h-1-j) = src (j, i).
+// box: as in the resample kernel, the filled rectangle's edge coverage, here in
+// the coordinates of the TURNED image (fractional positions: the image was
+// resampled in its own space first, then turned, then clipped softly).
 __global__ __launch_bounds__ (256) void flutl_rotate_cw_kernel_dev (
     const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int w, int h,
-    int src_stride_px, int dst_stride_px)
+    int src_stride_px, int dst_stride_px, ResampleBox box)
 {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);   // dst column, < h
   const int r = blockIdx.y * 4 + (threadIdx.x >> 6);    // dst row, < w
   if (c >= h || r >= w)
     return;
-  dst[(size_t) r * dst_stride_px + c] = src[(size_t) (h - 1 - c) * src_stride_px + r];
+  uint32_t v = src[(size_t) (h - 1 - c) * src_stride_px + r];
+  if (box.enabled) {
+    const uint32_t cov = min ((uint32_t) (overlap256 (box.x1, box.x2, c) *
+        overlap256 (box.y1, box.y2, r)) >> 8, 255u);
+    Px q = unpack (v);
+    const u16x2 cc = splat (cov);
+    q.rb = mul_un8 (q.rb, cc);
+    q.ag = mul_un8 (q.ag, cc);
+    v = pack (q);
+  }
+  dst[(size_t) r * dst_stride_px + c] = v;
 }
 
 int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst,
@@ -1090,15 +1103,23 @@ extern "C" int flutl_launch_resample (void *stream, const void *src, void *dst,
 }
 
 extern "C" int flutl_launch_rotate_cw (void *stream, const void *src, void *dst,
-    uint32_t w, uint32_t h, size_t src_stride_bytes, size_t dst_stride_bytes)
+    uint32_t w, uint32_t h, size_t src_stride_bytes, size_t dst_stride_bytes,
+    const int32_t *box)
 {
   if (!src || !dst || w == 0 || h == 0 || w > 32767 || h > 32767 ||
       (src_stride_bytes & 3) || (dst_stride_bytes & 3) ||
       src_stride_bytes < (size_t) w * 4 || dst_stride_bytes < (size_t) h * 4)
     return FLUTL_EINVAL;
+  ResampleBox b = { 0, 0, 0, 0, 0 };
+  if (box) {
+    for (int k = 0; k < 4; k++)
+      if (box[k] < -(1 << 24) || box[k] > (1 << 24))
+        return FLUTL_EINVAL;
+    b = ResampleBox { box[0], box[1], box[2], box[3], 1 };
+  }
   hipLaunchKernelGGL (flutl_rotate_cw_kernel_dev, dim3 ((h + 63) / 64, (w + 3) / 4),
       dim3 (256), 0, static_cast<hipStream_t> (stream), static_cast<const uint32_t *> (src),
       static_cast<uint32_t *> (dst), (int) w, (int) h, (int) (src_stride_bytes / 4),
-      (int) (dst_stride_bytes / 4));
+      (int) (dst_stride_bytes / 4), b);
   return hipGetLastError () == hipSuccess ? FLUTL_OK : FLUTL_ENODEV;
 }

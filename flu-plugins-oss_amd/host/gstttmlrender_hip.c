@@ -21,8 +21,7 @@
  * the odd ones; each is marked "reference:" below.
  *
  * Not implemented yet (counted and logged, never silently approximated):
- * blurred outlines at a fractional position in a vertical writing mode or with
- * a blur above 64 px, unknown-glyph boxes.
+ * blurred outlines with a blur above 64 px, unknown-glyph boxes.
  */
 #ifdef HAVE_CONFIG_H
 #include "config.h"
@@ -1186,18 +1185,19 @@ blurred_outline (GstTTMLRender *render, HipRegion *r, PangoLayout *layout, guint
   if (rotated) {
     /* device (x, y) = (x0 - user_y, y0 + user_x): source pixel (i, j) of the
      * surface set at user (px, py) lands on device pixel (x0 - py - j - 1,
-     * y0 + px + i).  At an integer position Cairo samples with NEAREST: the
-     * blit is the surface turned a quarter clockwise.  (A fractional position
-     * would be a bilinear resample along turned axes: not implemented.) */
-    const double X0 = m.x0 - (rect.y - br) - th, Y0 = m.y0 + (rect.x - br);
-    if (fabs (X0 - floor (X0 + 0.5)) > 1e-6 || fabs (Y0 - floor (Y0 + 0.5)) > 1e-6) {
+     * y0 + px + i).  The position is an integer here -- the reference REPLACES
+     * the CTM for these modes (cairo_set_matrix, :1313-1327), which discards the
+     * only fractional translation there is (displayAlign center, :1303-1309) --
+     * so Cairo samples with NEAREST: the blit is the surface turned a quarter
+     * clockwise. */
+    const double U0 = m.y0 + (rect.x - br), V0 = m.x0 - (rect.y - br);
+    if (fabs (U0 - floor (U0 + 0.5)) > 1e-9 || fabs (V0 - floor (V0 + 0.5)) > 1e-9) {
       GST_FIXME_OBJECT (render, "blurred textOutline at a fractional position in a "
-          "vertical writing mode is not implemented; outline of region '%s' not drawn",
-          r->id);
+          "vertical writing mode; outline of region '%s' not drawn", r->id);
       return;
     }
-    dst_x = (int) floor (X0 + 0.5);
-    dst_y = (int) floor (Y0 + 0.5);
+    dst_x = (int) floor (V0 + 0.5) - th;
+    dst_y = (int) floor (U0 + 0.5);
     fractional = FALSE;
     distx = disty = 0;
   } else
@@ -1229,6 +1229,9 @@ blurred_outline (GstTTMLRender *render, HipRegion *r, PangoLayout *layout, guint
       distx = disty = 0;
     }
   }
+  GST_LOG_OBJECT (render, "blurred outline of region '%s': %dx%d surface%s%s, entry at "
+      "(%d, %d), weights %u/%u", r->id, tw, th, rotated ? ", quarter turn" : "",
+      fractional ? ", fractional position" : "", dst_x, dst_y, distx, disty);
   if (priv->dump_only || !ensure_ctx (render)) {
     GST_WARNING_OBJECT (render, "blurred outline needs the device; not drawn");
     return;
@@ -1269,8 +1272,8 @@ blurred_outline (GstTTMLRender *render, HipRegion *r, PangoLayout *layout, guint
     g_free (key);
   } else {
     guint32 dev_off = 0, host_off;
-    const int ew = rotated ? th : tw + (fractional ? 1 : 0);
-    const int eh = rotated ? tw : th + (fractional ? 1 : 0);
+    const int gw = tw + (fractional ? 1 : 0), gh = th + (fractional ? 1 : 0);
+    const int ew = rotated ? gh : gw, eh = rotated ? gw : gh;     /* (never both) */
     guint8 *copy = g_malloc ((gsize) ew * eh * 4);
     int rc;
     if (!flush_atlas (render)) {          /* the sub list's masks must be in HBM */

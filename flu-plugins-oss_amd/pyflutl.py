@@ -102,7 +102,7 @@ def lib():
         L.flutl_atlas_put_blurred.argtypes = [vp, u32, u32, vp, u32, vp, u32, ctypes.c_int,
                                               ctypes.c_double, u32, u32, vp, ctypes.c_int,
                                               vp, ctypes.POINTER(u32)]
-        L.flutl_launch_rotate_cw.argtypes = [vp, vp, vp, u32, u32, sz, sz]
+        L.flutl_launch_rotate_cw.argtypes = [vp, vp, vp, u32, u32, sz, sz, vp]
         L.flutl_launch_resample.argtypes = [vp, vp, vp, u32, u32, sz, sz, u32, u32, vp]
         L.flutl_host_alloc.argtypes = [sz, ctypes.POINTER(vp)]
         L.flutl_host_free.argtypes = [vp]
@@ -227,7 +227,7 @@ class Context:
         prims = np.ascontiguousarray(prims, PRIM_DTYPE)
         grow = 1 if (distx or disty or box is not None) else 0
         b = None if box is None else np.ascontiguousarray(box, np.int32)
-        out = np.empty((w, h) if rotate_cw else (h + grow, w + grow), np.uint32)
+        out = np.empty((w + grow, h + grow) if rotate_cw else (h + grow, w + grow), np.uint32)
         off = ctypes.c_uint32()
         _check(lib().flutl_atlas_put_blurred(
             self._h, w, h, _np_ptr(regions), len(regions), _np_ptr(prims), len(prims),

@@ -190,9 +190,11 @@ int flutl_launch_resample (void *stream, const void *src, void *dst,
 /* Quarter turn clockwise of an ARGB32 image, w x h -> h x w: what cairo_fill
  * of a surface pattern produces under the 90-degree CTM of the vertical
  * writing modes (gstttmlrender.c:1313-1340, NEAREST filter at integer
- * positions): dst (row i, column h-1-j) = src (row j, column i). */
+ * positions): dst (row i, column h-1-j) = src (row j, column i).  box: as for
+ * flutl_launch_resample, in the coordinates of dst, or NULL. */
 int flutl_launch_rotate_cw (void *stream, const void *src, void *dst,
-    uint32_t w, uint32_t h, size_t src_stride_bytes, size_t dst_stride_bytes);
+    uint32_t w, uint32_t h, size_t src_stride_bytes, size_t dst_stride_bytes,
+    const int32_t *box);
 
 /* ---- context API (library-owned HBM; what the GStreamer element uses) ---- */
 
@@ -227,8 +229,9 @@ size_t flutl_atlas_size (const flutl_ctx *ctx);
  * constant for a pure translation; the entry is then the blurred surface
  * resampled by them, (w+1) x (h+1), stride 4*(w+1), blitted at integer
  * coordinates (see flutl_launch_resample, also for `box`).  0, 0, NULL: the
- * blurred surface itself.  rotate_cw (only with 0, 0, NULL): the entry is the
- * blurred surface turned a quarter clockwise, h x w (flutl_launch_rotate_cw).
+ * blurred surface itself.  rotate_cw: the entry is turned a quarter clockwise
+ * (flutl_launch_rotate_cw) -- after the resample, whose weights are then along
+ * the surface's own axes, and `box` is in the turned (device) axes.
  * If host_copy is not NULL the entry's bytes are also copied there (for
  * scene-pack dumps).  radius <= 128. */
 int  flutl_atlas_put_blurred (flutl_ctx *ctx, uint32_t w, uint32_t h,

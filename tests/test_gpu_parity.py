@@ -341,3 +341,15 @@ def test_context_blurred_atlas_entries(gpu):
         off2, rot = ctx.atlas_put_blurred(W, H, R, P, radius, sigma, rotate_cw=True)
         assert rot.shape == (W, H) and np.array_equal(rot, np.rot90(blurred, -1))
         assert off0 < off1 < off2
+        # resample, turn, then the box's edge coverage in the turned axes
+        tbox = [100, 300, 100 + (H + 1) * 256 - 150, 300 + (W + 1) * 256 - 500]
+        _, both = ctx.atlas_put_blurred(W, H, R, P, radius, sigma, distx=17, disty=120,
+                                        box=tbox, rotate_cw=True)
+        turned = np.rot90(O.resample(blurred, 17, 120), -1)
+        ys, xs = np.mgrid[0:turned.shape[0], 0:turned.shape[1]]
+        ov = lambda lo, hi, p: np.clip(np.minimum(hi, p * 256 + 256) - np.maximum(lo, p * 256),
+                                       0, None)
+        cov = np.minimum((ov(tbox[0], tbox[2], xs) * ov(tbox[1], tbox[3], ys)) >> 8, 255)
+        exp = O.group(np.ascontiguousarray(turned).reshape(-1), cov.astype(np.uint32).reshape(-1),
+                      np.zeros(turned.size, np.uint32)).reshape(turned.shape)
+        assert both.shape == (W + 1, H + 1) and np.array_equal(both, exp)
