@@ -68,10 +68,12 @@ typedef struct
   uint64_t hash;
   uint8_t *key;
   size_t key_len;
-  int base_x, base_y;        /* integer base the key is relative to */
-  int translatable;
+  int base_x, base_y;        /* integer base the key is relative to, raster coordinates */
+  int translatable;          /* made clear of its limits: valid at any integer
+                              * translation that stays clear of the limits there */
+  int lim[4];                /* the limits it was made under (device box) */
   uint32_t offset;           /* atlas offset of the tight A8 mask */
-  int x, y, w, h;            /* device box of the mask at (base_x, base_y) */
+  int x, y, w, h;            /* box of the mask at (base_x, base_y), raster coordinates */
 } StrokeEntry;
 
 struct FlutlRecorder
@@ -79,7 +81,7 @@ struct FlutlRecorder
   FlutlRecorder *parent;      /* child recorders put their masks in the parent's atlas */
   int width, height;
   cairo_surface_t *scratch;   /* A8, width x height */
-  int no_line_split;          /* FLUTL_NO_LINE_SPLIT=1: one mask per stroke, as drawn */
+  int line_split;             /* FLUTL_LINE_SPLIT=1: see path_to_mask (NOT exact) */
   cairo_t *cr;
 
   flutl_prim *prims;
@@ -117,6 +119,7 @@ struct FlutlRecorder
 };
 
 static void path_ops_clear (FlutlRecorder *rec);
+static void raster_origin (const FlutlRecorder *rec, int *ox, int *oy);
 
 /* ---- small helpers --------------------------------------------------------- */
 
@@ -320,7 +323,7 @@ flutl_recorder_new (void)
   if (!rec)
     abort ();
   rec->atlas_size = ATLAS_SLACK;
-  rec->no_line_split = g_getenv ("FLUTL_NO_LINE_SPLIT") != NULL;
+  rec->line_split = g_getenv ("FLUTL_LINE_SPLIT") != NULL;
   return rec;
 }
 
@@ -548,7 +551,12 @@ flutl_recorder_group_end (FlutlRecorder *rec, double opacity)
   p->cy0 = (int16_t) y0;
   p->cx1 = (int16_t) x1;
   p->cy1 = (int16_t) y1;
-  rec->frame_clear = 0;
+  /* cairo_paint_with_alpha returns before touching the surface if the alpha
+   * is "zero" (CAIRO_ALPHA_IS_ZERO: <= 0x00ff / 0xffff): the frame then still
+   * counts as clear for the next antialiased operation (found by
+   * tools/fuzz_ttml.py); the composite itself is a no-op either way */
+  if (!(opacity <= (double) 0x00ff / (double) 0xffff))
+    rec->frame_clear = 0;
 }
 
 void
@@ -953,7 +961,9 @@ stroke_emit (FlutlRecorder *rec, const StrokeEntry *e, int dx, int dy)
 {
   if (e->w == 0)
     return;
-  int ox = e->x + dx, oy = e->y + dy;
+  int gx, gy;
+  raster_origin (rec, &gx, &gy);
+  int ox = e->x + dx + gx, oy = e->y + dy + gy;
   int x0 = ox, y0 = oy, x1 = ox + e->w, y1 = oy + e->h;
   if (!clip_box (rec, &x0, &y0, &x1, &y1))
     return;
@@ -985,18 +995,80 @@ stroke_emit (FlutlRecorder *rec, const StrokeEntry *e, int dx, int dy)
 typedef struct
 {
   int bx0, by0, bx1, by1;       /* box to look at; empty: nothing to draw */
-  int inside;
+  int inside;                   /* the path stays clear of the limits */
+  int lim[4];                   /* limits: frame, clip and group surface */
 } RasterBox;
+
+/* What bounds a stroke in the reference: the surface it draws on (the frame,
+ * or the region's temporary surface when it has an opacity) and the region's
+ * clip rectangle.  Cairo hands this box to the polygon as "limits", and an
+ * edge that crosses a limit is cut there with rounded coordinates -- which
+ * moves coverages by +-1 here and there ALONG that edge, not only at the
+ * border (found by tools/fuzz_ttml.py).  So a path is rasterised under exactly
+ * these limits, and its mask is position independent only if it stays clear
+ * of them. */
+/* Paths are rasterised in the coordinates the reference strokes them in: the
+ * frame's, or -- inside an opacity group -- those of the region's temporary
+ * surface (gstttmlrender.c:1250-1255: cairo_translate (-originx, -originy)).
+ * This matters: Cairo's coverage is exact under integer translations in x but
+ * NOT in y (+-1 at a few pixels, irregularly: measured with one line of 17 px
+ * text at 40 vertical positions, 2 variants of its outline mask), so a moved
+ * group keeps its mask, and a mask is otherwise only reused at the same y. */
+static void
+raster_origin (const FlutlRecorder *rec, int *ox, int *oy)
+{
+  *ox = rec->in_group ? rec->group[0] : 0;
+  *oy = rec->in_group ? rec->group[1] : 0;
+}
+
+static void
+current_limits (FlutlRecorder *rec, int lim[4])
+{
+  int ox, oy;
+  raster_origin (rec, &ox, &oy);
+  if (rec->in_group) {
+    /* the region's temporary surface, which may reach beyond the frame: the
+     * frame only cuts the finished group, pixel by pixel */
+    lim[0] = rec->group[0];
+    lim[1] = rec->group[1];
+    lim[2] = rec->group[2];
+    lim[3] = rec->group[3];
+  } else {
+    lim[0] = 0;
+    lim[1] = 0;
+    lim[2] = rec->width;
+    lim[3] = rec->height;
+  }
+  if (rec->has_clip) {
+    lim[0] = imax (lim[0], rec->clip[0]);
+    lim[1] = imax (lim[1], rec->clip[1]);
+    lim[2] = imin (lim[2], rec->clip[2]);
+    lim[3] = imin (lim[3], rec->clip[3]);
+  }
+  if (lim[2] < lim[0])
+    lim[2] = lim[0];
+  if (lim[3] < lim[1])
+    lim[3] = lim[1];
+  lim[0] -= ox;                 /* in raster coordinates */
+  lim[2] -= ox;
+  lim[1] -= oy;
+  lim[3] -= oy;
+}
 
 static void
 raster_prepare (FlutlRecorder *rec, int fill, RasterBox *rb)
 {
   cairo_t *cr = rec->cr;
+  int ox, oy;
+  raster_origin (rec, &ox, &oy);
   cairo_new_path (cr);
   for (uint32_t i = 0; i < rec->n_ops; i++) {
     const PathOp *op = &rec->ops[i];
+    cairo_matrix_t m = op->m;
+    m.x0 -= ox;                 /* raster coordinates */
+    m.y0 -= oy;
     cairo_save (cr);
-    cairo_set_matrix (cr, &op->m);
+    cairo_set_matrix (cr, &m);
     if (op->sfont) {
       cairo_glyph_t g = { op->sglyph, 0, 0 };
       cairo_scale (cr, op->hscale, 1.0);
@@ -1019,11 +1091,13 @@ raster_prepare (FlutlRecorder *rec, int fill, RasterBox *rb)
   else
     cairo_stroke_extents (cr, &ex1, &ey1, &ex2, &ey2);
   cairo_restore (cr);
-  rb->inside = ex1 >= 3 && ey1 >= 3 && ex2 <= rec->width - 3 && ey2 <= rec->height - 3;
-  rb->bx0 = imax ((int) floor (ex1) - 2, 0);
-  rb->by0 = imax ((int) floor (ey1) - 2, 0);
-  rb->bx1 = imin ((int) ceil (ex2) + 2, rec->width);
-  rb->by1 = imin ((int) ceil (ey2) + 2, rec->height);
+  current_limits (rec, rb->lim);
+  rb->inside = ex1 >= rb->lim[0] + 3 && ey1 >= rb->lim[1] + 3 && ex2 <= rb->lim[2] - 3 &&
+      ey2 <= rb->lim[3] - 3;
+  rb->bx0 = imax (imax ((int) floor (ex1) - 2, rb->lim[0]), 0);
+  rb->by0 = imax (imax ((int) floor (ey1) - 2, rb->lim[1]), 0);
+  rb->bx1 = imin (imin ((int) ceil (ex2) + 2, rb->lim[2]), rec->width);
+  rb->by1 = imin (imin ((int) ceil (ey2) + 2, rb->lim[3]), rec->height);
 }
 
 static void
@@ -1103,11 +1177,23 @@ stroke_rasterise (FlutlRecorder *rec, StrokeEntry *e, int fill)
   /* coverage = what the stroker + scan converter hand to the span renderer */
   cairo_save (cr);
   cairo_set_source_rgba (cr, 1, 1, 1, 1);
+  if (!rb.inside) {             /* under the reference's limits, see current_limits */
+    cairo_path_t *pth = cairo_copy_path (cr);
+    cairo_new_path (cr);
+    cairo_save (cr);
+    cairo_identity_matrix (cr);
+    cairo_rectangle (cr, rb.lim[0], rb.lim[1], rb.lim[2] - rb.lim[0], rb.lim[3] - rb.lim[1]);
+    cairo_restore (cr);
+    cairo_clip (cr);
+    cairo_append_path (cr, pth);
+    cairo_path_destroy (pth);
+  }
   if (fill)
     cairo_fill (cr);
   else
     cairo_stroke (cr);
   cairo_restore (cr);
+  memcpy (e->lim, rb.lim, sizeof e->lim);
   raster_crop (rec, e, &rb);
   return rb.inside;
 }
@@ -1124,6 +1210,8 @@ typedef struct
   uint8_t *data;
   int stride, width;
   int y0, y1;
+  int clip;                      /* rasterise under lim (the path crosses it) */
+  int lim[4];
   GMutex *lock;
   GCond *cond;
   int *pending;
@@ -1142,6 +1230,10 @@ line_job_run (gpointer data, gpointer user_data)
       j->data, CAIRO_FORMAT_A8, j->width, j->y1, j->stride);
   cairo_t *cr;
   cr = cairo_create (s);
+  if (j->clip) {
+    cairo_rectangle (cr, j->lim[0], j->lim[1], j->lim[2] - j->lim[0], j->lim[3] - j->lim[1]);
+    cairo_clip (cr);
+  }
   cairo_append_path (cr, j->path);
   cairo_set_source_rgba (cr, 1, 1, 1, 1);
   cairo_set_line_width (cr, j->line_width);
@@ -1188,19 +1280,33 @@ ops_find_mask (FlutlRecorder *rec, int fill, int *dx, int *dy, int *is_new)
 {
   /* a fill does not depend on the line width: key it with a marker instead */
   double lw = fill ? -1.0 : cairo_get_line_width (rec->cr);
-  int base_x = (int) floor (rec->ops[0].m.x0), base_y = (int) floor (rec->ops[0].m.y0);
+  int ox, oy;
+  raster_origin (rec, &ox, &oy);
+  /* base in raster coordinates (the key itself only holds offsets from it) */
+  int base_x = (int) floor (rec->ops[0].m.x0) - ox, base_y = (int) floor (rec->ops[0].m.y0) - oy;
   uint8_t *key;
-  size_t key_len = stroke_key (rec, lw, base_x, base_y, &key);
+  size_t key_len = stroke_key (rec, lw, base_x + ox, base_y + oy, &key);
   uint64_t h = hash_bytes (key, key_len);
   *is_new = 0;
   for (uint32_t i = 0; i < rec->n_strokes; i++) {
     StrokeEntry *e = &rec->strokes[i];
-    if (e->hash == h && e->key_len == key_len && memcmp (e->key, key, key_len) == 0 &&
-        (e->translatable || (e->base_x == base_x && e->base_y == base_y))) {
-      free (key);
-      *dx = base_x - e->base_x;
-      *dy = base_y - e->base_y;
-      return e;
+    if (e->hash == h && e->key_len == key_len && memcmp (e->key, key, key_len) == 0) {
+      const int tx = base_x - e->base_x, ty = base_y - e->base_y;
+      /* A mask made clear of its limits is the stroke at any integer
+       * translation that stays clear of the limits in force there; one that
+       * crosses them is only good at the same place under the same limits. */
+      int lim[4];
+      current_limits (rec, lim);
+      const int same = tx == 0 && ty == 0 && memcmp (lim, e->lim, sizeof lim) == 0;
+      const int clear = e->w == 0 ||
+          (e->x + tx >= lim[0] + 2 && e->y + ty >= lim[1] + 2 &&
+           e->x + tx + e->w <= lim[2] - 2 && e->y + ty + e->h <= lim[3] - 2);
+      if (same || (e->translatable && clear && ty == 0)) {
+        free (key);
+        *dx = tx;
+        *dy = ty;
+        return e;
+      }
     }
   }
   if (rec->n_strokes == rec->cap_strokes) {
@@ -1270,16 +1376,16 @@ op_row_range (const PathOp *op, double reach, double *lo, double *hi)
   return 1;
 }
 
-/* cairo_stroke / cairo_fill of the pending path.  A stroke whose contours fall
- * into groups of DISJOINT device rows (the lines of a paragraph) is rasterised
- * and cached group by group: a line that reappears in the next cue (roll-up
- * captions, a changed second line) is then found in the cache.  This is exact
- * because Cairo's coverage of a pixel row depends only on the edges in that
- * row -- PROVIDED the groups' strokes really are row-disjoint, miter spikes
- * included.  That is not predicted but checked on the rasterised masks (their
- * covered rows, +-1); if they touch, the stroke is redone in one piece.  All
- * masks of one stroke use the same blend rule (decided before the target is
- * marked as painted). */
+/* cairo_stroke / cairo_fill of the pending path: one mask, as drawn.
+ *
+ * FLUTL_LINE_SPLIT=1 (off by default, an experiment kept for the record): a
+ * stroke whose contours fall into groups of disjoint device rows (the lines
+ * of a paragraph) is rasterised and cached group by group, the cache misses
+ * on worker threads -- 1.5x on streams with new outlined text in every cue.
+ * It is NOT exact: tools/fuzz_ttml.py found a strike-through rectangle whose
+ * edge rows come out a few units different when it is stroked without the
+ * glyphs that the reference has pending in the same cairo_stroke, six rows
+ * above it.  Cairo's scan converter is not row-local after all. */
 static void
 path_to_mask (FlutlRecorder *rec, int fill)
 {
@@ -1290,7 +1396,7 @@ path_to_mask (FlutlRecorder *rec, int fill)
     return;
   }
   uint32_t n = rec->n_ops;
-  int split = !fill && n >= 2 && !rec->no_line_split;
+  int split = !fill && n >= 2 && rec->line_split;
   double *lo = NULL, *hi = NULL;
   uint32_t *grp = NULL;
   uint32_t n_groups = 1;
@@ -1364,6 +1470,7 @@ path_to_mask (FlutlRecorder *rec, int fill)
         raster_prepare (rec, fill, &mbox[k]);
         e->w = e->h = 0;
         e->translatable = mbox[k].inside;
+        memcpy (e->lim, mbox[k].lim, sizeof e->lim);
         if (mbox[k].bx1 > mbox[k].bx0 && mbox[k].by1 > mbox[k].by0) {
           cairo_save (rec->cr);
           cairo_identity_matrix (rec->cr);      /* copy in device coordinates */
@@ -1407,7 +1514,9 @@ path_to_mask (FlutlRecorder *rec, int fill)
         for (uint32_t i = 0; i < n_groups; i++)
           if (miss[i]) {
             jobs[i] = (LineJob) { mpath[i], cairo_get_line_width (rec->cr), data, stride,
-              rec->width, mbox[i].by0, mbox[i].by1, parallel ? &lock : NULL, &cond, &pending };
+              rec->width, mbox[i].by0, mbox[i].by1, !mbox[i].inside,
+              { mbox[i].lim[0], mbox[i].lim[1], mbox[i].lim[2], mbox[i].lim[3] },
+              parallel ? &lock : NULL, &cond, &pending };
             last = i;
           }
         for (uint32_t i = 0; i < n_groups; i++)

@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the whole path: random TTML documents are rendered by the
+REFERENCE plugin and recorded by the fluttml-hip element (record-only, CPU) + composited
+by the oracle; every frame must be bit-identical.  Builder container (needs oracle/_ref).
+
+    python tools/fuzz_ttml.py [first_seed [count]]
+"""
+import os
+import random
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import compare_ref  # noqa: E402
+
+WORDS = ("subtitle overlay Glyph MAVERICK jumpy quiz, fix & go; Why? 12:45 öäü naïve "
+         "Test_under line ÆØ x y z").split()
+FAMS = ["DejaVu Sans", "DejaVu Serif", "DejaVu Sans Mono", "sansSerif", "serif", "monospace",
+        "default"]
+
+
+def col(r, alpha=None):
+    a = alpha if alpha is not None else r.choice([255, 255, 255, 192, 128, 64, 0])
+    return "#%02X%02X%02X%02X" % (r.randrange(256), r.randrange(256), r.randrange(256), a)
+
+
+def length(r, lo, hi, units=("px", "px", "%", "c", "em")):
+    u = r.choice(units)
+    v = r.uniform(lo, hi)
+    if u == "%":
+        return "%.1f%%" % (v / 3.2)
+    if u == "c":
+        return "%.2fc" % (v / 10.0)
+    if u == "em":
+        return "%.2fem" % (v / 16.0)
+    return ("%d" % v if r.random() < 0.7 else "%.2f" % v) + "px"
+
+
+def span_style(r):
+    s = []
+    if r.random() < 0.5:
+        s.append(f'tts:color="{col(r)}"')
+    if r.random() < 0.25:
+        s.append(f'tts:backgroundColor="{col(r)}"')
+    if r.random() < 0.3:
+        s.append(f'tts:fontSize="{r.randrange(10, 34)}px"')
+    if r.random() < 0.1:
+        s.append(f'tts:fontSize="{r.randrange(10, 30)}px {r.randrange(10, 30)}px"')
+    if r.random() < 0.25:
+        s.append('tts:fontStyle="%s"' % r.choice(["italic", "oblique", "reverseOblique", "normal"]))
+    if r.random() < 0.25:
+        s.append('tts:fontWeight="%s"' % r.choice(["bold", "normal"]))
+    if r.random() < 0.3:
+        s.append('tts:textDecoration="%s"' % r.choice(
+            ["underline", "lineThrough", "overline", "underline overline", "noUnderline",
+             "underline lineThrough overline"]))
+    if r.random() < 0.2:
+        s.append(f'tts:fontFamily="{r.choice(FAMS)}"')
+    if r.random() < 0.08:
+        s.append('tts:visibility="hidden"')
+    if r.random() < 0.08:
+        s.append('tts:unicodeBidi="bidiOverride" tts:direction="rtl"')
+    seen, out = set(), []
+    for a in " ".join(s).split(" tts:"):         # no attribute twice: XML would be invalid
+        name = a.split("=")[0].replace("tts:", "")
+        if a and name not in seen:
+            seen.add(name)
+            out.append(a if a.startswith("tts:") else "tts:" + a)
+    return " ".join(out)
+
+
+def text(r, n):
+    return " ".join(r.choice(WORDS) for _ in range(n)).replace("&", "&amp;")
+
+
+def gen(seed):
+    r = random.Random(seed)
+    regions, ps = [], []
+    for i in range(r.randrange(1, 5)):
+        x, y = r.randrange(0, 200), r.randrange(0, 110)
+        w, h = r.randrange(60, 320 - x + 40), r.randrange(30, 180 - y + 30)
+        a = [f'xml:id="r{i}"', f'tts:origin="{x}px {y}px"', f'tts:extent="{w}px {h}px"']
+        if r.random() < 0.7:
+            a.append(f'tts:backgroundColor="{col(r)}"')
+        if r.random() < 0.4:
+            a.append('tts:opacity="%.2f"' % r.choice([0.0, 0.25, 0.5, 0.81, 1.0, r.random()]))
+        if r.random() < 0.5:
+            a.append('tts:displayAlign="%s"' % r.choice(["before", "center", "after"]))
+        if r.random() < 0.5:
+            a.append('tts:textAlign="%s"' % r.choice(["left", "center", "right", "start", "end"]))
+        if r.random() < 0.35:
+            n = r.choice([1, 2, 4])
+            a.append('tts:padding="%s"' % " ".join(length(r, 0, 12, ("px", "px", "%")) for _ in range(n)))
+        if r.random() < 0.4:
+            a.append('tts:textOutline="%s %s"' % (r.choice(["black", col(r, 255), col(r)]),
+                                                   r.choice(["1px", "2px", "1.5px", "3px", "0.5px"])))
+        if r.random() < 0.25:
+            a.append(f'tts:zIndex="{r.randrange(-3, 4)}"')
+        if r.random() < 0.15:
+            a.append('tts:writingMode="%s"' % r.choice(["tbrl", "tblr", "rltb", "lrtb", "tb", "rl"]))
+        if r.random() < 0.2:
+            a.append('tts:wrapOption="%s"' % r.choice(["wrap", "noWrap"]))
+        if r.random() < 0.2:
+            a.append('tts:overflow="%s"' % r.choice(["visible", "hidden"]))
+        if r.random() < 0.2:
+            a.append('tts:showBackground="%s"' % r.choice(["always", "whenActive"]))
+        if r.random() < 0.25:
+            a.append('tts:lineHeight="%s"' % r.choice(["normal", "20px", "30px", "125%", "1.5c"]))
+        sets = ""
+        if r.random() < 0.3:
+            attr = r.choice(["tts:backgroundColor", "tts:opacity", "tts:origin", "tts:color"])
+            for k in range(r.randrange(1, 3)):
+                v = {"tts:backgroundColor": col(r), "tts:opacity": "%.2f" % r.random(),
+                     "tts:origin": f"{r.randrange(0, 200)}px {r.randrange(0, 100)}px",
+                     "tts:color": col(r)}[attr]
+                sets += f'<set begin="{0.5 + k * 0.5:.1f}s" end="{1.0 + k * 0.5:.1f}s" {attr}="{v}"/>'
+        regions.append("  <region " + " ".join(a) + (f">{sets}</region>" if sets else "/>"))
+        for k in range(r.randrange(0, 3)):
+            t0 = r.choice([0, 0, 0.5, 1.0])
+            t1 = t0 + r.choice([0.5, 1.0, 2.0])
+            body = ""
+            for _ in range(r.randrange(1, 4)):
+                if r.random() < 0.5:
+                    body += f'<span {span_style(r)}>{text(r, r.randrange(1, 4))}</span> '
+                else:
+                    body += text(r, r.randrange(1, 4)) + " "
+                if r.random() < 0.2:
+                    body += "<br/>"
+            st = span_style(r)
+            if "tts:fontSize" not in st:
+                st += f' tts:fontSize="{r.randrange(12, 30)}px"'
+            ps.append(f'  <p region="r{i}" begin="{t0}s" end="{t1}s" {st}>{body}</p>')
+    # The reference reads an uninitialised pointer when a paragraph holds BOTH an
+    # anamorphic font size and text that breaks its Pango markup (a raw '&':
+    # pango_parse_markup fails and leaves pango_attr_list unset,
+    # gstttmlrender.c:769-771); what follows is undefined, also for later frames.
+    import re
+    if re.search(r'tts:fontSize="[0-9.]+px [0-9.]+px"', "".join(ps)):
+        ps = [p.replace("&amp;", "and") for p in ps]
+    cell = ' ttp:cellResolution="32 15"' if r.random() < 0.5 else ""
+    return f'''<?xml version="1.0" encoding="UTF-8"?>
+<tt xmlns="http://www.w3.org/ns/ttml" xmlns:tts="http://www.w3.org/ns/ttml#styling" xmlns:ttp="http://www.w3.org/ns/ttml#parameter" xml:lang="en"{cell}>
+ <head><layout>
+{chr(10).join(regions)}
+ </layout></head>
+ <body><div>
+{chr(10).join(ps)}
+ </div></body>
+</tt>
+'''
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+    bad = []
+    for seed in range(first, first + count):
+        doc = gen(seed)
+        with tempfile.NamedTemporaryFile("w", suffix=".ttml", delete=False) as f:
+            f.write(doc)
+        try:
+            ok, ref, pk = compare_ref.compare(f.name, 320, 180, verbose=False)
+            note = f"{len(ref)} frames"
+        except Exception as e:      # noqa: BLE001
+            ok, note = None, "ERROR " + repr(e)[:200]
+        print(f"seed {seed}: {'ok' if ok else ('MISMATCH' if ok is False else 'error')} ({note})",
+              flush=True)
+        if not ok:
+            bad.append(seed)
+            keep = os.path.join(tempfile.gettempdir(), f"fuzz_{seed}.ttml")
+            os.replace(f.name, keep)
+            print("   kept", keep)
+        else:
+            os.unlink(f.name)
+    print("failing seeds:", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
