@@ -109,6 +109,7 @@ struct FlutlRecorder
 
   int has_clip, clip[4];      /* x0,y0,x1,y1 */
   int in_group, group[4];
+  int shift[2];                 /* frame = CTM coordinates + shift (integers) */
   int frame_clear, group_clear;
 
   double rgba[4];
@@ -463,6 +464,22 @@ flutl_recorder_region_begin (FlutlRecorder *rec)
 {
   rec->region_first = rec->n_prims;
   rec->in_region = 1;
+  rec->shift[0] = rec->shift[1] = 0;
+}
+
+/* From here to the end of the region, what the CTM of the tracking context
+ * maps to lies (dx, dy) whole pixels from its place in the frame.  The
+ * reference's vertical writing modes inside an opacity group need this: there
+ * the CTM is the bare quarter turn on the region's temporary surface, whose
+ * cos (pi/2) = 6e-17 leaves device positions a few ulp off the halves they
+ * would be exactly -- so "CTM + origin, then round" and "round, then + origin"
+ * place a glyph one pixel apart.  The shift is added after rounding, where the
+ * reference's paint of the temporary surface adds it. */
+void
+flutl_recorder_set_device_shift (FlutlRecorder *rec, int dx, int dy)
+{
+  rec->shift[0] = dx;
+  rec->shift[1] = dy;
 }
 
 void
@@ -644,6 +661,10 @@ flutl_recorder_fill_rect (FlutlRecorder *rec, double x, double y, double w, doub
   }
   int32_t fx1 = p0x < p2x ? p0x : p2x, fx2 = p0x < p2x ? p2x : p0x;
   int32_t fy1 = p0y < p2y ? p0y : p2y, fy2 = p0y < p2y ? p2y : p0y;
+  fx1 += rec->shift[0] * 256;
+  fx2 += rec->shift[0] * 256;
+  fy1 += rec->shift[1] * 256;
+  fy2 += rec->shift[1] * 256;
   if (fx1 == fx2 || fy1 == fy2)
     return;
   int x0 = fx1 >> 8, y0 = fy1 >> 8, x1 = (fx2 + 255) >> 8, y1 = (fy2 + 255) >> 8;
@@ -824,7 +845,8 @@ flutl_recorder_show_glyph (FlutlRecorder *rec, PangoFont *font,
   } else {
     cairo_matrix_transform_point (&m, &cx, &cy);
   }
-  int ix = (int) floor (cx + 0.5), iy = (int) floor (cy + 0.5);
+  int ix = (int) floor (cx + 0.5) + rec->shift[0];
+  int iy = (int) floor (cy + 0.5) + rec->shift[1];
   GlyphEntry *e = glyph_lookup (rec, sf, gi->glyph, &m);
   target_touched (rec);
   if (e->w == 0)
@@ -1062,11 +1084,17 @@ raster_prepare (FlutlRecorder *rec, int fill, RasterBox *rb)
   int ox, oy;
   raster_origin (rec, &ox, &oy);
   cairo_new_path (cr);
+  /* CTM coordinates -> raster coordinates; nothing to do (and no rounding of
+   * m.x0) where the CTM already is the reference's own */
+  ox -= rec->shift[0];
+  oy -= rec->shift[1];
   for (uint32_t i = 0; i < rec->n_ops; i++) {
     const PathOp *op = &rec->ops[i];
     cairo_matrix_t m = op->m;
-    m.x0 -= ox;                 /* raster coordinates */
-    m.y0 -= oy;
+    if (ox)
+      m.x0 -= ox;
+    if (oy)
+      m.y0 -= oy;
     cairo_save (cr);
     cairo_set_matrix (cr, &m);
     if (op->sfont) {
@@ -1282,6 +1310,8 @@ ops_find_mask (FlutlRecorder *rec, int fill, int *dx, int *dy, int *is_new)
   double lw = fill ? -1.0 : cairo_get_line_width (rec->cr);
   int ox, oy;
   raster_origin (rec, &ox, &oy);
+  ox -= rec->shift[0];
+  oy -= rec->shift[1];
   /* base in raster coordinates (the key itself only holds offsets from it) */
   int base_x = (int) floor (rec->ops[0].m.x0) - ox, base_y = (int) floor (rec->ops[0].m.y0) - oy;
   uint8_t *key;

@@ -40,6 +40,7 @@ cairo_t *flutl_recorder_cairo (FlutlRecorder *rec);
 
 /* One TTML region == one binning group of the display list. */
 void flutl_recorder_region_begin (FlutlRecorder *rec);
+void flutl_recorder_set_device_shift (FlutlRecorder *rec, int dx, int dy);
 void flutl_recorder_region_end (FlutlRecorder *rec);
 
 /* Opacity group = the temporary region surface of :1250-1256 / :1375-1382.

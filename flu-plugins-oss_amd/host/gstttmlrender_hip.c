@@ -1382,18 +1382,19 @@ record_region (HipRegion *r, GstTTMLRender *render)
     cairo_matrix_init_rotate (&om, G_PI / 2);
     cairo_matrix_translate (&om, r->pox,
         r->writing_mode == GST_TTML_WRITING_MODE_TBRL ? -r->pex : -r->poy);
-    if (grouped) {
-      /* reference: with an opacity the region is drawn on a temporary surface
-       * under cairo_translate (-origin) (:1250-1255) -- which this
-       * cairo_set_matrix discards as well: the text lands on that surface at
-       * its FRAME coordinates, i.e. moved by the region's origin once more */
-      om.x0 += r->ox;
-      om.y0 += r->oy;
-    }
     cairo_set_matrix (cr, &om);
     pango_context_set_base_gravity (render->pango_context, PANGO_GRAVITY_EAST);
     pango_context_set_gravity_hint (render->pango_context, PANGO_GRAVITY_HINT_STRONG);
     pango_cairo_update_context (cr, render->pango_context);
+    if (grouped) {
+      /* reference: with an opacity the region is drawn on a temporary surface
+       * under cairo_translate (-origin) (:1250-1255) -- which this
+       * cairo_set_matrix discards as well: the text lands on that surface at
+       * its FRAME coordinates, i.e. moved by the region's origin once more.
+       * The CTM stays the reference's; the recorder adds the origin to what
+       * it has rounded, as the paint of the temporary surface does. */
+      flutl_recorder_set_device_shift (rec, (int) r->ox, (int) r->oy);
+    }
   }
   {
     for (l = r->layouts; l; l = l->next) {
