@@ -151,8 +151,6 @@ constexpr int kSuperW = FLUTL_TILE_W;        // 64
 #endif
 constexpr int kRG = FLUTL_KRG;               // row groups per wave
 constexpr int kSuperH = 4 * kRG;             // kRG strips of 4 rows
-constexpr uint32_t kStInterior = 1u << 24;   // see `st` in the kernel
-static_assert (kRG <= 8, "strip masks are 8 bits wide");
 
 // A primitive held wave-uniformly in SGPRs.  During binning every lane holds
 // one candidate primitive (32 bytes = 8 VGPRs); a hit is broadcast to the
@@ -289,56 +287,6 @@ __device__ __forceinline__ void strip_blend (Px (&t)[4], Px s, uint32_t w)
   }
 }
 
-// The blend of a whole primitive is chosen ONCE (kernel: BLEND_STRIPS), not per
-// strip: the scalar unit, one per CU, is as scarce here as the vector units.
-//   kBlendOpaque  every LERP, and PIXMAN with an opaque colour: both are
-//                 s * m + t * (255 - m) with each product rounded on its own;
-//                 only the rounding constant differs (0x7f cairo / 0x80 pixman),
-//                 passed in `rnd` (alpha (s IN m) == m exactly when alpha (s) == 255);
-//   kBlendBlack   the same for opaque black (the usual outline): s * m is
-//                 {0, 0, 0, m} without a multiplication;
-//   kBlendPixman  PIXMAN with a translucent colour: t * (255 - alpha (s IN m)).
-enum { kBlendOpaque = 0, kBlendBlack = 1, kBlendPixman = 2 };
-
-__device__ __forceinline__ u16x2 mul_rnd (u16x2 x, u16x2 a, u16x2 rnd)
-{
-  u16x2 t = x * a + rnd;
-  return (t + (t >> 8)) >> 8;
-}
-
-template <int V, int K>
-__device__ __forceinline__ void px_blend (Px &t, Px s, uint32_t w, u16x2 rnd)
-{
-  if (V == kBlendPixman) {
-    px_pixman<false, K> (t, s, w);
-    return;
-  }
-  const u16x2 mm = splat_byte<K> (w);
-  const u16x2 im = as_u16x2 (as_u32 (mm) ^ 0x00ff00ffu);
-  if (V == kBlendBlack) {
-    t.rb = mul_rnd (t.rb, im, rnd);
-    t.ag = as_u16x2 (as_u32 (mm) & 0xffff0000u) + mul_rnd (t.ag, im, rnd);
-  } else {
-    t.rb = mul_rnd (s.rb, mm, rnd) + mul_rnd (t.rb, im, rnd);
-    t.ag = mul_rnd (s.ag, mm, rnd) + mul_rnd (t.ag, im, rnd);
-  }
-}
-
-template <int V>
-__device__ __forceinline__ void strip_blend_v (uint4 &v, Px s, uint32_t w, u16x2 rnd)
-{
-#if FLUTL_EXP == 1   // ablation: no blend arithmetic
-  v.x ^= w;
-  return;
-#endif
-  Px t[4] = { unpack (v.x), unpack (v.y), unpack (v.z), unpack (v.w) };
-  px_blend<V, 0> (t[0], s, w, rnd);
-  px_blend<V, 1> (t[1], s, w, rnd);
-  px_blend<V, 2> (t[2], s, w, rnd);
-  px_blend<V, 3> (t[3], s, w, rnd);
-  v = make_uint4 (pack (t[0]), pack (t[1]), pack (t[2]), pack (t[3]));
-}
-
 // The A8 coverage bytes of a MASK primitive for this lane's 4 pixels in each
 // of its kRG strips (rows y0 + 4r).  Issued one primitive ahead of use: OVER
 // is order dependent, the loads are not.  Select free: lanes that the prim
@@ -412,9 +360,9 @@ __device__ __forceinline__ int clamp_scalar (int v, int hi)
   return min (a, hi);
 }
 
-__device__ __forceinline__ uint32_t strip_range (int lo, int hi, int nmax)
+__device__ __forceinline__ uint32_t strip_range (int lo, int hi)
 {
-  const int a = clamp_scalar (lo >> 2, nmax), b = clamp_scalar (hi >> 2, nmax);
+  const int a = clamp_scalar (lo >> 2, kRG), b = clamp_scalar (hi >> 2, kRG);
   return b > a ? ((1u << b) - 1u) & ~((1u << a) - 1u) : 0u;
 }
 
@@ -424,37 +372,27 @@ __device__ __forceinline__ uint32_t strip_range (int lo, int hi, int nmax)
 // edge from this lane's first pixel: pixels outside the frame are never
 // stored, nor read back.  The read-back is by the lane that stored, at the
 // same address, later in program order: no fence is needed for that.
-template <bool EDGES>
 __device__ __forceinline__ void park_store (uint8_t *o, uint4 v, bool whole, int nx, int ny)
 {
   if (whole) {
     *reinterpret_cast<uint4 *> (o) = v;
     return;
   }
-  uint32_t *q = reinterpret_cast<uint32_t *> (o);
-  const uint32_t e[4] = { v.x, v.y, v.z, v.w };
-  if (!EDGES) {         // only the alignment is missing
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      q[k] = e[k];
-    return;
-  }
   if (ny <= 0)
     return;
+  uint32_t *q = reinterpret_cast<uint32_t *> (o);
+  const uint32_t e[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
   for (int k = 0; k < 4; k++)
     if (k < nx)
       q[k] = e[k];
 }
 
-template <bool EDGES>
 __device__ __forceinline__ uint4 park_load (const uint8_t *o, bool whole, int nx, int ny)
 {
   if (whole)
     return *reinterpret_cast<const uint4 *> (o);
   const uint32_t *q = reinterpret_cast<const uint32_t *> (o);
-  if (!EDGES)
-    return make_uint4 (q[0], q[1], q[2], q[3]);
   uint32_t e[4] = { 0u, 0u, 0u, 0u };
   if (ny > 0) {
 #pragma unroll
@@ -488,27 +426,6 @@ __device__ __forceinline__ void strip_apply (uint4 &v, const PrimU &p, uint32_t 
   v = make_uint4 (pack (t[0]), pack (t[1]), pack (t[2]), pack (t[3]));
 }
 
-__device__ __forceinline__ uint4 splat4 (uint32_t c)
-{
-  return make_uint4 (c, c, c, c);
-}
-
-// pixman arithmetic on wave-uniform colours: done once on the vector unit
-// (there is no scalar packed arithmetic) and handed back to an SGPR
-__device__ __forceinline__ uint32_t uniform_in (uint32_t c, u16x2 al)
-{
-  Px sp = unpack (c);
-  sp.rb = mul_un8 (sp.rb, al);
-  sp.ag = mul_un8 (sp.ag, al);
-  return (uint32_t) __builtin_amdgcn_readfirstlane ((int) pack (sp));
-}
-__device__ __forceinline__ uint32_t uniform_over (uint32_t d, uint32_t s)
-{
-  Px v = unpack (d);
-  over (v, unpack (s));
-  return (uint32_t) __builtin_amdgcn_readfirstlane ((int) pack (v));
-}
-
 // At least 6 waves per SIMD (4 KB of LDS per wave allows 8): measured 5 -> 6
 // waves +4 %, 6 = 7 = 8 -- and at 8 the 96-SGPR budget makes the compiler
 // spill scalars into VGPR lanes, +60 VALU per wave on a VALU-bound kernel.
@@ -519,15 +436,7 @@ __device__ __forceinline__ uint32_t uniform_over (uint32_t d, uint32_t s)
 // frame (same geometry as dst) in the store epilogue -- the "blend over the
 // video buffer" of the north star, fused so that the overlay never exists in
 // memory.  Separate instantiation: the plain overlay path pays nothing.
-// EDGES: supertiles may be cut by the right or bottom border of the frame at any
-// pixel.  The instantiation without is for frames whose width is a multiple of
-// 64 and whose height is a multiple of 4 (every broadcast format from 720p up):
-// a supertile then ends on a whole strip, which is a wave-uniform fact, and no
-// lane-divergent branch is left inside the replay loop -- which matters beyond
-// the branches themselves: with one in it, the compiler "structurises" the
-// whole loop body and turns its (wave-uniform) dispatch into flag juggling on
-// the scalar unit.
-template <bool VIDEO, bool EDGES>
+template <bool VIDEO>
 __attribute__ ((amdgpu_waves_per_eu (FLUTL_WAVES)))
 __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
     FrameParams fp, uint8_t *__restrict__ dst, const uint8_t *__restrict__ video,
@@ -588,49 +497,17 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
   const int x_lane = sx0 + (lane & 15) * 4;
   const int y_lane = sy0 + (lane >> 4);         // row in strip 0; strip r: + 4r
 
-  // Wave-uniform bookkeeping, packed into ONE scalar register `st` (the kernel
-  // sits at the 102-SGPR limit of the architecture; a spilled scalar costs a
-  // v_writelane in every wave):
-  //   bits  0.. 7  "touched":  strip r of the current surface holds pixels in LDS;
-  //   bits  8..15  "solid":    strip r is one uniform colour `base` all over
-  //                (never together with touched): a background box that covers
-  //                the strip.  Such a strip costs scalar bookkeeping only -- no
-  //                LDS write, no LDS read, and a box under an opacity group is
-  //                faded once per supertile, not per pixel -- until something
-  //                with coverage lands on it;
-  //   bits 16..23  "touched_frame": strips of the FRAME that held pixels when
-  //                the current opacity group began;
-  //   bit  24      the whole supertile is inside the frame and its rows are
-  //                16-byte aligned ("interior").
-  // A strip that is neither touched nor solid is transparent and is neither
+  // Wave-uniform bookkeeping (SGPRs): which strips of the current surface
+  // hold pixels (bit r); an untouched strip is transparent and is neither
   // initialised nor read.
-  uint32_t base = 0;
-  uint32_t st = ((!EDGES || (sx0 + kSuperW <= (int) fp.width && sy0 + kSuperH <= (int) fp.height)) &&
+  uint32_t touched = 0, touched_frame = 0;
+  // the whole supertile is inside the frame and its rows are 16-byte aligned
+  const bool interior = sx0 + kSuperW <= (int) fp.width && sy0 + kSuperH <= (int) fp.height &&
       ((reinterpret_cast<uintptr_t> (dst) | (VIDEO ? reinterpret_cast<uintptr_t> (video) : 0) |
-          dst_off | fp.stride) & 15u) == 0) ? kStInterior : 0u;   // scalar
-  // strips of this supertile that exist (!EDGES: the rest lies below the frame
-  // and is never touched; EDGES: pixels are tested one by one where it matters)
-  const int nstr = EDGES ? kRG : min (kRG, ((int) fp.height - sy0) >> 2);
+          dst_off | fp.stride) & 15u) == 0;   // scalar
 
-#define ST_TOUCHED      (st & 0xffu)
-#define ST_SOLID        ((st >> 8) & 0xffu)
-#define ST_T(r)         ((st >> (r)) & 1u)
-#define ST_S(r)         ((st >> (8 + (r))) & 1u)
-#define ST_INTERIOR     ((st & kStInterior) != 0u)
-#define STRIP_UNIFORM(r) (ST_S (r) ? base : 0u)        /* scalar */
-#define STRIP_LOAD(r)  (ST_T (r) ? s_surf[r][lane] : splat4 (STRIP_UNIFORM (r)))
-#define STRIP_STORE(r, v) do { s_surf[r][lane] = (v); \
-    st = (st | (1u << (r))) & ~(0x100u << (r)); } while (0)
-  // the strips of mask m become the uniform colour c (one `base` per supertile:
-  // a second colour, e.g. where two regions meet inside it, goes to LDS)
-#define STRIPS_SET_UNIFORM(m, c) do { \
-    const uint32_t m_ = (m), c_ = (c); \
-    if ((ST_SOLID & ~m_) == 0u || base == c_) { \
-      base = c_; st = (st | (m_ << 8)) & ~m_; \
-    } else { \
-      _Pragma ("unroll") for (int r_ = 0; r_ < kRG; r_++) \
-        if ((m_ >> r_) & 1u) STRIP_STORE (r_, splat4 (c_)); \
-    } } while (0)
+#define STRIP_LOAD(r)  ((touched >> (r)) & 1u ? s_surf[r][lane] : make_uint4 (0u, 0u, 0u, 0u))
+#define STRIP_STORE(r, v) do { s_surf[r][lane] = (v); touched |= 1u << (r); } while (0)
 
   // this lane's pixels of strip r in the destination frame (x, y0 = the lane's
   // first pixel of strip 0; recomputed where needed, not kept in registers)
@@ -655,7 +532,7 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
       rmask &= rmask - 1;
       const uint32_t pfirst = rdl (rv.z, rl), pcount = rdl (rv.w, rl);
 #if FLUTL_EXP == 4    // ablation: region cull only
-      base ^= pfirst + pcount;
+      touched ^= pfirst + pcount;
       continue;
 #endif
 
@@ -673,7 +550,7 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
         if (!hits)
           continue;
 #if FLUTL_EXP == 5    // ablation: prim chunk load + bbox test only
-        base ^= (uint32_t) hits ^ rdl (hi.x, 0);
+        touched ^= (uint32_t) hits ^ rdl (hi.x, 0);
         continue;
 #endif
 
@@ -696,91 +573,39 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
             fnxt = mask_fetch4 (prim_decode (nxt), atlas, x, y0);
           }
 #if FLUTL_EXP == 6    // ablation: replay loop without the op bodies
-          base ^= p.color ^ rdl (f.w[0] ^ f.w[1] ^ f.w[2] ^ f.w[3], 0);
+          touched ^= p.color ^ rdl (f.w[0] ^ f.w[1] ^ f.w[2] ^ f.w[3], 0);
           if (!more)
             break;
           continue;
 #endif
 
-#if FLUTL_EXP == 7      // ablations: one kind of op body removed
-          const bool skip_op = p.op == FLUTL_OP_GROUP_END || p.op == FLUTL_OP_IMAGE;
-#elif FLUTL_EXP == 8
-          const bool skip_op = p.op == FLUTL_OP_RECT;
-#elif FLUTL_EXP == 9
-          const bool skip_op = p.op == FLUTL_OP_MASK;
-#else
-          const bool skip_op = false;
-#endif
-          if (skip_op) {
-            base ^= (p.color ^ rdl (f.w[0] ^ f.w[1] ^ f.w[2] ^ f.w[3], 0)) & 1u;
-          } else if (p.op == FLUTL_OP_MASK || p.op == FLUTL_OP_RECT) {
+          if (p.op == FLUTL_OP_MASK || p.op == FLUTL_OP_RECT) {
             // ---- solid colour through 8-bit coverage: an A8 mask, or the
             //      24.8 box of cairo's rectangular scan converter -------------
-            // strips the clipped bbox touches: a bit mask made once per
-            // primitive with scalar ops
-            uint32_t smask = strip_range (p.cy0 - sy0, p.cy1 - sy0 + 3, nstr);
+            // strips the clipped bbox touches, and (RECT) strips the box covers
+            // completely: bit masks made once per primitive with scalar ops
+            const uint32_t smask = strip_range (p.cy0 - sy0, p.cy1 - sy0 + 3);
+            uint32_t fmask = 0u;
             uint32_t w[kRG];
             if (p.op == FLUTL_OP_RECT) {
-              // strips the box covers completely (coverage 255 all over)
-              uint32_t fmask = 0u;
               if (((p.a + 255) >> 8) <= sx0 && (p.c >> 8) >= sx0 + kSuperW &&
                   p.cx0 <= sx0 && p.cx1 >= sx0 + kSuperW)
                 fmask = strip_range (max ((p.b + 255) >> 8, p.cy0) - sy0 + 3,
-                    min (p.d >> 8, p.cy1) - sy0, nstr);
-              if (fmask) {
-                // t = s OVER t with a uniform s.  Opaque s, LERP, or nothing
-                // painted yet: t = s exactly.
-                const bool replace = (p.color >> 24) == 255u || p.rule == FLUTL_RULE_LERP;
-                const uint32_t plain = replace ? fmask : fmask & ~(ST_TOUCHED | ST_SOLID);
-                const uint32_t tinted = fmask & ~plain & ST_SOLID;   // uniform under a translucent box
-                const uint32_t under = fmask & ~plain & ST_TOUCHED;  // pixels under a translucent box
-                if (tinted) {
-                  const uint32_t c = uniform_over (base, p.color);
-                  if ((ST_SOLID & ~tinted) == 0u) {
-                    base = c;
-                  } else {
+                    min (p.d >> 8, p.cy1) - sy0);
 #pragma unroll
-                    for (int r = 0; r < kRG; r++)
-                      if ((tinted >> r) & 1u)
-                        STRIP_STORE (r, splat4 (c));
-                  }
-                }
-                if (plain)
-                  STRIPS_SET_UNIFORM (plain, p.color);
-                if (under) {
-                  const Px sc = unpack (p.color);
+              for (int r = 0; r < kRG; r++) {
+                w[r] = 0u;
+                if ((((smask & ~fmask) >> r) & 1u) == 0u)
+                  continue;
+                // cairo rectangular scan converter coverage (box edges only)
+                const int y = y0 + 4 * r;
+                const bool rowin = (uint32_t) (y - p.cy0) < (uint32_t) (p.cy1 - p.cy0);
+                const int oy = overlap256 (p.b, p.d, y);
+                uint32_t c = 0;
 #pragma unroll
-                  for (int r = 0; r < kRG; r++) {
-                    if (((under >> r) & 1u) == 0u)
-                      continue;
-                    const uint4 d = s_surf[r][lane];
-                    Px v0 = unpack (d.x), v1 = unpack (d.y), v2 = unpack (d.z), v3 = unpack (d.w);
-                    over (v0, sc);
-                    over (v1, sc);
-                    over (v2, sc);
-                    over (v3, sc);
-                    s_surf[r][lane] = make_uint4 (pack (v0), pack (v1), pack (v2), pack (v3));
-                  }
-                }
-                smask &= ~fmask;
-              }
-              // what is left are the edges of the box: coverage from cairo's
-              // rectangular scan converter
-              if (smask) {
-#pragma unroll
-                for (int r = 0; r < kRG; r++) {
-                  w[r] = 0u;
-                  if (((smask >> r) & 1u) == 0u)
-                    continue;
-                  const int y = y0 + 4 * r;
-                  const bool rowin = (uint32_t) (y - p.cy0) < (uint32_t) (p.cy1 - p.cy0);
-                  const int oy = overlap256 (p.b, p.d, y);
-                  uint32_t c = 0;
-#pragma unroll
-                  for (int k = 0; k < 4; k++)
-                    c |= min ((uint32_t) (overlap256 (p.a, p.c, x + k) * oy) >> 8, 255u) << (8 * k);
-                  w[r] = c & pixel_mask (p, x, rowin);
-                }
+                for (int k = 0; k < 4; k++)
+                  c |= min ((uint32_t) (overlap256 (p.a, p.c, x + k) * oy) >> 8, 255u) << (8 * k);
+                w[r] = c & pixel_mask (p, x, rowin);
               }
             } else {
 #pragma unroll
@@ -793,93 +618,90 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
                   w[r] &= pm;
               }
             }
-            if (smask) {
-              const Px sc = unpack (p.color);
-              const u16x2 rnd = as_u16x2 (p.rule == FLUTL_RULE_LERP ? 0x007f007fu : 0x00800080u);
-#define BLEND_STRIPS(V) \
-              _Pragma ("unroll") for (int r = 0; r < kRG; r++) { \
-                if (((smask >> r) & 1u) == 0u) \
-                  continue; \
-                if (__ballot (w[r] != 0) == 0) \
-                  continue;                          /* nothing lands in this strip */ \
-                uint4 v = STRIP_LOAD (r); \
-                strip_blend_v<V> (v, sc, w[r], rnd); \
-                STRIP_STORE (r, v); \
+#pragma unroll
+            for (int r = 0; r < kRG; r++) {
+              if (((smask >> r) & 1u) == 0u)
+                continue;
+              if ((fmask >> r) & 1u) {
+                // coverage 255 on the whole strip: t = s OVER t with a uniform
+                // s.  Opaque s, LERP, or nothing painted yet: t = s exactly.
+                if ((p.color >> 24) == 255u || p.rule == FLUTL_RULE_LERP ||
+                    ((touched >> r) & 1u) == 0u) {
+                  STRIP_STORE (r, make_uint4 (p.color, p.color, p.color, p.color));
+                } else {
+                  const Px sc = unpack (p.color);
+                  const uint4 d = s_surf[r][lane];
+                  Px v0 = unpack (d.x), v1 = unpack (d.y), v2 = unpack (d.z), v3 = unpack (d.w);
+                  over (v0, sc);
+                  over (v1, sc);
+                  over (v2, sc);
+                  over (v3, sc);
+                  s_surf[r][lane] = make_uint4 (pack (v0), pack (v1), pack (v2), pack (v3));
+                }
+                continue;
               }
-              if (p.color == 0xff000000u) {
-                BLEND_STRIPS (kBlendBlack)
-              } else if ((p.color >> 24) == 255u || p.rule == FLUTL_RULE_LERP) {
-                BLEND_STRIPS (kBlendOpaque)
-              } else {
-                BLEND_STRIPS (kBlendPixman)
-              }
-#undef BLEND_STRIPS
+              if (__ballot (w[r] != 0) == 0)
+                continue;                            // nothing lands in this strip
+              uint4 v = STRIP_LOAD (r);
+              strip_apply (v, p, w[r]);
+              STRIP_STORE (r, v);
             }
           } else if (p.op == FLUTL_OP_GROUP_BEGIN) {
             // the region's temporary surface starts transparent; what the
             // frame holds here so far (overlapping regions only) is parked
-            // (uniform frame strips become pixels first: overlapping regions only)
-            if (ST_SOLID) {
-#pragma unroll
-              for (int r = 0; r < kRG; r++)
-                if (ST_S (r))
-                  STRIP_STORE (r, splat4 (base));
-            }
+            touched_frame = touched;
 #pragma unroll
             for (int r = 0; r < kRG; r++)
-              if (ST_T (r))
-                park_store<EDGES> (STRIP_OUT (r, x, y0), s_surf[r][lane], ST_INTERIOR,
+              if ((touched >> r) & 1u)
+                park_store (STRIP_OUT (r, x, y0), s_surf[r][lane], interior,
                     (int) fp.width - x, (int) fp.height - (y0 + 4 * r));
-            st = (st & kStInterior) | (ST_TOUCHED << 16);    // touched_frame = touched; nothing else
-          } else if (p.op == FLUTL_OP_GROUP_END) {
-            // ---- (group surface IN alpha) OVER frame ---------------------------
-            // back to the frame; the group surface becomes the source.  A strip
-            // the group did not write to LDS still holds its frame pixels there.
-            const uint32_t sg = st;     // the group's touched / solid, the frame's touched_frame
-            const uint32_t base_group = base;
-            st = (sg & kStInterior) | ((sg >> 16) & ~sg & 0xffu);   // touched = touched_frame & ~touched_group
+            touched = 0;
+          } else {
+            // ---- per-pixel premultiplied source, OVER: IMAGE / GROUP_END ----
+            const bool is_end = p.op == FLUTL_OP_GROUP_END;
+            uint32_t touched_group = 0;
+            if (is_end) {
+              // back to the frame; the group surface becomes the source.  A
+              // strip the group did not touch still holds its frame pixels.
+              touched_group = touched;
+              touched = touched_frame & ~touched_group;
+            }
             const u16x2 al = splat (p.param);
-            // a uniform group strip, wholly inside the group's clip, over an
-            // empty frame strip: scalar bookkeeping
-            const bool xfull = p.cx0 <= sx0 && p.cx1 >= sx0 + kSuperW;
-            uint32_t cin = 0u;
-            if (sg & 0xff00u)
-              cin = uniform_in (base_group, al);
 #pragma unroll
             for (int r = 0; r < kRG; r++) {
-              if ((((sg | (sg >> 8)) >> r) & 1u) == 0u)
-                continue;
               const int ry0 = sy0 + 4 * r;
-              const bool src_solid = (sg >> (8 + r)) & 1u;
-              const bool frame_lds = (sg >> (16 + r)) & 1u;
-              if (src_solid && xfull && p.cy0 <= ry0 && p.cy1 >= ry0 + 4 && !frame_lds) {
-                STRIPS_SET_UNIFORM (1u << r, cin);
+              if (is_end ? ((touched_group >> r) & 1u) == 0u
+                         : (p.cy1 <= ry0 || p.cy0 >= ry0 + 4))
                 continue;
-              }
               const int y = y0 + 4 * r;
               const bool rowin = (uint32_t) (y - p.cy0) < (uint32_t) (p.cy1 - p.cy0);
               const uint32_t pmask = pixel_mask (p, x, rowin);
-              const uint4 g = src_solid ? splat4 (base_group) : s_surf[r][lane];
-              uint32_t sv[4];
-              sv[0] = (pmask & 0x1u) ? g.x : 0u;
-              sv[1] = (pmask & 0x100u) ? g.y : 0u;
-              sv[2] = (pmask & 0x10000u) ? g.z : 0u;
-              sv[3] = (pmask & 0x1000000u) ? g.w : 0u;
+              uint32_t sv[4] = { 0u, 0u, 0u, 0u };
               uint4 d;
-              if (frame_lds) {
-                if (src_solid) {
-                  d = s_surf[r][lane];          // never overwritten by the group
-                } else {
-                  d = park_load<EDGES> (STRIP_OUT (r, x, y0), ST_INTERIOR,
+              if (is_end) {
+                const uint4 g = s_surf[r][lane];
+                sv[0] = (pmask & 0x1u) ? g.x : 0u;
+                sv[1] = (pmask & 0x100u) ? g.y : 0u;
+                sv[2] = (pmask & 0x10000u) ? g.z : 0u;
+                sv[3] = (pmask & 0x1000000u) ? g.w : 0u;
+                d = make_uint4 (0u, 0u, 0u, 0u);
+                if ((touched_frame >> r) & 1u) {
+                  d = park_load (STRIP_OUT (r, x, y0), interior,
                       (int) fp.width - x, (int) fp.height - y);
-                  STRIP_STORE (r, d);           // the frame strip is back
+                  STRIP_STORE (r, d);     // the frame strip is back
                 }
               } else {
-                d = splat4 (0u);
+                const uint32_t rowoff = (uint32_t) p.a +
+                    (uint32_t) (y - p.d) * (uint32_t) p.b + (uint32_t) (x - p.c) * 4u;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                  if ((pmask >> (8 * k)) & 1u)
+                    sv[k] = *reinterpret_cast<const uint32_t *> (
+                        atlas + (rowoff + 4u * (uint32_t) k));
               }
               if (__ballot ((sv[0] | sv[1] | sv[2] | sv[3]) != 0) == 0)
                 continue;   // 0 OVER d == d
-              if (!frame_lds) {
+              if (is_end && ((touched_frame >> r) & 1u) == 0u) {
                 // nothing under the group here (regions that do not overlap,
                 // the usual case): x OVER 0 == x, only the IN remains
                 uint32_t o[4];
@@ -893,47 +715,18 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
                 STRIP_STORE (r, make_uint4 (o[0], o[1], o[2], o[3]));
                 continue;
               }
+              if (!is_end)
+                d = STRIP_LOAD (r);
               uint32_t dv[4] = { d.x, d.y, d.z, d.w };
 #pragma unroll
               for (int k = 0; k < 4; k++) {
                 Px sp = unpack (sv[k]);
-                sp.rb = mul_un8 (sp.rb, al);
-                sp.ag = mul_un8 (sp.ag, al);
+                if (is_end) {   // (group IN alpha)
+                  sp.rb = mul_un8 (sp.rb, al);
+                  sp.ag = mul_un8 (sp.ag, al);
+                }
                 Px v = unpack (dv[k]);
                 over (v, sp);
-                dv[k] = pack (v);
-              }
-              STRIP_STORE (r, make_uint4 (dv[0], dv[1], dv[2], dv[3]));
-            }
-          } else {
-            // ---- IMAGE: per-pixel premultiplied source, OVER --------------------
-#pragma unroll
-            for (int r = 0; r < kRG; r++) {
-              const int ry0 = sy0 + 4 * r;
-              if (p.cy1 <= ry0 || p.cy0 >= ry0 + 4 || r >= nstr)
-                continue;
-              const int y = y0 + 4 * r;
-              const bool rowin = (uint32_t) (y - p.cy0) < (uint32_t) (p.cy1 - p.cy0);
-              const uint32_t pmask = pixel_mask (p, x, rowin);
-              uint32_t sv[4];
-              const uint32_t rowoff = (uint32_t) p.a +
-                  (uint32_t) (y - p.d) * (uint32_t) p.b + (uint32_t) (x - p.c) * 4u;
-              // select free, like the mask bytes: pixels outside the image read
-              // the leading zeros of the atlas (contract: 16 of them)
-#pragma unroll
-              for (int k = 0; k < 4; k++) {
-                uint32_t off = ((pmask >> (8 * k)) & 1u) ? rowoff + 4u * (uint32_t) k : 0u;
-                asm volatile ("" : "+v"(off));
-                sv[k] = *reinterpret_cast<const uint32_t *> (atlas + off);
-              }
-              if (__ballot ((sv[0] | sv[1] | sv[2] | sv[3]) != 0) == 0)
-                continue;   // 0 OVER d == d
-              const uint4 d = STRIP_LOAD (r);
-              uint32_t dv[4] = { d.x, d.y, d.z, d.w };
-#pragma unroll
-              for (int k = 0; k < 4; k++) {
-                Px v = unpack (dv[k]);
-                over (v, unpack (sv[k]));
                 dv[k] = pack (v);
               }
               STRIP_STORE (r, make_uint4 (dv[0], dv[1], dv[2], dv[3]));
@@ -951,27 +744,17 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
   uint8_t *const out = STRIP_OUT (0, x_lane, y_lane);
   const uint8_t *const vin = VIDEO
       ? video + dst_off + (size_t) y_lane * fp.stride + (size_t) x_lane * 4 : nullptr;
-  if (!EDGES || ST_INTERIOR) {
-    const bool vec = EDGES || ST_INTERIOR;    // scalar: 16-byte aligned rows
+  if (interior) {
 #pragma unroll
     for (int r = 0; r < kRG; r++) {
-      if (r >= nstr)
-        continue;
       // streaming (nt) stores: the frame is written once and never read here,
       // so it should not evict glyph masks and list entries from the L2
       // (measured +6 % on the whole kernel; the store-only floor is unchanged)
       uint4 v = STRIP_LOAD (r);
-      uint8_t *const o = out + (size_t) (4 * r) * fp.stride;
       if (VIDEO) {
-        const uint8_t *const vi = vin + (size_t) (4 * r) * fp.stride;
-        u32x4 q;
-        if (vec) {
-          q = __builtin_nontemporal_load (reinterpret_cast<const u32x4 *> (vi));
-        } else {
-          const uint32_t *vq = reinterpret_cast<const uint32_t *> (vi);
-          q = u32x4 { vq[0], vq[1], vq[2], vq[3] };
-        }
-        if (ST_T (r) | ST_S (r)) {
+        const u32x4 q = __builtin_nontemporal_load (
+            reinterpret_cast<const u32x4 *> (vin + (size_t) (4 * r) * fp.stride));
+        if ((touched >> r) & 1u) {
           Px d0 = unpack (q.x), d1 = unpack (q.y), d2 = unpack (q.z), d3 = unpack (q.w);
           over (d0, unpack (v.x));
           over (d1, unpack (v.y));
@@ -982,16 +765,8 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
           v = make_uint4 (q.x, q.y, q.z, q.w);      // nothing painted: the video pixel
         }
       }
-      if (vec) {
-        const u32x4 nv = { v.x, v.y, v.z, v.w };
-        __builtin_nontemporal_store (nv, reinterpret_cast<u32x4 *> (o));
-      } else {
-        uint32_t *oq = reinterpret_cast<uint32_t *> (o);
-        oq[0] = v.x;
-        oq[1] = v.y;
-        oq[2] = v.z;
-        oq[3] = v.w;
-      }
+      const u32x4 nv = { v.x, v.y, v.z, v.w };
+      __builtin_nontemporal_store (nv, reinterpret_cast<u32x4 *> (out + (size_t) (4 * r) * fp.stride));
     }
   } else if (x_lane < (int) fp.width) {
     // frame edge or unaligned destination: per-pixel bounds
@@ -1015,13 +790,6 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
 #undef STRIP_OUT
 #undef STRIP_LOAD
 #undef STRIP_STORE
-#undef STRIPS_SET_UNIFORM
-#undef STRIP_UNIFORM
-#undef ST_TOUCHED
-#undef ST_SOLID
-#undef ST_T
-#undef ST_S
-#undef ST_INTERIOR
 }
 
 // ---------------------------------------------------------------------------
@@ -1218,23 +986,15 @@ int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst
   fp.magic_stx = fp.st_x > 1u
       ? (uint32_t) ((0x100000000ull + fp.st_x - 1u) / fp.st_x) : 0u;
   fp.stride = stride;
-  // frames that end on whole strips take the kernel without per-pixel border
-  // tests (alignment is dealt with inside: dst_offset lives in device memory)
-#ifdef FLUTL_FORCE_EDGES      // A/B measurements
-  const bool edges = true;
-#else
-  const bool edges = (width % kSuperW) != 0 || (height % 4u) != 0;
-#endif
-#define LAUNCH_K(V, E, grid) \
-      hipLaunchKernelGGL ((flutl_composite_kernel<V, E>), grid, dim3 (kThreads), 0, stream, fp, \
-          static_cast<uint8_t *> (dst), static_cast<const uint8_t *> (video), frames, \
-          regions, prims, atlas)
 #define LAUNCH(grid) do { \
-    if (video) { \
-      if (edges) LAUNCH_K (true, true, grid); else LAUNCH_K (true, false, grid); \
-    } else { \
-      if (edges) LAUNCH_K (false, true, grid); else LAUNCH_K (false, false, grid); \
-    } \
+    if (video) \
+      hipLaunchKernelGGL (flutl_composite_kernel<true>, grid, dim3 (kThreads), 0, stream, fp, \
+          static_cast<uint8_t *> (dst), static_cast<const uint8_t *> (video), frames, \
+          regions, prims, atlas); \
+    else \
+      hipLaunchKernelGGL (flutl_composite_kernel<false>, grid, dim3 (kThreads), 0, stream, fp, \
+          static_cast<uint8_t *> (dst), static_cast<const uint8_t *> (nullptr), frames, \
+          regions, prims, atlas); \
   } while (0)
   // one workgroup (= one wave) per supertile; grid.x is a multiple of 8 so
   // that blockIdx.x & 7 is the XCD of the workgroup in every row of the grid
@@ -1258,7 +1018,6 @@ int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst
     LAUNCH (dim3 ((fp.st_y + 7u) / 8u * fp.st_x * 8u, rest));
   }
 #undef LAUNCH
-#undef LAUNCH_K
   return hipGetLastError () == hipSuccess ? FLUTL_OK : FLUTL_ENODEV;
 }
 
