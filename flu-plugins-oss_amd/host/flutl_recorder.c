@@ -33,6 +33,8 @@ typedef struct
   uint32_t offset; /* atlas offset of the tight A8 bitmap */
   int w, h;        /* tight bitmap size; 0 x 0 = blank glyph */
   int bx, by;      /* bitmap top-left relative to the glyph origin */
+  int mbox[4];     /* the font's metric box of the glyph (device pixels, relative to
+                    * the origin): what Cairo tests against the clip */
 } GlyphEntry;
 
 typedef struct
@@ -74,13 +76,15 @@ typedef struct
   int lim[4];                /* the limits it was made under (device box) */
   uint32_t offset;           /* atlas offset of the tight A8 mask */
   int x, y, w, h;            /* box of the mask at (base_x, base_y), raster coordinates */
+  int ext[4];                /* extents of the stroke / fill there, unclipped */
 } StrokeEntry;
 
 struct FlutlRecorder
 {
   FlutlRecorder *parent;      /* child recorders put their masks in the parent's atlas */
   int width, height;
-  cairo_surface_t *scratch;   /* A8, width x height */
+  cairo_surface_t *scratch;   /* A8, sw x sh: the frame, or more (flutl_recorder_reserve) */
+  int sw, sh;
   int line_split;             /* FLUTL_LINE_SPLIT=1: see path_to_mask (NOT exact) */
   cairo_t *cr;
 
@@ -288,6 +292,38 @@ clip_box (FlutlRecorder *rec, int *x0, int *y0, int *x1, int *y1)
   return *x1 > *x0 && *y1 > *y0;
 }
 
+/* Does a device box meet the surface being drawn on (frame, or the region's
+ * temporary surface) and the clip?  Cairo returns NOTHING_TO_DO for an
+ * operation whose extents do not -- BEFORE it marks the surface as no longer
+ * clear (cairo-surface.c: is_clear = FALSE only if status != NOTHING_TO_DO),
+ * and "clear" selects the arithmetic of the next antialiased operation
+ * (found by tools/fuzz_ttml.py: a line of text clipped away above the region,
+ * then a background box with fractional edges). */
+static int
+box_hits_target (const FlutlRecorder *rec, int x0, int y0, int x1, int y1)
+{
+  if (x1 <= x0 || y1 <= y0)
+    return 0;
+  if (rec->in_group) {
+    x0 = imax (x0, rec->group[0]);
+    y0 = imax (y0, rec->group[1]);
+    x1 = imin (x1, rec->group[2]);
+    y1 = imin (y1, rec->group[3]);
+  } else {
+    x0 = imax (x0, 0);
+    y0 = imax (y0, 0);
+    x1 = imin (x1, rec->width);
+    y1 = imin (y1, rec->height);
+  }
+  if (rec->has_clip) {
+    x0 = imax (x0, rec->clip[0]);
+    y0 = imax (y0, rec->clip[1]);
+    x1 = imin (x1, rec->clip[2]);
+    y1 = imin (y1, rec->clip[3]);
+  }
+  return x1 > x0 && y1 > y0;
+}
+
 static flutl_prim *
 push_prim (FlutlRecorder *rec)
 {
@@ -432,8 +468,8 @@ flutl_recorder_begin_frame (FlutlRecorder *rec, int width, int height)
       cairo_surface_destroy (rec->scratch);
     rec->scratch = cairo_image_surface_create (CAIRO_FORMAT_A8, width, height);
     rec->cr = NULL;
-    rec->width = width;
-    rec->height = height;
+    rec->width = rec->sw = width;
+    rec->height = rec->sh = height;
   }
   if (rec->cr)
     cairo_destroy (rec->cr);
@@ -449,6 +485,28 @@ flutl_recorder_begin_frame (FlutlRecorder *rec, int width, int height)
   rec->unsupported = 0;
   path_ops_clear (rec);
   flutl_recorder_set_color (rec, 0, 0, 0, 1);
+}
+
+/* Paths are rasterised on the scratch surface under the bounds the reference
+ * draws them under -- and the surface itself is one more bound.  A region with
+ * an opacity draws on a temporary surface of ITS size, which may be larger than
+ * the frame: the scratch surface must not end before it does (found by
+ * tools/fuzz_ttml.py: a glyph outline that crosses x = frame width inside a
+ * wider region came out 1/255 different in one pixel).  To be called after
+ * flutl_recorder_begin_frame and before anything is drawn: the tracking context
+ * is made anew. */
+void
+flutl_recorder_reserve (FlutlRecorder *rec, int w, int h)
+{
+  if (w <= rec->sw && h <= rec->sh)
+    return;
+  rec->sw = imax (rec->sw, w);
+  rec->sh = imax (rec->sh, h);
+  cairo_destroy (rec->cr);
+  cairo_surface_destroy (rec->scratch);
+  rec->scratch = cairo_image_surface_create (CAIRO_FORMAT_A8, rec->sw, rec->sh);
+  rec->cr = cairo_create (rec->scratch);
+  cairo_set_source_rgba (rec->cr, 1, 1, 1, 1);
 }
 
 cairo_t *
@@ -730,6 +788,7 @@ glyph_rasterise (FlutlRecorder *rec, cairo_scaled_font_t *sf, GlyphEntry *e)
   cairo_text_extents_t ext;
   cairo_scaled_font_glyph_extents (sf, &g, 1, &ext);
   e->w = e->h = 0;
+  memset (e->mbox, 0, sizeof e->mbox);
   if (!(ext.width > 0) || !(ext.height > 0))
     return;
   /* device-space box of the glyph under the linear part of the CTM (identity
@@ -750,6 +809,10 @@ glyph_rasterise (FlutlRecorder *rec, cairo_scaled_font_t *sf, GlyphEntry *e)
   }
   int x0 = (int) floor (bx0) - 3, y0 = (int) floor (by0) - 3;
   int w = (int) ceil (bx1 - bx0) + 8, h = (int) ceil (by1 - by0) + 8;
+  e->mbox[0] = (int) floor (bx0);
+  e->mbox[1] = (int) floor (by0);
+  e->mbox[2] = (int) ceil (bx1);
+  e->mbox[3] = (int) ceil (by1);
   cairo_surface_t *s = cairo_image_surface_create (CAIRO_FORMAT_A8, w, h);
   cairo_t *cr = cairo_create (s);
   lin.x0 = -x0;                 /* glyph origin at the integer pixel (-x0, -y0) */
@@ -848,7 +911,9 @@ flutl_recorder_show_glyph (FlutlRecorder *rec, PangoFont *font,
   int ix = (int) floor (cx + 0.5) + rec->shift[0];
   int iy = (int) floor (cy + 0.5) + rec->shift[1];
   GlyphEntry *e = glyph_lookup (rec, sf, gi->glyph, &m);
-  target_touched (rec);
+  if (box_hits_target (rec, ix + e->mbox[0], iy + e->mbox[1], ix + e->mbox[2],
+          iy + e->mbox[3]))
+    target_touched (rec);
   if (e->w == 0)
     return;
   int ox = ix + e->bx, oy = iy + e->by;
@@ -981,18 +1046,24 @@ stroke_key (FlutlRecorder *rec, double line_width, int base_x, int base_y,
 static void
 stroke_emit (FlutlRecorder *rec, const StrokeEntry *e, int dx, int dy)
 {
-  if (e->w == 0)
-    return;
   int gx, gy;
   raster_origin (rec, &gx, &gy);
+  /* the surface stops being "clear" if the extents of the stroke meet it,
+   * whether or not any coverage does (see box_hits_target) -- after the rule
+   * of this very primitive has been chosen */
+  const int was_clear = target_is_clear (rec);
+  if (box_hits_target (rec, e->ext[0] + dx + gx, e->ext[1] + dy + gy,
+          e->ext[2] + dx + gx, e->ext[3] + dy + gy))
+    target_touched (rec);
+  if (e->w == 0)
+    return;
   int ox = e->x + dx + gx, oy = e->y + dy + gy;
   int x0 = ox, y0 = oy, x1 = ox + e->w, y1 = oy + e->h;
   if (!clip_box (rec, &x0, &y0, &x1, &y1))
     return;
   flutl_prim *p = push_prim (rec);
   p->op = FLUTL_OP_MASK;
-  p->rule = (rec->color_opaque || target_is_clear (rec))
-      ? FLUTL_RULE_LERP : FLUTL_RULE_PIXMAN;
+  p->rule = (rec->color_opaque || was_clear) ? FLUTL_RULE_LERP : FLUTL_RULE_PIXMAN;
   p->cx0 = (int16_t) x0;
   p->cy0 = (int16_t) y0;
   p->cx1 = (int16_t) x1;
@@ -1019,6 +1090,7 @@ typedef struct
   int bx0, by0, bx1, by1;       /* box to look at; empty: nothing to draw */
   int inside;                   /* the path stays clear of the limits */
   int lim[4];                   /* limits: frame, clip and group surface */
+  int ext[4];                   /* extents of the stroke / fill, unclipped */
 } RasterBox;
 
 /* What bounds a stroke in the reference: the surface it draws on (the frame,
@@ -1122,10 +1194,14 @@ raster_prepare (FlutlRecorder *rec, int fill, RasterBox *rb)
   current_limits (rec, rb->lim);
   rb->inside = ex1 >= rb->lim[0] + 3 && ey1 >= rb->lim[1] + 3 && ex2 <= rb->lim[2] - 3 &&
       ey2 <= rb->lim[3] - 3;
+  rb->ext[0] = (int) floor (ex1);
+  rb->ext[1] = (int) floor (ey1);
+  rb->ext[2] = (int) ceil (ex2);
+  rb->ext[3] = (int) ceil (ey2);
   rb->bx0 = imax (imax ((int) floor (ex1) - 2, rb->lim[0]), 0);
   rb->by0 = imax (imax ((int) floor (ey1) - 2, rb->lim[1]), 0);
-  rb->bx1 = imin (imin ((int) ceil (ex2) + 2, rb->lim[2]), rec->width);
-  rb->by1 = imin (imin ((int) ceil (ey2) + 2, rb->lim[3]), rec->height);
+  rb->bx1 = imin (imin ((int) ceil (ex2) + 2, rb->lim[2]), rec->sw);
+  rb->by1 = imin (imin ((int) ceil (ey2) + 2, rb->lim[3]), rec->sh);
 }
 
 static void
@@ -1198,6 +1274,7 @@ stroke_rasterise (FlutlRecorder *rec, StrokeEntry *e, int fill)
   RasterBox rb;
   raster_prepare (rec, fill, &rb);
   e->w = e->h = 0;
+  memcpy (e->ext, rb.ext, sizeof e->ext);
   if (rb.bx1 <= rb.bx0 || rb.by1 <= rb.by0) {
     cairo_new_path (cr);
     return rb.inside;
@@ -1603,7 +1680,6 @@ path_to_mask (FlutlRecorder *rec, int fill)
   }
   free (lo);
   free (grp);
-  target_touched (rec);
   path_ops_clear (rec);
 }
 
@@ -1665,8 +1741,9 @@ flutl_recorder_paint_image (FlutlRecorder *rec, cairo_surface_t *img, int x, int
     e->offset = atlas_put (rec, tight, (size_t) w * h * 4);
     free (tight);
   }
-  target_touched (rec);
   int x0 = x, y0 = y, x1 = x + e->w, y1 = y + e->h;
+  if (box_hits_target (rec, x0, y0, x1, y1))
+    target_touched (rec);
   if (!clip_box (rec, &x0, &y0, &x1, &y1))
     return;
   flutl_prim *p = push_prim (rec);

@@ -33,6 +33,7 @@ void flutl_recorder_reset (FlutlRecorder *rec);
 
 /* Start a new frame of width x height; keeps atlas + glyph cache. */
 void flutl_recorder_begin_frame (FlutlRecorder *rec, int width, int height);
+void flutl_recorder_reserve (FlutlRecorder *rec, int w, int h);
 
 /* The tracking context: callers issue cairo_save/translate/restore and path
  * calls on it exactly as the reference does on render->cairo. */

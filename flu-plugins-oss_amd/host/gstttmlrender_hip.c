@@ -1501,6 +1501,12 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
   }
   for (l = base->active_spans; l; l = l->next)
     span_to_region (render, &regions, l->data);
+  for (l = regions; l; l = l->next) {
+    /* a region with an opacity is drawn on a surface of its own size */
+    const HipRegion *r = l->data;
+    if (r->opacity < 1.0)
+      flutl_recorder_reserve (rec, (int) r->ex, (int) r->ey);
+  }
   for (l = regions; l; l = l->next)
     record_region (l->data, render);
   g_list_free_full (regions, region_free);
