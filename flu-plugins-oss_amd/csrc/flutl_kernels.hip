@@ -68,7 +68,9 @@ __device__ __forceinline__ Px unpack (uint32_t p)
 }
 __device__ __forceinline__ uint32_t pack (Px p)
 {
-  return as_u32 (p.rb) | (as_u32 (p.ag) << 8);
+  // {A, R, G, B} = {ag.byte2, rb.byte2, ag.byte0, rb.byte0}: one v_perm_b32
+  // (the compiler makes shift + or, two instructions, of the plain expression)
+  return __builtin_amdgcn_perm (as_u32 (p.ag), as_u32 (p.rb), 0x06020400u);
 }
 __device__ __forceinline__ u16x2 splat (uint32_t v)
 {
@@ -424,37 +426,27 @@ __device__ __forceinline__ uint32_t strip_range (int lo, int hi, int nmax)
 // edge from this lane's first pixel: pixels outside the frame are never
 // stored, nor read back.  The read-back is by the lane that stored, at the
 // same address, later in program order: no fence is needed for that.
-template <bool EDGES>
 __device__ __forceinline__ void park_store (uint8_t *o, uint4 v, bool whole, int nx, int ny)
 {
   if (whole) {
     *reinterpret_cast<uint4 *> (o) = v;
     return;
   }
-  uint32_t *q = reinterpret_cast<uint32_t *> (o);
-  const uint32_t e[4] = { v.x, v.y, v.z, v.w };
-  if (!EDGES) {         // only the alignment is missing
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      q[k] = e[k];
-    return;
-  }
   if (ny <= 0)
     return;
+  uint32_t *q = reinterpret_cast<uint32_t *> (o);
+  const uint32_t e[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
   for (int k = 0; k < 4; k++)
     if (k < nx)
       q[k] = e[k];
 }
 
-template <bool EDGES>
 __device__ __forceinline__ uint4 park_load (const uint8_t *o, bool whole, int nx, int ny)
 {
   if (whole)
     return *reinterpret_cast<const uint4 *> (o);
   const uint32_t *q = reinterpret_cast<const uint32_t *> (o);
-  if (!EDGES)
-    return make_uint4 (q[0], q[1], q[2], q[3]);
   uint32_t e[4] = { 0u, 0u, 0u, 0u };
   if (ny > 0) {
 #pragma unroll
@@ -519,15 +511,12 @@ __device__ __forceinline__ uint32_t uniform_over (uint32_t d, uint32_t s)
 // frame (same geometry as dst) in the store epilogue -- the "blend over the
 // video buffer" of the north star, fused so that the overlay never exists in
 // memory.  Separate instantiation: the plain overlay path pays nothing.
-// EDGES: supertiles may be cut by the right or bottom border of the frame at any
-// pixel.  The instantiation without is for frames whose width is a multiple of
-// 64 and whose height is a multiple of 4 (every broadcast format from 720p up):
-// a supertile then ends on a whole strip, which is a wave-uniform fact, and no
-// lane-divergent branch is left inside the replay loop -- which matters beyond
-// the branches themselves: with one in it, the compiler "structurises" the
-// whole loop body and turns its (wave-uniform) dispatch into flag juggling on
-// the scalar unit.
-template <bool VIDEO, bool EDGES>
+// (Tried: a second instantiation for frames that end on whole strips -- width a
+// multiple of 64, height of 4 -- with no lane-divergent branch left in the
+// replay loop, so that the compiler does not "structurise" its wave-uniform
+// dispatch into flag juggling.  It came out with MORE scalar branches, not
+// fewer, and 2 % slower; dropped.)
+template <bool VIDEO>
 __attribute__ ((amdgpu_waves_per_eu (FLUTL_WAVES)))
 __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
     FrameParams fp, uint8_t *__restrict__ dst, const uint8_t *__restrict__ video,
@@ -605,12 +594,9 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
   // A strip that is neither touched nor solid is transparent and is neither
   // initialised nor read.
   uint32_t base = 0;
-  uint32_t st = ((!EDGES || (sx0 + kSuperW <= (int) fp.width && sy0 + kSuperH <= (int) fp.height)) &&
+  uint32_t st = (sx0 + kSuperW <= (int) fp.width && sy0 + kSuperH <= (int) fp.height &&
       ((reinterpret_cast<uintptr_t> (dst) | (VIDEO ? reinterpret_cast<uintptr_t> (video) : 0) |
           dst_off | fp.stride) & 15u) == 0) ? kStInterior : 0u;   // scalar
-  // strips of this supertile that exist (!EDGES: the rest lies below the frame
-  // and is never touched; EDGES: pixels are tested one by one where it matters)
-  const int nstr = EDGES ? kRG : min (kRG, ((int) fp.height - sy0) >> 2);
 
 #define ST_TOUCHED      (st & 0xffu)
 #define ST_SOLID        ((st >> 8) & 0xffu)
@@ -718,7 +704,7 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
             //      24.8 box of cairo's rectangular scan converter -------------
             // strips the clipped bbox touches: a bit mask made once per
             // primitive with scalar ops
-            uint32_t smask = strip_range (p.cy0 - sy0, p.cy1 - sy0 + 3, nstr);
+            uint32_t smask = strip_range (p.cy0 - sy0, p.cy1 - sy0 + 3, kRG);
             uint32_t w[kRG];
             if (p.op == FLUTL_OP_RECT) {
               // strips the box covers completely (coverage 255 all over)
@@ -726,7 +712,7 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
               if (((p.a + 255) >> 8) <= sx0 && (p.c >> 8) >= sx0 + kSuperW &&
                   p.cx0 <= sx0 && p.cx1 >= sx0 + kSuperW)
                 fmask = strip_range (max ((p.b + 255) >> 8, p.cy0) - sy0 + 3,
-                    min (p.d >> 8, p.cy1) - sy0, nstr);
+                    min (p.d >> 8, p.cy1) - sy0, kRG);
               if (fmask) {
                 // t = s OVER t with a uniform s.  Opaque s, LERP, or nothing
                 // painted yet: t = s exactly.
@@ -828,7 +814,7 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
 #pragma unroll
             for (int r = 0; r < kRG; r++)
               if (ST_T (r))
-                park_store<EDGES> (STRIP_OUT (r, x, y0), s_surf[r][lane], ST_INTERIOR,
+                park_store (STRIP_OUT (r, x, y0), s_surf[r][lane], ST_INTERIOR,
                     (int) fp.width - x, (int) fp.height - (y0 + 4 * r));
             st = (st & kStInterior) | (ST_TOUCHED << 16);    // touched_frame = touched; nothing else
           } else if (p.op == FLUTL_OP_GROUP_END) {
@@ -870,7 +856,7 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
                 if (src_solid) {
                   d = s_surf[r][lane];          // never overwritten by the group
                 } else {
-                  d = park_load<EDGES> (STRIP_OUT (r, x, y0), ST_INTERIOR,
+                  d = park_load (STRIP_OUT (r, x, y0), ST_INTERIOR,
                       (int) fp.width - x, (int) fp.height - y);
                   STRIP_STORE (r, d);           // the frame strip is back
                 }
@@ -910,7 +896,7 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
 #pragma unroll
             for (int r = 0; r < kRG; r++) {
               const int ry0 = sy0 + 4 * r;
-              if (p.cy1 <= ry0 || p.cy0 >= ry0 + 4 || r >= nstr)
+              if (p.cy1 <= ry0 || p.cy0 >= ry0 + 4)
                 continue;
               const int y = y0 + 4 * r;
               const bool rowin = (uint32_t) (y - p.cy0) < (uint32_t) (p.cy1 - p.cy0);
@@ -951,26 +937,16 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
   uint8_t *const out = STRIP_OUT (0, x_lane, y_lane);
   const uint8_t *const vin = VIDEO
       ? video + dst_off + (size_t) y_lane * fp.stride + (size_t) x_lane * 4 : nullptr;
-  if (!EDGES || ST_INTERIOR) {
-    const bool vec = EDGES || ST_INTERIOR;    // scalar: 16-byte aligned rows
+  if (ST_INTERIOR) {
 #pragma unroll
     for (int r = 0; r < kRG; r++) {
-      if (r >= nstr)
-        continue;
       // streaming (nt) stores: the frame is written once and never read here,
       // so it should not evict glyph masks and list entries from the L2
       // (measured +6 % on the whole kernel; the store-only floor is unchanged)
       uint4 v = STRIP_LOAD (r);
-      uint8_t *const o = out + (size_t) (4 * r) * fp.stride;
       if (VIDEO) {
-        const uint8_t *const vi = vin + (size_t) (4 * r) * fp.stride;
-        u32x4 q;
-        if (vec) {
-          q = __builtin_nontemporal_load (reinterpret_cast<const u32x4 *> (vi));
-        } else {
-          const uint32_t *vq = reinterpret_cast<const uint32_t *> (vi);
-          q = u32x4 { vq[0], vq[1], vq[2], vq[3] };
-        }
+        const u32x4 q = __builtin_nontemporal_load (
+            reinterpret_cast<const u32x4 *> (vin + (size_t) (4 * r) * fp.stride));
         if (ST_T (r) | ST_S (r)) {
           Px d0 = unpack (q.x), d1 = unpack (q.y), d2 = unpack (q.z), d3 = unpack (q.w);
           over (d0, unpack (v.x));
@@ -982,16 +958,8 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
           v = make_uint4 (q.x, q.y, q.z, q.w);      // nothing painted: the video pixel
         }
       }
-      if (vec) {
-        const u32x4 nv = { v.x, v.y, v.z, v.w };
-        __builtin_nontemporal_store (nv, reinterpret_cast<u32x4 *> (o));
-      } else {
-        uint32_t *oq = reinterpret_cast<uint32_t *> (o);
-        oq[0] = v.x;
-        oq[1] = v.y;
-        oq[2] = v.z;
-        oq[3] = v.w;
-      }
+      const u32x4 nv = { v.x, v.y, v.z, v.w };
+      __builtin_nontemporal_store (nv, reinterpret_cast<u32x4 *> (out + (size_t) (4 * r) * fp.stride));
     }
   } else if (x_lane < (int) fp.width) {
     // frame edge or unaligned destination: per-pixel bounds
@@ -1218,23 +1186,15 @@ int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst
   fp.magic_stx = fp.st_x > 1u
       ? (uint32_t) ((0x100000000ull + fp.st_x - 1u) / fp.st_x) : 0u;
   fp.stride = stride;
-  // frames that end on whole strips take the kernel without per-pixel border
-  // tests (alignment is dealt with inside: dst_offset lives in device memory)
-#ifdef FLUTL_FORCE_EDGES      // A/B measurements
-  const bool edges = true;
-#else
-  const bool edges = (width % kSuperW) != 0 || (height % 4u) != 0;
-#endif
-#define LAUNCH_K(V, E, grid) \
-      hipLaunchKernelGGL ((flutl_composite_kernel<V, E>), grid, dim3 (kThreads), 0, stream, fp, \
-          static_cast<uint8_t *> (dst), static_cast<const uint8_t *> (video), frames, \
-          regions, prims, atlas)
 #define LAUNCH(grid) do { \
-    if (video) { \
-      if (edges) LAUNCH_K (true, true, grid); else LAUNCH_K (true, false, grid); \
-    } else { \
-      if (edges) LAUNCH_K (false, true, grid); else LAUNCH_K (false, false, grid); \
-    } \
+    if (video) \
+      hipLaunchKernelGGL (flutl_composite_kernel<true>, grid, dim3 (kThreads), 0, stream, fp, \
+          static_cast<uint8_t *> (dst), static_cast<const uint8_t *> (video), frames, \
+          regions, prims, atlas); \
+    else \
+      hipLaunchKernelGGL (flutl_composite_kernel<false>, grid, dim3 (kThreads), 0, stream, fp, \
+          static_cast<uint8_t *> (dst), static_cast<const uint8_t *> (nullptr), frames, \
+          regions, prims, atlas); \
   } while (0)
   // one workgroup (= one wave) per supertile; grid.x is a multiple of 8 so
   // that blockIdx.x & 7 is the XCD of the workgroup in every row of the grid
@@ -1258,7 +1218,6 @@ int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst
     LAUNCH (dim3 ((fp.st_y + 7u) / 8u * fp.st_x * 8u, rest));
   }
 #undef LAUNCH
-#undef LAUNCH_K
   return hipGetLastError () == hipSuccess ? FLUTL_OK : FLUTL_ENODEV;
 }
 
