@@ -629,8 +629,10 @@ flutl_recorder_group_end (FlutlRecorder *rec, double opacity)
   /* cairo_paint_with_alpha returns before touching the surface if the alpha
    * is "zero" (CAIRO_ALPHA_IS_ZERO: <= 0x00ff / 0xffff): the frame then still
    * counts as clear for the next antialiased operation (found by
-   * tools/fuzz_ttml.py); the composite itself is a no-op either way */
-  if (!(opacity <= (double) 0x00ff / (double) 0xffff))
+   * tools/fuzz_ttml.py); the composite itself is a no-op either way
+   * -- and so does the paint of a temporary surface that nothing was drawn
+   * on (cairo-surface.c nothing_to_do: OVER with a clear source) */
+  if (!(opacity <= (double) 0x00ff / (double) 0xffff) && !rec->group_clear)
     rec->frame_clear = 0;
 }
 
