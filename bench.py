@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one batch of input: `--batch` (default
-32) overlay frames, each a DISTINCT scene state, composited by ONE launch of the
+64) overlay frames, each a DISTINCT scene state, composited by ONE launch of the
 tile kernel from display lists + glyph atlas already resident in HBM into a
 ring of device frames larger than the 256 MiB Infinity Cache.  At N>1 every
 rank renders its own independent stream (weak scaling, no data-path
@@ -98,9 +98,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", default="cfg2_2160p_8regions_outline",
                     choices=sorted(CONFIGS))
-    ap.add_argument("--batch", type=int, default=32,
+    ap.add_argument("--batch", type=int, default=64,
                     help="frames (distinct scene states) per launch = per step")
-    ap.add_argument("--states", type=int, default=32, help="distinct scene states")
+    ap.add_argument("--states", type=int, default=64, help="distinct scene states")
     ap.add_argument("--ring", type=int, default=0, help="output frames in the ring")
     ap.add_argument("--gather", action="store_true",
                     help="RCCL gather of every finished frame to rank 0")
