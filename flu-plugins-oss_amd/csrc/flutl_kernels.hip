@@ -538,6 +538,11 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
   // lane's own pixels of the destination frame, which are written for good
   // at the end anyway.
   __shared__ uint4 s_surf[kRG][kThreads];
+  // Blend results by coverage, for the strips a primitive meets while they are
+  // still one uniform colour (the outline of a text over its background box):
+  // there the result depends on the coverage byte alone, so it is computed once
+  // for the 256 coverages -- 4 per lane -- and looked up per pixel (BLEND_STRIPS).
+  __shared__ uint32_t s_lut[256];
 
   // One wavefront per workgroup: nothing is shared between waves.
   const int lane = threadIdx.x;
@@ -782,12 +787,39 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
             if (smask) {
               const Px sc = unpack (p.color);
               const u16x2 rnd = as_u16x2 (p.rule == FLUTL_RULE_LERP ? 0x007f007fu : 0x00800080u);
+              // strips where coverage lands at all, and those of them that are
+              // still uniform
+              uint32_t cmask = 0u;
+#pragma unroll
+              for (int r = 0; r < kRG; r++)
+                if (((smask >> r) & 1u) && __ballot (w[r] != 0) != 0)
+                  cmask |= 1u << r;
+              uint32_t lmask = cmask & ST_SOLID;
+#if FLUTL_EXP == 10      // ablation: no lookup table
+              lmask = 0u;
+#endif
+              if (__builtin_popcount (lmask) < 2)
+                lmask = 0u;           // one strip: the table would cost more than it saves
+              cmask &= ~lmask;
 #define BLEND_STRIPS(V) \
+              if (lmask) { \
+                _Pragma ("unroll") for (int j = 0; j < 4; j++) { \
+                  const uint32_t m = (uint32_t) lane + 64u * (uint32_t) j; \
+                  Px t = unpack (base); \
+                  px_blend<V, 0> (t, sc, m, rnd); \
+                  s_lut[m] = pack (t); \
+                } \
+                _Pragma ("unroll") for (int r = 0; r < kRG; r++) { \
+                  if (((lmask >> r) & 1u) == 0u) \
+                    continue; \
+                  const uint32_t ww = w[r]; \
+                  STRIP_STORE (r, make_uint4 (s_lut[ww & 0xffu], s_lut[(ww >> 8) & 0xffu], \
+                      s_lut[(ww >> 16) & 0xffu], s_lut[ww >> 24])); \
+                } \
+              } \
               _Pragma ("unroll") for (int r = 0; r < kRG; r++) { \
-                if (((smask >> r) & 1u) == 0u) \
+                if (((cmask >> r) & 1u) == 0u) \
                   continue; \
-                if (__ballot (w[r] != 0) == 0) \
-                  continue;                          /* nothing lands in this strip */ \
                 uint4 v = STRIP_LOAD (r); \
                 strip_blend_v<V> (v, sc, w[r], rnd); \
                 STRIP_STORE (r, v); \
