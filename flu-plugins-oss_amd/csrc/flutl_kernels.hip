@@ -709,15 +709,20 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
             //      24.8 box of cairo's rectangular scan converter -------------
             // strips the clipped bbox touches: a bit mask made once per
             // primitive with scalar ops
-            uint32_t smask = strip_range (p.cy0 - sy0, p.cy1 - sy0 + 3, kRG);
+            uint32_t smask;
             uint32_t w[kRG];
             if (p.op == FLUTL_OP_RECT) {
-              // strips the box covers completely (coverage 255 all over)
+              // strips the box covers completely (coverage 255 all over); the
+              // usual supertile lies wholly inside a background box
               uint32_t fmask = 0u;
               if (((p.a + 255) >> 8) <= sx0 && (p.c >> 8) >= sx0 + kSuperW &&
-                  p.cx0 <= sx0 && p.cx1 >= sx0 + kSuperW)
-                fmask = strip_range (max ((p.b + 255) >> 8, p.cy0) - sy0 + 3,
-                    min (p.d >> 8, p.cy1) - sy0, kRG);
+                  p.cx0 <= sx0 && p.cx1 >= sx0 + kSuperW) {
+                const int fy0 = max ((p.b + 255) >> 8, p.cy0), fy1 = min (p.d >> 8, p.cy1);
+                fmask = (fy0 <= sy0 && fy1 >= sy0 + kSuperH) ? (1u << kRG) - 1u
+                    : strip_range (fy0 - sy0 + 3, fy1 - sy0, kRG);
+              }
+              smask = fmask == (1u << kRG) - 1u ? 0u
+                  : strip_range (p.cy0 - sy0, p.cy1 - sy0 + 3, kRG);
               if (fmask) {
                 // t = s OVER t with a uniform s.  Opaque s, LERP, or nothing
                 // painted yet: t = s exactly.
@@ -774,6 +779,7 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
                 }
               }
             } else {
+              smask = strip_range (p.cy0 - sy0, p.cy1 - sy0 + 3, kRG);
 #pragma unroll
               for (int r = 0; r < kRG; r++)
                 w[r] = f.w[r];
@@ -875,14 +881,16 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
                 continue;
               }
               const int y = y0 + 4 * r;
-              const bool rowin = (uint32_t) (y - p.cy0) < (uint32_t) (p.cy1 - p.cy0);
-              const uint32_t pmask = pixel_mask (p, x, rowin);
               const uint4 g = src_solid ? splat4 (base_group) : s_surf[r][lane];
-              uint32_t sv[4];
-              sv[0] = (pmask & 0x1u) ? g.x : 0u;
-              sv[1] = (pmask & 0x100u) ? g.y : 0u;
-              sv[2] = (pmask & 0x10000u) ? g.z : 0u;
-              sv[3] = (pmask & 0x1000000u) ? g.w : 0u;
+              uint32_t sv[4] = { g.x, g.y, g.z, g.w };
+              if (!(xfull && p.cy0 <= ry0 && p.cy1 >= ry0 + 4)) {   // cut by the group's box
+                const bool rowin = (uint32_t) (y - p.cy0) < (uint32_t) (p.cy1 - p.cy0);
+                const uint32_t pmask = pixel_mask (p, x, rowin);
+                sv[0] = (pmask & 0x1u) ? g.x : 0u;
+                sv[1] = (pmask & 0x100u) ? g.y : 0u;
+                sv[2] = (pmask & 0x10000u) ? g.z : 0u;
+                sv[3] = (pmask & 0x1000000u) ? g.w : 0u;
+              }
               uint4 d;
               if (frame_lds) {
                 if (src_solid) {
