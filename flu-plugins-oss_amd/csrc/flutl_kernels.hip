@@ -810,7 +810,8 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
 #define BLEND_STRIPS(V) \
               if (lmask) { \
                 _Pragma ("unroll") for (int j = 0; j < 4; j++) { \
-                  const uint32_t m = (uint32_t) lane + 64u * (uint32_t) j; \
+                  uint32_t m = (uint32_t) lane + 64u * (uint32_t) j; \
+                  asm volatile ("" : "+v"(m));    /* or everything derived from it is hoisted to the kernel's top */ \
                   Px t = unpack (base); \
                   px_blend<V, 0> (t, sc, m, rnd); \
                   s_lut[m] = pack (t); \
