@@ -153,8 +153,8 @@ constexpr int kSuperW = FLUTL_TILE_W;        // 64
 #endif
 constexpr int kRG = FLUTL_KRG;               // row groups per wave
 constexpr int kSuperH = 4 * kRG;             // kRG strips of 4 rows
-constexpr uint32_t kStInterior = 1u << 24;   // see `st` in the kernel
-static_assert (kRG <= 8, "strip masks are 8 bits wide");
+constexpr uint32_t kStInterior = 1u << 31;   // see `st` in the kernel
+static_assert (kRG <= 7, "strip masks: 8 bits wide, the last one 7");
 
 // A primitive held wave-uniformly in SGPRs.  During binning every lane holds
 // one candidate primitive (32 bytes = 8 VGPRs); a hit is broadcast to the
@@ -594,11 +594,13 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
   //                with coverage lands on it;
   //   bits 16..23  "touched_frame": strips of the FRAME that held pixels when
   //                the current opacity group began;
-  //   bit  24      the whole supertile is inside the frame and its rows are
+  //   bits 24..30  "solid_frame": strips of the FRAME that were uniform then
+  //                (colour: base_frame);
+  //   bit  31      the whole supertile is inside the frame and its rows are
   //                16-byte aligned ("interior").
   // A strip that is neither touched nor solid is transparent and is neither
   // initialised nor read.
-  uint32_t base = 0;
+  uint32_t base = 0, base_frame = 0;
   uint32_t st = (sx0 + kSuperW <= (int) fp.width && sy0 + kSuperH <= (int) fp.height &&
       ((reinterpret_cast<uintptr_t> (dst) | (VIDEO ? reinterpret_cast<uintptr_t> (video) : 0) |
           dst_off | fp.stride) & 15u) == 0) ? kStInterior : 0u;   // scalar
@@ -843,48 +845,61 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
           } else if (p.op == FLUTL_OP_GROUP_BEGIN) {
             // the region's temporary surface starts transparent; what the
             // frame holds here so far (overlapping regions only) is parked
-            // (uniform frame strips become pixels first: overlapping regions only)
-            if (ST_SOLID) {
-#pragma unroll
-              for (int r = 0; r < kRG; r++)
-                if (ST_S (r))
-                  STRIP_STORE (r, splat4 (base));
-            }
 #pragma unroll
             for (int r = 0; r < kRG; r++)
               if (ST_T (r))
                 park_store (STRIP_OUT (r, x, y0), s_surf[r][lane], ST_INTERIOR,
                     (int) fp.width - x, (int) fp.height - (y0 + 4 * r));
-            st = (st & kStInterior) | (ST_TOUCHED << 16);    // touched_frame = touched; nothing else
+            // touched_frame = touched, solid_frame = solid, nothing in the group yet
+            base_frame = base;
+            st = (st & kStInterior) | (ST_TOUCHED << 16) | (ST_SOLID << 24);
           } else if (p.op == FLUTL_OP_GROUP_END) {
             // ---- (group surface IN alpha) OVER frame ---------------------------
             // back to the frame; the group surface becomes the source.  A strip
-            // the group did not write to LDS still holds its frame pixels there.
-            const uint32_t sg = st;     // the group's touched / solid, the frame's touched_frame
+            // the group did not write to LDS still holds its frame pixels there,
+            // and a uniform frame strip is uniform still.
+            const uint32_t sg = st;     // the group's touched / solid, the frame's of before
             const uint32_t base_group = base;
-            st = (sg & kStInterior) | ((sg >> 16) & ~sg & 0xffu);   // touched = touched_frame & ~touched_group
+            const uint32_t lds_frame = (sg >> 16) & 0xffu, solid_frame = (sg >> 24) & 0x7fu;
+            st = (sg & kStInterior) | (lds_frame & ~sg & 0xffu) | (solid_frame << 8);
+            base = base_frame;
             const u16x2 al = splat (p.param);
-            // a uniform group strip, wholly inside the group's clip, over an
-            // empty frame strip: scalar bookkeeping
+            // uniform group strips, wholly inside the group's box, over frame
+            // strips that are uniform or empty: scalar bookkeeping (all of a
+            // supertile that only background boxes have met, however many
+            // regions overlap there)
             const bool xfull = p.cx0 <= sx0 && p.cx1 >= sx0 + kSuperW;
-            uint32_t cin = 0u;
-            if (sg & 0xff00u)
-              cin = uniform_in (base_group, al);
+            const uint32_t inside = xfull ? strip_range (p.cy0 - sy0 + 3, p.cy1 - sy0, kRG) : 0u;
+            const uint32_t um = (sg >> 8) & inside & ~lds_frame;
+            if (um) {
+              const uint32_t cin = uniform_in (base_group, al);
+              const uint32_t um_over = um & solid_frame;
+              if (um_over) {
+                const uint32_t cover = uniform_over (base_frame, cin);
+                if ((ST_SOLID & ~um_over) == 0u) {
+                  base = cover;
+                } else {
+#pragma unroll
+                  for (int r = 0; r < kRG; r++)
+                    if ((um_over >> r) & 1u)
+                      STRIP_STORE (r, splat4 (cover));
+                }
+              }
+              if (um & ~solid_frame)
+                STRIPS_SET_UNIFORM (um & ~solid_frame, cin);
+            }
 #pragma unroll
             for (int r = 0; r < kRG; r++) {
-              if ((((sg | (sg >> 8)) >> r) & 1u) == 0u)
+              if (((((sg | (sg >> 8)) & ~um) >> r) & 1u) == 0u)
                 continue;
               const int ry0 = sy0 + 4 * r;
               const bool src_solid = (sg >> (8 + r)) & 1u;
-              const bool frame_lds = (sg >> (16 + r)) & 1u;
-              if (src_solid && xfull && p.cy0 <= ry0 && p.cy1 >= ry0 + 4 && !frame_lds) {
-                STRIPS_SET_UNIFORM (1u << r, cin);
-                continue;
-              }
+              const bool frame_lds = (lds_frame >> r) & 1u;
+              const bool frame_solid = (solid_frame >> r) & 1u;
               const int y = y0 + 4 * r;
               const uint4 g = src_solid ? splat4 (base_group) : s_surf[r][lane];
               uint32_t sv[4] = { g.x, g.y, g.z, g.w };
-              if (!(xfull && p.cy0 <= ry0 && p.cy1 >= ry0 + 4)) {   // cut by the group's box
+              if (((inside >> r) & 1u) == 0u) {   // cut by the group's box
                 const bool rowin = (uint32_t) (y - p.cy0) < (uint32_t) (p.cy1 - p.cy0);
                 const uint32_t pmask = pixel_mask (p, x, rowin);
                 sv[0] = (pmask & 0x1u) ? g.x : 0u;
@@ -902,11 +917,11 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
                   STRIP_STORE (r, d);           // the frame strip is back
                 }
               } else {
-                d = splat4 (0u);
+                d = splat4 (frame_solid ? base_frame : 0u);
               }
               if (__ballot ((sv[0] | sv[1] | sv[2] | sv[3]) != 0) == 0)
                 continue;   // 0 OVER d == d
-              if (!frame_lds) {
+              if (!frame_lds && !frame_solid) {
                 // nothing under the group here (regions that do not overlap,
                 // the usual case): x OVER 0 == x, only the IN remains
                 uint32_t o[4];
