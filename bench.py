@@ -102,6 +102,8 @@ def main():
                     help="frames (distinct scene states) per launch = per step")
     ap.add_argument("--states", type=int, default=64, help="distinct scene states")
     ap.add_argument("--ring", type=int, default=0, help="output frames in the ring")
+    ap.add_argument("--row-pad", type=int, default=0,
+                    help="experiment: bytes of padding after each row of the device frames")
     ap.add_argument("--gather", action="store_true",
                     help="RCCL gather of every finished frame to rank 0")
     ap.add_argument("--over-video", action="store_true",
@@ -142,7 +144,8 @@ def main():
     W, H, states, atlas, source = load_states(args.config, args.states, stream_seed)
     n_states = len(states)
     B = args.batch
-    frame_bytes = W * H * 4
+    stride = W * 4 + args.row_pad
+    frame_bytes = stride * H
     ring = args.ring or max(2 * B, (640 << 20) // frame_bytes + 1)
     ring = (ring + B - 1) // B * B
 
@@ -196,7 +199,7 @@ def main():
                                     D_dev.data_ptr() + ds * B * 16, B, R_dev, P_dev, A_dev)
             else:
                 F.launch_batch(stream, W, H, out, D_dev.data_ptr() + ds * B * 16, B,
-                               R_dev, P_dev, A_dev)
+                               R_dev, P_dev, A_dev, stride=stride)
             if args.gather and world > 1:
                 for j in range(B):
                     slot = (ds * B + j) % ring
