@@ -616,8 +616,18 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
     st = (st | (1u << (r))) & ~(0x100u << (r)); } while (0)
   // the strips of mask m become the uniform colour c (one `base` per supertile:
   // a second colour, e.g. where two regions meet inside it, goes to LDS)
+  // (inside an opacity group, a strip whose LDS slots the group has written to
+  // while the frame's pixels of that strip are parked stays in LDS: GROUP_END
+  // tells by the touched bit whether the slots still hold the frame's pixels)
 #define STRIPS_SET_UNIFORM(m, c) do { \
-    const uint32_t m_ = (m), c_ = (c); \
+    const uint32_t c_ = (c); \
+    uint32_t m_ = (m); \
+    const uint32_t keep_ = m_ & st & (st >> 16) & 0xffu; \
+    if (keep_) { \
+      _Pragma ("unroll") for (int r_ = 0; r_ < kRG; r_++) \
+        if ((keep_ >> r_) & 1u) s_surf[r_][lane] = splat4 (c_); \
+      m_ &= ~keep_; \
+    } \
     if ((ST_SOLID & ~m_) == 0u || base == c_) { \
       base = c_; st = (st | (m_ << 8)) & ~m_; \
     } else { \

@@ -101,11 +101,16 @@ def random_scene(seed, width, height, n_regions=6, prims_per_region=24,
                 fy1 = int(rng.integers(clip[1] * 256 - 300, clip[3] * 256))
                 fx2 = fx1 + int(rng.integers(1, 40 * 256))
                 fy2 = fy1 + int(rng.integers(1, 6 * 256))
+                if rng.random() < 0.25:     # a box with fractional edges over many tiles
+                    fx2 = fx1 + int(rng.integers(1, max(2, (clip[2] - clip[0]) * 256)))
+                    fy2 = fy1 + int(rng.integers(1, max(2, (clip[3] - clip[1]) * 256)))
                 if rng.random() < 0.3:
                     fx1 &= ~255; fx2 &= ~255
                 col = _premul(rng)
                 aligned = ((fx1 | fy1 | fx2 | fy2) & 255) == 0
                 rule = F.RULE_LERP if (col >> 24) == 255 and not aligned else F.RULE_PIXMAN
+                if not aligned and rng.random() < 0.15:
+                    rule = F.RULE_LERP      # cairo: any colour onto a surface that is still clear
                 bb = _clip(fx1 >> 8, fy1 >> 8, (fx2 + 255) >> 8, (fy2 + 255) >> 8, clip)
                 add(F.OP_RECT, rule, bb, col, fx1, fy1, fx2, fy2)
             elif kind < 0.85:  # glyph / outline mask

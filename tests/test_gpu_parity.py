@@ -34,7 +34,7 @@ SIZES = [(320, 180), (1, 1), (3, 2), (64, 8), (65, 9), (63, 7), (130, 50),
 
 
 @pytest.mark.parametrize("size", SIZES)
-@pytest.mark.parametrize("seed", [0, 1, 2])
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
 def test_kernel_matches_oracle_on_random_lists(gpu, size, seed):
     W, H = size
     R, P, A = scenes.random_scene(seed * 100 + W, W, H, n_regions=8)
@@ -49,6 +49,35 @@ def test_many_prims_per_region_spans_binning_chunks(gpu):
     R, P, A = scenes.random_scene(77, W, H, n_regions=3, prims_per_region=600,
                                   fixed_count=True)
     assert max(R["count"]) > 256
+    assert np.array_equal(gpu.hip_render(W, H, R, P, A), O.render(W, H, R, P, A))
+
+
+def test_group_repaints_a_strip_whose_frame_pixels_are_parked(gpu):
+    """Frame pixels (a mask of a lower region), then an overlapping opacity group
+    that first puts coverage on the same strips and then covers them with an
+    opaque box: the strips are one colour again, but their LDS slots no longer
+    hold the frame's pixels (found by the random lists once they had big boxes)."""
+    W, H = 192, 48
+    atlas = scenes.AtlasBuilder()
+    rng = np.random.default_rng(5)
+    m = (rng.integers(0, 256, (40, 150)) * (rng.random((40, 150)) < 0.7)).astype(np.uint8)
+    buf = np.zeros((40, 154), np.uint8); buf[:, :150] = m
+    off = atlas.put(buf, lead=4)
+    prims = [
+        # region 0 (no group): background box + a big mask -> frame strips in LDS
+        (F.OP_RECT, F.RULE_PIXMAN, 0, 0, 0, W, H, 0x80402010, 0, 0, W * 256, H * 256),
+        (F.OP_MASK, F.RULE_PIXMAN, 0, 10, 4, 160, 44, 0xc0a05030, off, 154, 10, 4),
+        # region 1: a group over it
+        (F.OP_GROUP_BEGIN, 0, 0, 0, 0, W, H, 0, 0, 0, 0, 0),
+        (F.OP_RECT, F.RULE_PIXMAN, 0, 0, 0, W, H, 0x60102030, 0, 0, W * 256, H * 256),
+        (F.OP_MASK, F.RULE_PIXMAN, 0, 20, 2, 170, 42, 0xff204060, off, 154, 20, 2),
+        (F.OP_RECT, F.RULE_PIXMAN, 0, 0, 8, W, 40, 0xff807060, 0, 8 * 256, W * 256, 40 * 256),
+        (F.OP_MASK, F.RULE_LERP, 0, 30, 20, 180, 48, 0xff000000, off, 154, 30, 20),
+        (F.OP_GROUP_END, 0, 150, 0, 0, W, H, 0, 0, 0, 0, 0),
+    ]
+    P = np.array(prims, F.PRIM_DTYPE)
+    R = np.array([(0, 0, W, H, 0, 2), (0, 0, W, H, 2, 6)], F.REGION_DTYPE)
+    A = atlas.finish()
     assert np.array_equal(gpu.hip_render(W, H, R, P, A), O.render(W, H, R, P, A))
 
 
