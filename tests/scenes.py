@@ -30,6 +30,8 @@ class AtlasBuilder:
 
 
 def _premul(rng, opaque=None):
+    if opaque is None and rng.random() < 0.08:
+        return 0xff000000           # opaque black: the usual outline, a variant of its own
     a = 255 if opaque else int(rng.integers(1, 256))
     if opaque is None and rng.random() < 0.3:
         a = 255
