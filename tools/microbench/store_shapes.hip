@@ -124,6 +124,59 @@ static void run (const char *name, uint8_t *buf, int frames)
   printf ("%-10s tile %4dx%-3d : %.2f us / frame, %.0f GB/s\n", name, TW, TH, ms * 1e3 / reps / frames, fb * (double) frames * reps / (ms * 1e-3) / 1e9);
 }
 
+// workgroups of WAVES independent waves, each a 64x16 tile; the tiles of a workgroup
+// are adjacent in x (ALONG_X) or stacked in y; XCD: frame f goes to XCD f % 8 as a
+// whole (workgroup index round robin over XCDs), like the compositor's mapping
+template <int WAVES, bool ALONG_X, bool XCD>
+__global__ __launch_bounds__ (64 * WAVES) void fill_wg (uint8_t *dst, size_t stride, size_t frame_bytes,
+    int frames)
+{
+  constexpr int TX = 60, TY = 135;      // 3840x2160 in 64x16 tiles
+  constexpr int GX = ALONG_X ? TX / WAVES : TX, GY = ALONG_X ? TY : (TY + WAVES - 1) / WAVES;
+  const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+  int b = blockIdx.x, f;
+  if (XCD) {
+    const int xcd = b & 7, i = b >> 3;
+    f = xcd + 8 * (i / (GX * GY));
+    b = i % (GX * GY);
+  } else {
+    f = b / (GX * GY);
+    b = b % (GX * GY);
+  }
+  if (f >= frames)
+    return;
+  const int gx = b % GX, gy = b / GX;
+  const int tx = ALONG_X ? gx * WAVES + wave : gx, ty = ALONG_X ? gy : gy * WAVES + wave;
+  if (ty >= TY)
+    return;
+  const int x = tx * 64 + (lane % 16) * 4, y = ty * 16 + lane / 16;
+  const u32x4 v = { 0u, 0u, 0u, 0u };
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+    __builtin_nontemporal_store (v, reinterpret_cast<u32x4 *> (dst + f * frame_bytes + (size_t) (y + 4 * r) * stride + (size_t) x * 4));
+}
+
+template <int WAVES, bool ALONG_X, bool XCD>
+static void run_wg (const char *name, uint8_t *buf, int frames)
+{
+  constexpr int TX = 60, TY = 135;
+  constexpr int GX = ALONG_X ? TX / WAVES : TX, GY = ALONG_X ? TY : (TY + WAVES - 1) / WAVES;
+  const size_t fb = (size_t) 3840 * 2160 * 4;
+  const int grid = GX * GY * frames;
+  hipEvent_t a, b;
+  hipEventCreate (&a); hipEventCreate (&b);
+  for (int it = 0; it < 3; it++)
+    hipLaunchKernelGGL ((fill_wg<WAVES, ALONG_X, XCD>), dim3 (grid), dim3 (64 * WAVES), 0, 0, buf, (size_t) 3840 * 4, fb, frames);
+  hipEventRecord (a);
+  const int reps = 20;
+  for (int it = 0; it < reps; it++)
+    hipLaunchKernelGGL ((fill_wg<WAVES, ALONG_X, XCD>), dim3 (grid), dim3 (64 * WAVES), 0, 0, buf, (size_t) 3840 * 4, fb, frames);
+  hipEventRecord (b);
+  hipEventSynchronize (b);
+  float ms; hipEventElapsedTime (&ms, a, b);
+  printf ("%-34s: %.0f GB/s\n", name, fb * (double) frames * reps / (ms * 1e-3) / 1e9);
+}
+
 int main ()
 {
   const int frames = 32;
@@ -137,6 +190,13 @@ int main ()
   run_var<1> ("64x16 nt, 8192 persistent", buf, frames, 8192);
   run_var<1> ("64x16 nt, 16384 persistent", buf, frames, 16384);
   run_var<2> ("64x16 plain, 8192 persistent", buf, frames, 8192);
+  run_wg<1, true, false> ("64x16, 1 wave/WG", buf, frames);
+  run_wg<1, true, true> ("64x16, 1 wave/WG, frame per XCD", buf, frames);
+  run_wg<4, true, false> ("64x16, 4 waves/WG along x", buf, frames);
+  run_wg<4, true, true> ("64x16, 4 waves/WG along x, XCD", buf, frames);
+  run_wg<2, true, true> ("64x16, 2 waves/WG along x, XCD", buf, frames);
+  run_wg<4, false, true> ("64x16, 4 waves/WG along y, XCD", buf, frames);
+  run_wg<4, false, false> ("64x16, 4 waves/WG along y", buf, frames);
   run_linear<64, 4> ("linear 4 KB per wave", buf, frames);
   run_linear<64, 16> ("linear 16 KB per wave", buf, frames);
   run_linear<256, 4> ("linear 16 KB per 4-wave WG", buf, frames);
