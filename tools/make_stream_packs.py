@@ -19,7 +19,7 @@ import gstenv            # noqa: E402
 import pyflutl as F      # noqa: E402
 import scene_pack        # noqa: E402
 
-N_STATES = 32
+N_STATES = 64
 
 
 def main():
