@@ -3,7 +3,7 @@
 REFERENCE plugin and recorded by the fluttml-hip element (record-only, CPU) + composited
 by the oracle; every frame must be bit-identical.  Builder container (needs oracle/_ref).
 
-    python tools/fuzz_ttml.py [first_seed [count]]
+    [FUZZ_SCALE=k] python tools/fuzz_ttml.py [first_seed [count]]
 """
 import os
 import random
@@ -155,12 +155,19 @@ def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 50
     bad = []
+    # FUZZ_SCALE=k: the same documents with every px length multiplied by k on a frame
+    # k times as large (fonts of 30-100 px at k = 3: other hinting, wider outlines)
+    scale = int(os.environ.get("FUZZ_SCALE", "1"))
     for seed in range(first, first + count):
         doc = gen(seed)
+        if scale != 1:
+            import re
+            doc = re.sub(r'(\d+(?:\.\d+)?)px',
+                         lambda m: ("%g" % (float(m.group(1)) * scale)) + "px", doc)
         with tempfile.NamedTemporaryFile("w", suffix=".ttml", delete=False) as f:
             f.write(doc)
         try:
-            ok, ref, pk = compare_ref.compare(f.name, 320, 180, verbose=False)
+            ok, ref, pk = compare_ref.compare(f.name, 320 * scale, 180 * scale, verbose=False)
             note = f"{len(ref)} frames"
         except Exception as e:      # noqa: BLE001
             ok, note = None, "ERROR " + repr(e)[:200]
@@ -168,7 +175,7 @@ def main():
               flush=True)
         if not ok:
             bad.append(seed)
-            keep = os.path.join(tempfile.gettempdir(), f"fuzz_{seed}.ttml")
+            keep = os.path.join(tempfile.gettempdir(), f"fuzz_{seed}.ttml" if scale == 1 else f"fuzz_x{scale}_{seed}.ttml")
             os.replace(f.name, keep)
             print("   kept", keep)
         else:
