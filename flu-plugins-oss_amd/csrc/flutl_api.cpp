@@ -480,7 +480,7 @@ extern "C" int flutl_render (flutl_ctx *c, const flutl_list *l, void *dst_dev,
 static int render_lists_to_host (flutl_ctx *c, uint32_t width, uint32_t height,
     const flutl_region *regions_dev, uint32_t n_regions, const flutl_prim *prims_dev,
     void *dst_host, size_t dst_stride_bytes, const uint32_t *bands = nullptr,
-    uint32_t n_bands = 0);
+    uint32_t n_bands = 0, uint32_t col0 = 0, uint32_t col1 = 0);
 
 extern "C" int flutl_render_frame_to_host (flutl_ctx *c, uint32_t width,
     uint32_t height, const flutl_region *regions, uint32_t n_regions,
@@ -496,7 +496,18 @@ extern "C" int flutl_render_frame_rows_to_host (flutl_ctx *c, uint32_t width,
     const flutl_prim *prims, uint32_t n_prims, void *dst_host,
     size_t dst_stride_bytes, const uint32_t *row_bands, uint32_t n_bands)
 {
-  if (!c || !dst_host || dst_stride_bytes < (size_t) width * 4 || (n_bands && !row_bands))
+  return flutl_render_frame_window_to_host (c, width, height, regions, n_regions, prims,
+      n_prims, dst_host, dst_stride_bytes, row_bands, n_bands, 0, width);
+}
+
+extern "C" int flutl_render_frame_window_to_host (flutl_ctx *c, uint32_t width,
+    uint32_t height, const flutl_region *regions, uint32_t n_regions,
+    const flutl_prim *prims, uint32_t n_prims, void *dst_host,
+    size_t dst_stride_bytes, const uint32_t *row_bands, uint32_t n_bands,
+    uint32_t col0, uint32_t col1)
+{
+  if (!c || !dst_host || dst_stride_bytes < (size_t) width * 4 || (n_bands && !row_bands) ||
+      col0 >= col1 || col1 > width)
     return FLUTL_EINVAL;
   for (uint32_t i = 0; i < n_bands; i++)
     if (row_bands[2 * i] >= row_bands[2 * i + 1] || row_bands[2 * i + 1] > height)
@@ -513,7 +524,7 @@ extern "C" int flutl_render_frame_rows_to_host (flutl_ctx *c, uint32_t width,
   // (the final stream synchronise also covers the H2D of the caller's pageable
   // list memory, which hipMemcpyAsync stages before returning)
   return render_lists_to_host (c, width, height, rd, n_regions, pd, dst_host,
-      dst_stride_bytes, row_bands, n_bands);
+      dst_stride_bytes, row_bands, n_bands, col0, col1);
 }
 
 /* Copy a (validated) display list into the context's reusable list buffer. */
@@ -563,8 +574,11 @@ extern "C" int flutl_render_to_host (flutl_ctx *c, const flutl_list *l,
 
 static int render_lists_to_host (flutl_ctx *c, uint32_t width, uint32_t height,
     const flutl_region *regions_dev, uint32_t n_regions, const flutl_prim *prims_dev,
-    void *dst_host, size_t dst_stride_bytes, const uint32_t *bands, uint32_t n_bands)
+    void *dst_host, size_t dst_stride_bytes, const uint32_t *bands, uint32_t n_bands,
+    uint32_t col0, uint32_t col1)
 {
+  if (col1 == 0)
+    col1 = width;
   struct { uint32_t width, height, n_regions; const flutl_region *regions;
     const flutl_prim *prims; } lv = { width, height, n_regions, regions_dev, prims_dev };
   const auto *l = &lv;
@@ -585,8 +599,8 @@ static int render_lists_to_host (flutl_ctx *c, uint32_t width, uint32_t height,
       l->regions, l->n_regions, l->prims, c->atlas);
   if (rc)
     return rc;
-  // whole frame, or only the caller's row bands (dirty-rectangle copy: the
-  // caller guarantees the rest of dst_host already holds what it should)
+  // whole frame, or only the caller's row bands and columns (dirty-rectangle
+  // copy: the caller guarantees the rest of dst_host already holds what it should)
   const uint32_t whole[2] = { 0, l->height };
   if (!n_bands) {
     bands = whole;
@@ -595,12 +609,15 @@ static int render_lists_to_host (flutl_ctx *c, uint32_t width, uint32_t height,
   bool ok = true;
   for (uint32_t i = 0; i < n_bands && ok; i++) {
     const uint32_t y0 = bands[2 * i], rows = bands[2 * i + 1] - y0;
-    uint8_t *d = static_cast<uint8_t *> (dst_host) + (size_t) y0 * dst_stride_bytes;
-    const uint8_t *sp = static_cast<const uint8_t *> (c->frame) + (size_t) y0 * tight;
-    if (dst_stride_bytes == tight)
+    uint8_t *d = static_cast<uint8_t *> (dst_host) + (size_t) y0 * dst_stride_bytes +
+        (size_t) col0 * 4;
+    const uint8_t *sp = static_cast<const uint8_t *> (c->frame) + (size_t) y0 * tight +
+        (size_t) col0 * 4;
+    const size_t wbytes = (size_t) (col1 - col0) * 4;
+    if (dst_stride_bytes == tight && wbytes == tight)
       ok = hip_ok (hipMemcpyAsync (d, sp, tight * rows, hipMemcpyDeviceToHost, c->stream));
     else
-      ok = hip_ok (hipMemcpy2DAsync (d, dst_stride_bytes, sp, tight, tight, rows,
+      ok = hip_ok (hipMemcpy2DAsync (d, dst_stride_bytes, sp, tight, wbytes, rows,
           hipMemcpyDeviceToHost, c->stream));
   }
   if (!hip_ok (hipStreamSynchronize (c->stream)) || !ok)

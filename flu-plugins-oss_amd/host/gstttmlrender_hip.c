@@ -75,7 +75,7 @@ enum
  * regions plus the block's previous bands are copied from the device (which
  * renders the whole frame in HBM anyway): typical subtitles cover a fifth of
  * the frame, and the 33 MB PCIe copy is what bounds the element.  The memory is
- * handed out READONLY so that nobody scribbles outside the remembered bands
+ * handed out READONLY so that nobody scribbles outside the remembered bands and columns
  * (a downstream element that wants to write makes its copy, as GStreamer's
  * writability rules require anyway).  FLUTL_FULL_D2H=1 restores whole-frame
  * copies into writable memory. */
@@ -86,6 +86,7 @@ typedef struct
   gpointer block;
   guint n_bands;
   guint32 bands[2 * MAX_BANDS];   /* [y0, y1) pairs, sorted, disjoint */
+  guint32 cols[2];                /* [x0, x1): the columns written in those rows */
 } FrameSlot;
 
 typedef struct
@@ -1557,13 +1558,27 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
       memcpy (now, bands, sizeof (guint32) * 2 * n_now);
       memcpy (bands + 2 * n_now, slot->bands, sizeof (guint32) * 2 * slot->n_bands);
       n = bands_normalise (bands, n_now + slot->n_bands);
-      if (n == 0)     /* nothing now, nothing before: the block is already the frame */
+      /* ... and of those rows the columns any region reaches, now or before */
+      guint32 c0 = (guint32) width, c1 = 0, c0_now, c1_now;
+      for (i = 0; i < n_rg; i++) {
+        c0 = MIN (c0, (guint32) CLAMP (rg[i].x0, 0, width));
+        c1 = MAX (c1, (guint32) CLAMP (rg[i].x1, 0, width));
+      }
+      c0_now = c0;
+      c1_now = c1;
+      if (slot->n_bands) {
+        c0 = MIN (c0, slot->cols[0]);
+        c1 = MAX (c1, slot->cols[1]);
+      }
+      if (n == 0 || c0 >= c1)     /* nothing now, nothing before: the block is already the frame */
         rc = FLUTL_OK;
       else
-        rc = flutl_render_frame_rows_to_host (priv->ctx, width, height, rg, n_rg, pr, n_pr,
-            slot->block, (size_t) width * 4, bands, n);
+        rc = flutl_render_frame_window_to_host (priv->ctx, width, height, rg, n_rg, pr, n_pr,
+            slot->block, (size_t) width * 4, bands, n, c0, c1);
       memcpy (slot->bands, now, sizeof (guint32) * 2 * n_now);
       slot->n_bands = n_now;
+      slot->cols[0] = c0_now;
+      slot->cols[1] = c1_now;
       g_free (bands);
     } else if (buffer) {
       rc = flutl_render_frame_to_host (priv->ctx, width, height, rg, n_rg, pr, n_pr,

@@ -49,7 +49,7 @@ EXPORTS = [
     "flutl_list_create", "flutl_list_destroy",
     "flutl_render", "flutl_render_to_host",
     "flutl_host_alloc", "flutl_host_free", "flutl_render_frame_to_host",
-    "flutl_render_frame_rows_to_host",
+    "flutl_render_frame_rows_to_host", "flutl_render_frame_window_to_host",
     "flutl_atlas_put_blurred",
 ]
 
@@ -99,6 +99,8 @@ def lib():
         L.flutl_render_frame_to_host.argtypes = [vp, u32, u32, vp, u32, vp, u32, vp, sz]
         L.flutl_render_frame_rows_to_host.argtypes = [vp, u32, u32, vp, u32, vp, u32, vp, sz,
                                                       vp, u32]
+        L.flutl_render_frame_window_to_host.argtypes = [vp, u32, u32, vp, u32, vp, u32, vp, sz,
+                                                        vp, u32, u32, u32]
         L.flutl_atlas_put_blurred.argtypes = [vp, u32, u32, vp, u32, vp, u32, ctypes.c_int,
                                               ctypes.c_double, u32, u32, vp, ctypes.c_int,
                                               vp, ctypes.POINTER(u32)]
@@ -260,16 +262,23 @@ class Context:
                "flutl_render_to_host")
         return out
 
-    def render_frame_rows_into(self, width, height, regions, prims, out, bands):
+    def render_frame_rows_into(self, width, height, regions, prims, out, bands, cols=None):
         """dirty-rectangle form: only the row bands [(y0, y1), ...] of `out` (a C-contiguous
-        (height, width) uint32 array) are written"""
+        (height, width) uint32 array) are written -- and of those only the columns
+        cols = (x0, x1), if given"""
         regions = np.ascontiguousarray(regions, REGION_DTYPE)
         prims = np.ascontiguousarray(prims, PRIM_DTYPE)
         b = np.ascontiguousarray(bands, np.uint32).reshape(-1)
-        _check(lib().flutl_render_frame_rows_to_host(
-            self._h, width, height, _np_ptr(regions), len(regions), _np_ptr(prims),
-            len(prims), _np_ptr(out), width * 4, _np_ptr(b) if b.size else None,
-            b.size // 2), "flutl_render_frame_rows_to_host")
+        if cols is None:
+            _check(lib().flutl_render_frame_rows_to_host(
+                self._h, width, height, _np_ptr(regions), len(regions), _np_ptr(prims),
+                len(prims), _np_ptr(out), width * 4, _np_ptr(b) if b.size else None,
+                b.size // 2), "flutl_render_frame_rows_to_host")
+        else:
+            _check(lib().flutl_render_frame_window_to_host(
+                self._h, width, height, _np_ptr(regions), len(regions), _np_ptr(prims),
+                len(prims), _np_ptr(out), width * 4, _np_ptr(b) if b.size else None,
+                b.size // 2, cols[0], cols[1]), "flutl_render_frame_window_to_host")
 
     def render_frame_to_host(self, width, height, regions, prims, pinned=True):
         """the element's per-buffer call; with pinned=True the frame lands in

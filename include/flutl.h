@@ -275,6 +275,13 @@ int  flutl_render_frame_rows_to_host (flutl_ctx *ctx, uint32_t width, uint32_t h
     const flutl_prim *prims, uint32_t n_prims,
     void *dst_host, size_t dst_stride_bytes,
     const uint32_t *row_bands, uint32_t n_bands);
+/* ... and of those rows only the columns [col0, col1): the regions of a subtitle
+ * frame rarely reach the left and right borders of the picture. */
+int  flutl_render_frame_window_to_host (flutl_ctx *ctx, uint32_t width, uint32_t height,
+    const flutl_region *regions, uint32_t n_regions,
+    const flutl_prim *prims, uint32_t n_prims,
+    void *dst_host, size_t dst_stride_bytes,
+    const uint32_t *row_bands, uint32_t n_bands, uint32_t col0, uint32_t col1);
 
 /* Page-locked host memory for output frames: a D2H copy into it is a true
  * asynchronous DMA at PCIe rate (pageable memory goes through a bounce buffer

@@ -319,6 +319,15 @@ def test_context_row_band_copy_leaves_other_rows_alone(gpu):
         assert (out[~inside] == 0xDEADBEEF).all()
         ctx.render_frame_rows_into(W, H, R, P, out, [])       # no bands: whole frame
         assert np.array_equal(out, exp)
+        # ... and a column window of those bands
+        out[:] = 0xDEADBEEF
+        ctx.render_frame_rows_into(W, H, R, P, out, bands, cols=(17, 250))
+        win = np.zeros((H, W), bool)
+        win[inside, 17:250] = True
+        assert np.array_equal(out[win], exp[win])
+        assert (out[~win] == 0xDEADBEEF).all()
+        with pytest.raises(F.FlutlError):
+            ctx.render_frame_rows_into(W, H, R, P, out, bands, cols=(10, W + 1))
 
 
 def test_contexts_on_concurrent_threads(gpu):
