@@ -83,12 +83,7 @@ __device__ __forceinline__ u16x2 mul_un8 (u16x2 x, u16x2 a)
   u16x2 t = x * a + (u16x2) (0x80);
   return (t + (t >> 8)) >> 8;
 }
-// cairo mul8_8 (cairo-image-compositor.c): same with ONE_HALF = 0x7f
-__device__ __forceinline__ u16x2 mul_7f (u16x2 x, u16x2 a)
-{
-  u16x2 t = x * a + (u16x2) (0x7f);
-  return (t + (t >> 8)) >> 8;
-}
+// (cairo's mul8_8, cairo-image-compositor.c, is the same with ONE_HALF = 0x7f: mul_rnd below)
 __device__ __forceinline__ u16x2 add_sat (u16x2 a, u16x2 b)
 {
   return __builtin_elementwise_min ((u16x2) (a + b), (u16x2) (255));
@@ -101,28 +96,6 @@ __device__ __forceinline__ void over (Px &d, Px s)
   u16x2 ia = splat (255u - a);
   d.rb = add_sat (s.rb, mul_un8 (d.rb, ia));
   d.ag = add_sat (s.ag, mul_un8 (d.ag, ia));
-}
-
-// d = (s IN m) OVER d   -- pixman over_n_8_8888 / glyph compositing
-// Branch free: m == 0 gives sm = 0 and 0 OVER d == d exactly (MUL_UN8 (x, 255)
-// == x), so lanes without coverage need no early-out.
-__device__ __forceinline__ void blend_pixman (Px &d, Px s, uint32_t m)
-{
-  u16x2 mm = splat (m);
-  Px sm;
-  sm.rb = mul_un8 (s.rb, mm);
-  sm.ag = mul_un8 (s.ag, mm);
-  over (d, sm);
-}
-
-// cairo in-place lerp for opaque solid sources (0x7f rounding)
-// Branch free as well: mul_7f (x, 255) == x and mul_7f (x, 0) == 0, so m == 0
-// leaves d and m == 255 yields s exactly, as cairo's special cases do.
-__device__ __forceinline__ void blend_lerp (Px &d, Px s, uint32_t m)
-{
-  u16x2 mm = splat (m), im = splat (255u - m);
-  d.rb = add_sat (mul_7f (s.rb, mm), mul_7f (d.rb, im));
-  d.ag = add_sat (mul_7f (s.ag, mm), mul_7f (d.ag, im));
 }
 
 // cairo rectangular scan converter: overlap of [lo,hi) (24.8) with pixel p
@@ -210,25 +183,6 @@ __device__ __forceinline__ PrimU prim_decode (const PrimRaw &q)
   return p;
 }
 
-__device__ __forceinline__ PrimU prim_from_lane (const uint4 &lo, const uint4 &hi, int l)
-{
-  const uint32_t w0 = rdl (lo.x, l), w1 = rdl (lo.y, l), w2 = rdl (lo.z, l);
-  PrimU p;
-  p.op = w0 & 0xffu;
-  p.rule = (w0 >> 8) & 0xffu;
-  p.param = w0 >> 16;
-  p.cx0 = (int16_t) (w1 & 0xffffu);
-  p.cy0 = (int16_t) (w1 >> 16);
-  p.cx1 = (int16_t) (w2 & 0xffffu);
-  p.cy1 = (int16_t) (w2 >> 16);
-  p.color = rdl (lo.w, l);
-  p.a = (int) rdl (hi.x, l);
-  p.b = (int) rdl (hi.y, l);
-  p.c = (int) rdl (hi.z, l);
-  p.d = (int) rdl (hi.w, l);
-  return p;
-}
-
 // The strip's 4 pixels per lane are kept UNPACKED (rb / ag, 2 x 16 bit each):
 // a primitive then costs no unpack/pack, only the final store packs.
 
@@ -256,39 +210,6 @@ __device__ __forceinline__ void px_pixman (Px &t, Px s, uint32_t w)
     ia = as_u16x2 (0x00ff00ffu - __builtin_amdgcn_perm (0u, as_u32 (sm_ag), 0x0c020c02u));
   t.rb = sm_rb + mul_un8 (t.rb, ia);
   t.ag = sm_ag + mul_un8 (t.ag, ia);
-}
-
-// cairo in-place lerp (0x7f rounding); mul_7f (255, m) == m, so the sum never
-// exceeds 255 either.  BLACK: the colour is opaque black (the usual outline),
-// s * m is then {0, 0, 0, m} without a multiplication.
-template <bool BLACK, int K>
-__device__ __forceinline__ void px_lerp (Px &t, Px s, uint32_t w)
-{
-  const u16x2 mm = splat_byte<K> (w);
-  const u16x2 im = as_u16x2 (as_u32 (mm) ^ 0x00ff00ffu);
-  if (BLACK) {
-    t.rb = mul_7f (t.rb, im);
-    t.ag = as_u16x2 (as_u32 (mm) & 0xffff0000u) + mul_7f (t.ag, im);
-  } else {
-    t.rb = mul_7f (s.rb, mm) + mul_7f (t.rb, im);
-    t.ag = mul_7f (s.ag, mm) + mul_7f (t.ag, im);
-  }
-}
-
-template <bool LERP, bool FLAG>
-__device__ __forceinline__ void strip_blend (Px (&t)[4], Px s, uint32_t w)
-{
-  if (LERP) {
-    px_lerp<FLAG, 0> (t[0], s, w);
-    px_lerp<FLAG, 1> (t[1], s, w);
-    px_lerp<FLAG, 2> (t[2], s, w);
-    px_lerp<FLAG, 3> (t[3], s, w);
-  } else {
-    px_pixman<FLAG, 0> (t[0], s, w);
-    px_pixman<FLAG, 1> (t[1], s, w);
-    px_pixman<FLAG, 2> (t[2], s, w);
-    px_pixman<FLAG, 3> (t[3], s, w);
-  }
 }
 
 // The blend of a whole primitive is chosen ONCE (kernel: BLEND_STRIPS), not per
@@ -455,29 +376,6 @@ __device__ __forceinline__ uint4 park_load (const uint8_t *o, bool whole, int nx
         e[k] = q[k];
   }
   return make_uint4 (e[0], e[1], e[2], e[3]);
-}
-
-// blend one strip (4 packed pixels of the lane) with coverage dword w
-__device__ __forceinline__ void strip_apply (uint4 &v, const PrimU &p, uint32_t w)
-{
-#if FLUTL_EXP == 1   // ablation: no blend arithmetic
-  v.x ^= w;
-  return;
-#endif
-  Px t[4] = { unpack (v.x), unpack (v.y), unpack (v.z), unpack (v.w) };
-  const Px s = unpack (p.color);
-  if (p.rule == FLUTL_RULE_LERP) {
-    if (p.color == 0xff000000u)
-      strip_blend<true, true> (t, s, w);
-    else
-      strip_blend<true, false> (t, s, w);
-  } else {
-    if ((p.color >> 24) == 255u)
-      strip_blend<false, true> (t, s, w);
-    else
-      strip_blend<false, false> (t, s, w);
-  }
-  v = make_uint4 (pack (t[0]), pack (t[1]), pack (t[2]), pack (t[3]));
 }
 
 __device__ __forceinline__ uint4 splat4 (uint32_t c)
