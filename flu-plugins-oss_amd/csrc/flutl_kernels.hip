@@ -8,23 +8,22 @@
 // scan converter) -- bit exact, integer only.  No MFMA: this is byte-wise
 // blending bound by HBM stores.
 //
-// Work decomposition (see DESIGN.md for the measurements behind it)
-//   * the blend granule is the 64x8 output tile: a wave instruction covers a
-//     64x4 strip, lane l owning the 4 adjacent pixels (16 bytes) at column
-//     4*(l%16), row l/16, so a wave store writes four 256-byte row segments;
-//   * one workgroup (2 wavefronts) owns a 64x32 "supertile" = 4 stacked tiles:
-//     region culling and primitive binning are done once per supertile and
-//     each lane carries 4 row groups, which amortises the dependent
-//     round trips (region table -> primitives -> mask bytes) that bound a
-//     one-tile-per-workgroup kernel (v1: 41 us/4K frame, latency bound);
-//   * every output pixel is written exactly once, from registers (there is no
-//     clear pass and no read of the destination);
-//   * supertiles are dealt to XCDs in contiguous bands (blocks b and b+8 share
-//     an XCD's L2), so a band's glyph masks are fetched into one L2 only;
-//   * regions are culled 64 at a time (one per lane + ballot), a region's
-//     primitives are binned by the 128 lanes in parallel (ballot + prefix
-//     popcount -> ordered, compacted 32-byte prims in LDS), then replayed in
-//     paint order with the next primitive's mask bytes already in flight.
+// Work decomposition (DESIGN.md 5 has the measurements behind every choice)
+//   * one wavefront = one workgroup = one 64x16 "supertile" (two stacked 64x8
+//     tiles of the north star): a wave instruction covers a 64x4 strip, lane l
+//     owning the 4 adjacent pixels (16 bytes) at column 4*(l%16), row l/16, so a
+//     wave store writes four 256-byte row segments; 4 strips per wave;
+//   * every output pixel is written exactly once (no clear pass, no read of the
+//     destination); the supertile's pixels live in 4 KB of LDS, lane-private
+//     16-byte slots, so no barrier and no bank conflict;
+//   * strips that only background boxes have met are not pixels at all but one
+//     colour in a scalar register ("uniform"), through opacity groups as well;
+//   * regions are culled 64 at a time (one per lane + ballot); a hit region's
+//     primitives are loaded 64 at a time, one per lane, bbox-tested, balloted,
+//     and the hits replayed in paint order, each broadcast to SGPRs by
+//     v_readlane, with the next hit's mask bytes already in flight;
+//   * workgroups are dealt to the 8 XCDs round robin: whole frames per XCD for
+//     batches, interleaved supertile rows otherwise (see the kernel).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
