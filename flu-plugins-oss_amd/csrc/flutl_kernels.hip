@@ -115,10 +115,10 @@ struct FrameParams {
   uint64_t stride;                      // bytes
 };
 
-// Workgroup footprint: a 64 x 32 "supertile" = four stacked 64x8 output tiles.
-// Wave w owns rows [16w, 16w+16); lane l owns, in each of the wave's 4 row
-// groups r, the 4 pixels at column 4*(l%16), row 4*r + l/16 -- so one store
-// instruction of a wave writes four 256-byte row segments.
+// Workgroup (= wave) footprint: a 64 x 16 "supertile" = two stacked 64x8 output
+// tiles = kRG strips of 4 rows.  Lane l owns, in each strip r, the 4 pixels at
+// column 4*(l%16), row 4*r + l/16 -- so one store instruction of the wave
+// writes four 256-byte row segments.
 constexpr int kSuperW = FLUTL_TILE_W;        // 64
 #ifndef FLUTL_KRG
 #define FLUTL_KRG 4
