@@ -404,6 +404,11 @@ __device__ __forceinline__ uint32_t uniform_over (uint32_t d, uint32_t s)
 #ifndef FLUTL_WAVES
 #define FLUTL_WAVES 6
 #endif
+// strips a primitive must meet in their uniform state for the coverage lookup
+// table to be made (1 ... 4: within 0.5 % of each other on cfg2, which is write bound)
+#ifndef FLUTL_LUT_MIN
+#define FLUTL_LUT_MIN 2
+#endif
 // VIDEO: the finished overlay pixel is composited OVER the pixel of a video
 // frame (same geometry as dst) in the store epilogue -- the "blend over the
 // video buffer" of the north star, fused so that the overlay never exists in
@@ -713,7 +718,7 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
 #if FLUTL_EXP == 10      // ablation: no lookup table
               lmask = 0u;
 #endif
-              if (__builtin_popcount (lmask) < 2)
+              if (__builtin_popcount (lmask) < FLUTL_LUT_MIN)
                 lmask = 0u;           // one strip: the table would cost more than it saves
               cmask &= ~lmask;
 #define BLEND_STRIPS(V) \
