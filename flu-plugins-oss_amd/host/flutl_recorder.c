@@ -1158,6 +1158,20 @@ raster_prepare (FlutlRecorder *rec, int fill, RasterBox *rb)
   int ox, oy;
   raster_origin (rec, &ox, &oy);
   cairo_new_path (cr);
+  /* The reference builds its path on a context that carries the region's clip,
+   * and cairo_glyph_path DROPS glyphs whose origin lies more than 10 font sizes
+   * outside surface extents x clip extents (_cairo_gstate_transform_glyphs_to_
+   * backend) -- the far end of a noWrap line that runs a long way out of its
+   * region.  Missing or not, they lie outside the clip; but their edges share
+   * rows with the visible ones, and Cairo's coverage is not independent of
+   * that (found by tools/fuzz_ttml.py at FUZZ_SCALE=2).  So the path is built
+   * under the same bounds. */
+  current_limits (rec, rb->lim);
+  cairo_save (cr);
+  cairo_identity_matrix (cr);
+  cairo_rectangle (cr, rb->lim[0], rb->lim[1], rb->lim[2] - rb->lim[0], rb->lim[3] - rb->lim[1]);
+  cairo_clip (cr);
+  cairo_new_path (cr);
   /* CTM coordinates -> raster coordinates; nothing to do (and no rounding of
    * m.x0) where the CTM already is the reference's own */
   ox -= rec->shift[0];
@@ -1185,6 +1199,7 @@ raster_prepare (FlutlRecorder *rec, int fill, RasterBox *rb)
     }
     cairo_restore (cr);
   }
+  cairo_restore (cr);           /* the clip goes, the path stays */
   double ex1, ey1, ex2, ey2;
   cairo_save (cr);
   cairo_identity_matrix (cr);            /* extents in device space */
@@ -1193,7 +1208,6 @@ raster_prepare (FlutlRecorder *rec, int fill, RasterBox *rb)
   else
     cairo_stroke_extents (cr, &ex1, &ey1, &ex2, &ey2);
   cairo_restore (cr);
-  current_limits (rec, rb->lim);
   rb->inside = ex1 >= rb->lim[0] + 3 && ey1 >= rb->lim[1] + 3 && ex2 <= rb->lim[2] - 3 &&
       ey2 <= rb->lim[3] - 3;
   rb->ext[0] = (int) floor (ex1);

@@ -14,6 +14,7 @@
     python tools/make_goldens.py [scenes] [cfg0 cfg1 cfg2 cfg4]
 """
 import hashlib
+import re
 import json
 import os
 import subprocess
@@ -56,6 +57,8 @@ def scenes(gpu=False):
     for name in sorted(f[:-5] for f in os.listdir(d)
                        if f.endswith(".ttml") and f.startswith("g" if gpu else "k")):
         ttml = os.path.join(d, name + ".ttml")
+        m = re.search(r"frame:\s*(\d+)x(\d+)", open(ttml).read())     # <!-- frame: WxH -->
+        W, H = (int(m.group(1)), int(m.group(2))) if m else SCENE_SIZE
         ref = np.frombuffer(gstenv.render(gstenv.REF_PLUGIN_DIR, ttml, W, H),
                             np.uint32).reshape(-1, H, W)
         pk = record(ttml, W, H, gpu)
