@@ -197,9 +197,14 @@ static uint32_t
 atlas_put_dedup (FlutlRecorder *rec, const uint8_t *src, size_t bytes)
 {
   uint64_t h = hash_bytes (src, bytes);
+  /* (a child recorder keeps its own table of masks, but the bytes live in the
+   * parent's atlas, see atlas_put_ex) */
+  const FlutlRecorder *root = rec;
+  while (root->parent)
+    root = root->parent;
   for (uint32_t i = 0; i < rec->n_masks; i++)
     if (rec->masks[i].hash == h && rec->masks[i].bytes == bytes &&
-        memcmp (rec->atlas + rec->masks[i].offset, src, bytes) == 0)
+        memcmp (root->atlas + rec->masks[i].offset, src, bytes) == 0)
       return rec->masks[i].offset;
   if (rec->n_masks == rec->cap_masks) {
     rec->cap_masks = rec->cap_masks ? rec->cap_masks * 2 : 64;
@@ -392,6 +397,8 @@ flutl_recorder_paint_atlas_image (FlutlRecorder *rec, uint32_t offset, int w, in
     int x, int y)
 {
   target_touched (rec);
+  x += rec->shift[0];           /* (the position came from the CTM, see set_device_shift) */
+  y += rec->shift[1];
   int x0 = x, y0 = y, x1 = x + w, y1 = y + h;
   if (!clip_box (rec, &x0, &y0, &x1, &y1))
     return;

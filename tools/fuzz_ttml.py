@@ -20,6 +20,13 @@ FAMS = ["DejaVu Sans", "DejaVu Serif", "DejaVu Sans Mono", "sansSerif", "serif",
         "default"]
 
 
+# FUZZ_E2E=1 (GPU box): the element renders for real and its frames are compared with
+# the reference's byte for byte -- kernel, read-back and device-made atlas entries
+# included; only then are blurred outlines generated (they need the device)
+E2E = bool(os.environ.get("FUZZ_E2E"))
+BLUR = E2E
+
+
 def col(r, alpha=None):
     a = alpha if alpha is not None else r.choice([255, 255, 255, 192, 128, 64, 0])
     return "#%02X%02X%02X%02X" % (r.randrange(256), r.randrange(256), r.randrange(256), a)
@@ -93,8 +100,10 @@ def gen(seed):
             n = r.choice([1, 2, 4])
             a.append('tts:padding="%s"' % " ".join(length(r, 0, 12, ("px", "px", "%")) for _ in range(n)))
         if r.random() < 0.4:
-            a.append('tts:textOutline="%s %s"' % (r.choice(["black", col(r, 255), col(r)]),
-                                                   r.choice(["1px", "2px", "1.5px", "3px", "0.5px"])))
+            a.append('tts:textOutline="%s %s%s"' % (r.choice(["black", col(r, 255), col(r)]),
+                                                     r.choice(["1px", "2px", "1.5px", "3px", "0.5px"]),
+                                                     BLUR and r.random() < 0.5 and
+                                                     r.choice([" 1px", " 2px", " 3.5px", " 0.5px"]) or ""))
         if r.random() < 0.25:
             a.append(f'tts:zIndex="{r.randrange(-3, 4)}"')
         if r.random() < 0.15:
@@ -167,7 +176,15 @@ def main():
         with tempfile.NamedTemporaryFile("w", suffix=".ttml", delete=False) as f:
             f.write(doc)
         try:
-            ok, ref, pk = compare_ref.compare(f.name, 320 * scale, 180 * scale, verbose=False)
+            if E2E:
+                import gstenv
+                W, H = 320 * scale, 180 * scale
+                ref = gstenv.render(gstenv.REF_PLUGIN_DIR, f.name, W, H)
+                got = gstenv.render(gstenv.HIP_PLUGIN_DIR, f.name, W, H)
+                ok = ref == got
+                ref = range(len(ref) // (W * H * 4))
+            else:
+                ok, ref, pk = compare_ref.compare(f.name, 320 * scale, 180 * scale, verbose=False)
             note = f"{len(ref)} frames"
         except Exception as e:      # noqa: BLE001
             ok, note = None, "ERROR " + repr(e)[:200]
@@ -175,8 +192,10 @@ def main():
               flush=True)
         if not ok:
             bad.append(seed)
-            keep = os.path.join(tempfile.gettempdir(), f"fuzz_{seed}.ttml" if scale == 1 else f"fuzz_x{scale}_{seed}.ttml")
-            os.replace(f.name, keep)
+            keep = os.path.join(os.environ.get("FUZZ_KEEP_DIR", tempfile.gettempdir()),
+                                f"fuzz_{seed}.ttml" if scale == 1 else f"fuzz_x{scale}_{seed}.ttml")
+            import shutil
+            shutil.move(f.name, keep)
             print("   kept", keep)
         else:
             os.unlink(f.name)

@@ -53,7 +53,7 @@ def render(plugin_dir, ttml_path, width, height, out_path=None, extra_env=None,
         tmp.close()
         out_path = tmp.name
     sink_desc = f"filesink location={out_path}" if sink == "filesink" else "fakesink"
-    cmd = [os.path.join(CONDA, "bin", "gst-launch-1.0"), "-q",
+    cmd = [os.path.join(CONDA, "bin", "gst-launch-1.0"), "-q", "--no-fault",
            "filesrc", f"location={os.path.abspath(ttml_path)}", "!", "ttmlrender", "!",
            f"video/x-raw,width={width},height={height}", "!"] + sink_desc.split()
     # cwd: the reference's base class can append an XML dump to ./ttml.xml
