@@ -11,7 +11,17 @@ rank renders its own independent stream (weak scaling, no data-path
 collective); `--gather` adds the RCCL gather of finished frames to rank 0 that
 SURVEY §8(e) describes for the "single ordered output" case.
 
-Prints ONE JSON line on rank 0.
+`python bench.py --gpus N` with WORLD_SIZE unset starts its N ranks itself (N
+child processes, before anything touches the GPU); under torchrun it is one of
+the ranks.  Prints ONE JSON line on rank 0:
+  value         frames/s over EXACTLY --steps steps (barrier + synchronize on both sides)
+  value_steady  the same over a timed region of >= 0.5 s (a 20-step run is a 9 ms sample)
+  roofline      kernel time from HIP events around >= 400 launches, whatever --steps is:
+                mean (-> achieved, frac), median, p10, p90; traffic_frac = counter bytes
+                of the committed rocprofv3 PMC passes / kernel time / peak
+  cpu_baseline  the reference's own ttmlrender on the host cores (1 and all)
+  e2e           the drop-in element in a GStreamer pipeline, TTML in -> frames in host
+                memory, next to the reference on the same documents
 """
 import argparse
 import json
@@ -91,6 +101,85 @@ def profiled_traffic(cfg, batch):
     return int(t["write"] + t["fetch_raw"]) if t else None
 
 
+def self_launch(n):
+    """`--gpus N` without a launcher: N ranks as child processes, one per GPU,
+    started BEFORE this process imports torch or touches HIP (a process that has
+    initialised the GPU must not fork/exec workers on this pool).  Rank 0's child
+    prints the JSON line; the exit code is the worst of the children's."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(globals()['__file__'])] + sys.argv[1:],
+                                      env=env))
+    rc = 0
+    try:
+        for pr in procs:
+            rc = max(rc, abs(pr.wait()))
+            if rc:                      # a rank died: the others would wait for ever
+                break
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+                pr.wait()
+    return rc
+
+
+def e2e_block(W, H, cpu_baseline):
+    """The drop-in element end to end on the GPU box: filesrc ! ttmlrender ! caps !
+    fakesink (tools/e2e_timing.py), for the metric's document (cfg2: animated
+    attributes over static text) and for a typical stream (new outlined text in
+    every cue), with the reference's ttmlrender timed on the same documents."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import e2e_timing
+    import gstenv
+    if not gstenv.available(gstenv.HIP_PLUGIN_DIR):
+        return {"skipped": "GStreamer runtime or the element plugin not present"}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    log = os.path.join(ROOT, "gpurun_out", "e2e_bench.log")
+    open(log, "w").close()
+    out = {"pipeline": e2e_timing.PIPELINE.format(W=W, H=H),
+           "method": "(buffers - 1) / (end of first gen_buffer -> last frame complete in "
+                     "host memory); best of 2 runs after a warm-up run", "log": "gpurun_out/e2e_bench.log"}
+    for doc in ("cfg2", "typical_4k"):
+        ttml = os.path.join(ROOT, "bench_data", doc + ".ttml")
+        try:
+            e2e_timing.measure(ttml, W, H)                      # warm-up
+            runs = [e2e_timing.measure(ttml, W, H, log_path=log) for _ in range(2)]
+            best = max(runs, key=lambda r: r["frames_per_s"])
+            d = {"value": best["frames_per_s"], "unit": "frames/s", "buffers": best["buffers"],
+                 "host_record_us": best["record_us_per_buffer"],
+                 "device_us": best["device_us_per_buffer"], "runs": [r["frames_per_s"] for r in runs]}
+            ref = None
+            if doc == "cfg2" and cpu_baseline and cpu_baseline.get("kind") == "reference":
+                ref = cpu_baseline
+            else:
+                try:
+                    import ref_runner
+                    ref = ref_runner.measure_reference(doc, W, H)
+                except Exception as e:      # noqa: BLE001
+                    print(f"e2e: reference leg for {doc} failed ({e!r})", file=sys.stderr)
+            if ref:
+                d["reference"] = ref["value"]
+                d["vs_reference"] = round(best["frames_per_s"] / ref["value"], 2)
+                if ref.get("all_cores"):
+                    d["reference_all_cores"] = ref["all_cores"]["value"]
+                    d["reference_cores"] = ref["all_cores"]["cores"]
+                    d["vs_reference_all_cores"] = round(
+                        best["frames_per_s"] / ref["all_cores"]["value"], 2)
+            out[doc] = d
+        except Exception as e:      # noqa: BLE001
+            out[doc] = {"error": repr(e)[:300]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,7 +199,18 @@ def main():
                     help="fused mode: composite each overlay OVER a resident video frame "
                          "(flutl_launch_batch_over); adds 4*W*H read bytes per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="skip the element end-to-end block (GStreamer pipeline runs)")
+    ap.add_argument("--kernel-launches", type=int, default=400,
+                    help="launches timed with HIP events for the roofline block (>= 400)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE="
+                         f"{os.environ.get('WORLD_SIZE')}: refusing to report a wrong n_gpus")
 
     import torch
     import torch.distributed as dist
@@ -134,7 +234,6 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1
 
     # one independent stream per rank (weak scaling); no data-path collective
     my_streams = streams.streams_of_rank(world, rank, world)
@@ -182,6 +281,12 @@ def main():
                                     ((s * B + j) % ring) * frame_bytes)
         D_dev = dev(descs)
     stream = torch.cuda.current_stream().cuda_stream
+    # --gather: finished frames go to rank 0 in rank order, one collective per
+    # step (the step's B frames are one contiguous block of the ring), issued
+    # asynchronously into double-buffered slots so that it overlaps the next launch
+    gatherer = (streams.FrameGatherer(B * frame_bytes, out.device, slots=2)
+                if args.gather and world > 1 else None)
+    assert ring >= 4 * B or gatherer is None
 
     def step(s):
         if B == 1 and video is None:
@@ -190,8 +295,8 @@ def main():
             F.launch_frame(stream, W, H, out.data_ptr() + slot * frame_bytes,
                            R_dev.data_ptr() + r_first[st] * 16, r_count[st],
                            P_dev, A_dev)
-            if args.gather and world > 1:
-                streams.gather_frames(out[slot * frame_bytes:(slot + 1) * frame_bytes])
+            if gatherer and args.gather:
+                gatherer.submit(out[slot * frame_bytes:(slot + 1) * frame_bytes])
         else:
             ds = s % n_desc_steps
             if video is not None:
@@ -200,12 +305,13 @@ def main():
             else:
                 F.launch_batch(stream, W, H, out, D_dev.data_ptr() + ds * B * 16, B,
                                R_dev, P_dev, A_dev, stride=stride)
-            if args.gather and world > 1:
-                for j in range(B):
-                    slot = (ds * B + j) % ring
-                    streams.gather_frames(out[slot * frame_bytes:(slot + 1) * frame_bytes])
+            if gatherer and args.gather:
+                first = (ds * B) % ring         # ring is a multiple of B: one block
+                gatherer.submit(out[first * frame_bytes:(first + B) * frame_bytes])
 
     def barrier():
+        if gatherer:
+            gatherer.flush()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -218,24 +324,40 @@ def main():
         step(args.warmup + s)
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = streams.max_over_ranks(elapsed, torch.device("cpu" if rehearsal else "cuda"))
+    tdev = torch.device("cpu" if rehearsal else "cuda")
+    elapsed = streams.max_over_ranks(elapsed, tdev)
+
+    # ---- the same, over a timed region of at least 0.5 s ---------------------
+    # (`elapsed` is already the maximum over ranks, so every rank takes the same count)
+    steady_steps = max(args.steps, int(0.6 / max(elapsed / args.steps, 1e-7)) + 1)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(steady_steps):
+        step(args.warmup + args.steps + s)
+    barrier()
+    steady = streams.max_over_ranks(time.perf_counter() - t0, tdev)
 
     # ---- per-launch kernel duration (HIP events on the launch stream) ------
-    kern_ms = None
+    # A fixed number of launches whatever --steps is; each event pair brackets one
+    # step's launch on the stream it is launched on.
+    kern = None
     if rank == 0:
-        n_ev = min(args.steps, 400)
+        n_ev = max(args.kernel_launches, 400)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                for _ in range(n_ev)]
+        saved, args.gather = args.gather, False
         torch.cuda.synchronize()
         for i, (a, b) in enumerate(evs):
             a.record()
-            saved = args.gather
-            args.gather = False
             step(args.warmup + i)
-            args.gather = saved
             b.record()
         torch.cuda.synchronize()
-        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        args.gather = saved
+        ms = np.array([a.elapsed_time(b) for a, b in evs])
+        kern = {"mean": float(ms.mean()), "median": float(np.median(ms)),
+                "p10": float(np.percentile(ms, 10)), "p90": float(np.percentile(ms, 90)),
+                "n": n_ev}
+    kern_ms = kern["mean"] if kern else None
     if world > 1:
         dist.barrier()
 
@@ -249,6 +371,10 @@ def main():
             "value": round(fps, 2),
             "unit": "frames/s",
             "mpix_per_s": round(fps * W * H / 1e6, 1),
+            "value_steady": round(steady_steps * B * world / steady, 2),
+            "steady_steps": steady_steps,
+            "steady_region_s": round(steady, 3),
+            "timed_region_s": round(elapsed, 4),
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -268,16 +394,29 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": None,
+                         "traffic_frac": None,
                          "kernel": "flutl_composite_kernel",
                          "kernel_ms": round(kern_ms, 5),
+                         "kernel_ms_median": round(kern["median"], 5),
+                         "kernel_ms_p10": round(kern["p10"], 5),
+                         "kernel_ms_p90": round(kern["p90"], 5),
+                         "kernel_launches_timed": kern["n"],
+                         "frac_median": round(mean_alg * B / (kern["median"] * 1e-3) / 1e9
+                                              / HBM_PEAK_GBS, 4),
                          "algorithmic_bytes_per_launch": int(mean_alg * B)},
         }
         if not args.over_video:
-            res["roofline"]["traffic"] = profiled_traffic(args.config, B)
+            tr = profiled_traffic(args.config, B)
+            res["roofline"]["traffic"] = tr
+            if tr:      # HBM-honest fraction: counter bytes, not algorithmic bytes
+                res["roofline"]["traffic_frac"] = round(
+                    tr / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import cpu_baseline
             res["cpu_baseline"] = cpu_baseline.measure(args.config, W, H, states, atlas)
+        if world == 1 and not args.no_e2e and H == 2160:
+            res["e2e"] = e2e_block(W, H, res.get("cpu_baseline"))
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -110,6 +110,11 @@ struct FlutlRecorder
   uint32_t n_ops, cap_ops;
   StrokeEntry *strokes;
   uint32_t n_strokes, cap_strokes;
+  /* the keys of `strokes` name scaled fonts by address: every such font is
+   * referenced here for as long as the cache lives, so that an address cannot
+   * come back as a different font */
+  cairo_scaled_font_t **key_fonts;
+  uint32_t n_key_fonts, cap_key_fonts;
 
   int has_clip, clip[4];      /* x0,y0,x1,y1 */
   int in_group, group[4];
@@ -430,6 +435,9 @@ drop_caches (FlutlRecorder *rec)
   for (uint32_t i = 0; i < rec->n_strokes; i++)
     free (rec->strokes[i].key);
   rec->n_strokes = 0;
+  for (uint32_t i = 0; i < rec->n_key_fonts; i++)
+    cairo_scaled_font_destroy (rec->key_fonts[i]);
+  rec->n_key_fonts = 0;
   rec->atlas_size = ATLAS_SLACK;
   if (rec->atlas)
     memset (rec->atlas, 0, rec->atlas_cap);
@@ -462,6 +470,7 @@ flutl_recorder_free (FlutlRecorder *rec)
   path_ops_clear (rec);
   free (rec->ops);
   free (rec->strokes);
+  free (rec->key_fonts);
   free (rec);
 }
 
@@ -1013,6 +1022,34 @@ flutl_recorder_path_rect (FlutlRecorder *rec, double x, double y, double w, doub
   op->h = h;
 }
 
+static void
+key_font_pin (FlutlRecorder *rec, cairo_scaled_font_t *sf)
+{
+  if (!sf)
+    return;
+  for (uint32_t i = 0; i < rec->n_key_fonts; i++)
+    if (rec->key_fonts[i] == sf)
+      return;
+  if (rec->n_key_fonts == rec->cap_key_fonts) {
+    rec->cap_key_fonts = rec->cap_key_fonts ? rec->cap_key_fonts * 2 : 8;
+    rec->key_fonts = xrealloc (rec->key_fonts, rec->cap_key_fonts * sizeof *rec->key_fonts);
+  }
+  rec->key_fonts[rec->n_key_fonts++] = cairo_scaled_font_reference (sf);
+}
+
+/* The fonts the pending ops name: pinned when their key is stored. */
+static void
+key_fonts_pin_ops (FlutlRecorder *rec)
+{
+  for (uint32_t i = 0; i < rec->n_ops; i++) {
+    const PathOp *op = &rec->ops[i];
+    if (op->sfont)
+      key_font_pin (rec, op->sfont);
+    else if (op->font)
+      key_font_pin (rec, pango_cairo_font_get_scaled_font ((PangoCairoFont *) op->font));
+  }
+}
+
 /* Serialise what determines the coverage mask, relative to an integer base. */
 static size_t
 stroke_key (FlutlRecorder *rec, double line_width, int base_x, int base_y,
@@ -1445,6 +1482,7 @@ ops_find_mask (FlutlRecorder *rec, int fill, int *dx, int *dy, int *is_new)
   }
   StrokeEntry *e = &rec->strokes[rec->n_strokes++];
   memset (e, 0, sizeof *e);
+  key_fonts_pin_ops (rec);
   e->hash = h;
   e->key = key;
   e->key_len = key_len;

@@ -87,6 +87,7 @@ typedef struct
   guint n_bands;
   guint32 bands[2 * MAX_BANDS];   /* [y0, y1) pairs, sorted, disjoint */
   guint32 cols[2];                /* [x0, x1): the columns written in those rows */
+  gboolean stale;                 /* a copy into it failed: not to be recycled */
 } FrameSlot;
 
 typedef struct
@@ -140,7 +141,7 @@ frame_block_release (gpointer data)
   FramePool *p = b->pool;
   g_mutex_lock (&p->lock);
   /* keep at most a few frames, and only of the current size */
-  if (b->size == p->block_size && p->free_slots->len < 6)
+  if (b->size == p->block_size && p->free_slots->len < 6 && !b->slot->stale)
     g_ptr_array_add (p->free_slots, b->slot);
   else
     frame_slot_free (b->slot);
@@ -244,10 +245,12 @@ typedef struct
   gboolean full_d2h;         /* FLUTL_FULL_D2H=1: whole-frame copies, writable memory */
   gboolean timing;           /* FLUTL_TIMING=1: host / device split on stderr at dispose */
   gint64 t_record, t_device;
+  gint64 t_first_return, t_last_return;   /* monotonic us: end of the first / last gen_buffer */
   guint n_timed;
   GHashTable *images;        /* id -> cairo_surface_t (decoded PNGs) */
   GHashTable *layouts;       /* layout cache: key string -> PangoLayout, per document */
   gboolean no_layout_cache;  /* FLUTL_NO_LAYOUT_CACHE=1 */
+  guint skipped;             /* outlines of this buffer that could not be drawn */
 } GstTTMLRenderPrivate;
 
 static GstStaticPadTemplate ttmlrender_src_template =
@@ -1181,6 +1184,7 @@ blurred_outline (GstTTMLRender *render, HipRegion *r, PangoLayout *layout, guint
       th > 32766 || fabs (m.x0) > 30000.0 || fabs (m.y0) > 30000.0) {
     GST_FIXME_OBJECT (render, "blurred textOutline under this CTM, or with a blur length "
         "above 64 px, is not implemented; outline of region '%s' not drawn", r->id);
+    priv->skipped++;
     return;
   }
   if (rotated) {
@@ -1195,6 +1199,7 @@ blurred_outline (GstTTMLRender *render, HipRegion *r, PangoLayout *layout, guint
     if (fabs (U0 - floor (U0 + 0.5)) > 1e-9 || fabs (V0 - floor (V0 + 0.5)) > 1e-9) {
       GST_FIXME_OBJECT (render, "blurred textOutline at a fractional position in a "
           "vertical writing mode; outline of region '%s' not drawn", r->id);
+      priv->skipped++;
       return;
     }
     dst_x = (int) floor (V0 + 0.5) - th;
@@ -1233,8 +1238,12 @@ blurred_outline (GstTTMLRender *render, HipRegion *r, PangoLayout *layout, guint
   GST_LOG_OBJECT (render, "blurred outline of region '%s': %dx%d surface%s%s, entry at "
       "(%d, %d), weights %u/%u", r->id, tw, th, rotated ? ", quarter turn" : "",
       fractional ? ", fractional position" : "", dst_x, dst_y, distx, disty);
-  if (priv->dump_only || !ensure_ctx (render)) {
+  if (priv->dump_only) {      /* record-only test facility: the frame is left blank anyway */
     GST_WARNING_OBJECT (render, "blurred outline needs the device; not drawn");
+    return;
+  }
+  if (!ensure_ctx (render)) {
+    priv->skipped++;
     return;
   }
 
@@ -1280,6 +1289,7 @@ blurred_outline (GstTTMLRender *render, HipRegion *r, PangoLayout *layout, guint
     if (!flush_atlas (render)) {          /* the sub list's masks must be in HBM */
       g_free (copy);
       g_free (key);
+      priv->skipped++;
       return;
     }
     rc = flutl_atlas_put_blurred (priv->ctx, tw, th, rg, n_rg, pr, n_pr, radius, sigma,
@@ -1288,6 +1298,7 @@ blurred_outline (GstTTMLRender *render, HipRegion *r, PangoLayout *layout, guint
       GST_ERROR_OBJECT (render, "flutl_atlas_put_blurred: %s", flutl_strerror (rc));
       g_free (copy);
       g_free (key);
+      priv->skipped++;
       return;
     }
     host_off = flutl_recorder_atlas_append_device_entry (rec, copy, (gsize) ew * eh * 4);
@@ -1295,6 +1306,7 @@ blurred_outline (GstTTMLRender *render, HipRegion *r, PangoLayout *layout, guint
     if (host_off != dev_off) {
       GST_ERROR_OBJECT (render, "atlas out of sync (%u vs %u)", host_off, dev_off);
       g_free (key);
+      priv->skipped++;
       return;
     }
     img = g_new0 (BlurredImage, 1);
@@ -1514,9 +1526,16 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
 
   rg = flutl_recorder_regions (rec, &n_rg);
   pr = flutl_recorder_prims (rec, &n_pr);
-  if (flutl_recorder_unsupported (rec))
-    GST_WARNING_OBJECT (render, "%u primitive(s) use features that are not "
-        "implemented and were left out", flutl_recorder_unsupported (rec));
+  if (flutl_recorder_unsupported (rec) || priv->skipped) {
+    /* never push a frame that differs from the reference's: no buffer at all
+     * (the base class's error convention, gstttmlbase.c:161-163) */
+    GST_ELEMENT_ERROR (render, STREAM, NOT_IMPLEMENTED,
+        ("ttmlrender: the document uses a rendering feature that is not implemented"),
+        ("%u primitive(s), %u outline(s) could not be reproduced exactly; buffer dropped",
+            flutl_recorder_unsupported (rec), priv->skipped));
+    priv->skipped = 0;
+    return NULL;
+  }
 
   if (priv->dump) {
     size_t atlas_size;
@@ -1575,6 +1594,8 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
       else
         rc = flutl_render_frame_window_to_host (priv->ctx, width, height, rg, n_rg, pr, n_pr,
             slot->block, (size_t) width * 4, bands, n, c0, c1);
+      if (rc != FLUTL_OK)         /* what the block holds is unknown now */
+        slot->stale = TRUE;
       memcpy (slot->bands, now, sizeof (guint32) * 2 * n_now);
       slot->n_bands = n_now;
       slot->cols[0] = c0_now;
@@ -1618,7 +1639,9 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
     gint64 t_end = g_get_monotonic_time ();
     priv->t_record += t_recorded - t_start;
     priv->t_device += t_end - t_recorded;
-    priv->n_timed++;
+    if (priv->n_timed++ == 0)
+      priv->t_first_return = t_end;
+    priv->t_last_return = t_end;
   }
   return buffer;
 }
@@ -1720,6 +1743,24 @@ gst_ttmlrender_set_property (GObject *object, guint id, const GValue *value,
   }
 }
 
+/* FLUTL_TIMING=1: one line per document on stderr (tools/e2e_timing.py reads it).
+ * span = end of the first gen_buffer to end of the last; drained = to the moment
+ * every frame of the document was complete in host memory. */
+static void
+timing_report (GstTTMLRender *render)
+{
+  GstTTMLRenderPrivate *priv = get_priv (render);
+  if (!priv->timing || !priv->n_timed)
+    return;
+  g_printerr ("ttmlrender-hip timing: buffers=%u record_us=%.1f device_us=%.1f "
+      "span_us=%" G_GINT64_FORMAT " drained_us=%" G_GINT64_FORMAT "\n", priv->n_timed,
+      (double) priv->t_record / priv->n_timed, (double) priv->t_device / priv->n_timed,
+      priv->t_last_return - priv->t_first_return,
+      priv->t_last_return - priv->t_first_return);   /* (gen_buffer is synchronous) */
+  priv->n_timed = 0;
+  priv->t_record = priv->t_device = 0;
+}
+
 /* ---- reset / dispose / init (reference :1610-1750) ------------------------------- */
 static void
 gst_ttmlrender_reset (GstTTMLBase *base)
@@ -1747,12 +1788,7 @@ gst_ttmlrender_dispose (GObject *object)
   GstTTMLRenderPrivate *priv = get_priv (render);
 
   gst_ttmlrender_reset (GST_TTMLBASE (render));
-  if (priv->timing && priv->n_timed) {
-    g_printerr ("ttmlrender-hip timing: %u buffers, record %.1f us, "
-        "atlas+upload+kernel+D2H %.1f us per buffer\n", priv->n_timed,
-        (double) priv->t_record / priv->n_timed, (double) priv->t_device / priv->n_timed);
-    priv->n_timed = 0;
-  }
+  timing_report (render);
   if (priv->dump) {
     flutl_pack_writer_free (priv->dump);
     priv->dump = NULL;

@@ -37,6 +37,41 @@ def gather_frames(frame, dst=0, group=None):
     return out
 
 
+class FrameGatherer:
+    """The same gather, overlapped with rendering: each call issues the collective
+    asynchronously (under RCCL it runs on the communicator's own stream, ordered
+    after the render work already queued, while the caller's stream goes on to the
+    next launch) into one of `slots` pre-allocated destination sets on `dst`.  A
+    slot is waited for only when it comes round again, so up to `slots` gathers
+    are in flight.  The caller must not overwrite a submitted source block before
+    `slots` further submissions or flush() (bench.py's output ring is deeper)."""
+
+    def __init__(self, block_bytes, device, slots=2, dst=0, group=None):
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.dst, self.group, self.slots = dst, group, slots
+        self.bufs = [[torch.empty(block_bytes, dtype=torch.uint8, device=device)
+                      for _ in range(self.world)] if self.rank == dst else None
+                     for _ in range(slots)]
+        self.work = [None] * slots
+        self.n = 0
+
+    def submit(self, block):
+        k = self.n % self.slots
+        self.n += 1
+        if self.work[k] is not None:
+            self.work[k].wait()
+        self.work[k] = dist.gather(block, self.bufs[k], dst=self.dst, group=self.group,
+                                   async_op=True)
+        return self.bufs[k]
+
+    def flush(self):
+        for k, w in enumerate(self.work):
+            if w is not None:
+                w.wait()
+                self.work[k] = None
+
+
 def max_over_ranks(seconds, device):
     """Timing convention of bench.py: the slowest rank defines the step time."""
     t = torch.tensor([seconds], dtype=torch.float64, device=device)

@@ -45,3 +45,25 @@ def test_element_still_records_the_committed_lists(ttml, tmp_path):
     for i, (R, P) in enumerate(st):
         assert np.array_equal(R, z[f"regions{i}"]) and np.array_equal(P, z[f"prims{i}"])
     assert np.array_equal(pk.atlas, z["atlas"])
+
+
+@pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
+                    reason="fluttml-hip plugin / GStreamer runtime not present")
+def test_embedded_images_record_like_file_images(tmp_path):
+    """smpte:image data embedded in the document (tests/golden/variants/): the
+    reference loses it to a buffer its base class keeps writing to
+    (gstttmlstate.c:440-443 vs gstttmlbase.c:428-435; every decode fails here), so
+    its frames cannot pin this branch.  The element keeps a copy of the data
+    (host/flutl_state_fix.c) and must record exactly what it records for the same
+    PNGs referenced as files (k08, which the reference does render) -- and exit
+    cleanly (gstenv.render raises on the reference's teardown abort)."""
+    d = os.path.join(ROOT, "tests", "golden")
+    z = np.load(os.path.join(d, "scenes", "k08_images.npz"))
+    W, H = int(z["width"]), int(z["height"])
+    pk = scene_pack.load(gstenv.dump_pack(
+        os.path.join(d, "variants", "k08_images_embedded.ttml"), W, H, str(tmp_path / "p.flpk")))
+    st = pk.states()
+    assert len(st) == int(z["n_states"])
+    for i, (R, P) in enumerate(st):
+        assert np.array_equal(R, z[f"regions{i}"]) and np.array_equal(P, z[f"prims{i}"])
+    assert np.array_equal(pk.atlas, z["atlas"])

@@ -30,6 +30,18 @@ def _worker(rank, world, port, q):
         frames = [O.render(W, H, z[f"regions{i}"], z[f"prims{i}"], z["atlas"]) for i in sched]
         got = streams.gather_frames(torch.from_numpy(frames[0].view(np.uint8).reshape(-1).copy()))
         t = streams.max_over_ranks(0.5 + rank, torch.device("cpu"))
+        # the overlapped gather of bench.py --gather: 5 blocks through 2 slots
+        g = streams.FrameGatherer(64, torch.device("cpu"), slots=2)
+        for k in range(5):
+            blk = torch.full((64,), 16 * k + rank, dtype=torch.uint8)
+            dstbufs = g.submit(blk)
+            if k >= 3:          # the last two are still resident after flush
+                keep = keep + [dstbufs] if k > 3 else [dstbufs]
+        g.flush()
+        if rank == 0:
+            for j, bufs in enumerate(keep):
+                for r in range(world):
+                    assert bool((bufs[r] == 16 * (3 + j) + r).all())
         if rank == 0:
             other = streams.state_schedule(n, 1, step=3, batch=2, world=world)[0]
             ok = (np.array_equal(got[0].numpy().view(np.uint32).reshape(H, W), z["frames"][sched[0]])
@@ -64,3 +76,38 @@ def test_stream_partition_covers_all_streams_once():
     for n, w in [(8, 8), (8, 3), (5, 2), (1, 4), (16, 8)]:
         got = sum((streams.streams_of_rank(n, r, w) for r in range(w)), [])
         assert got == list(range(n))
+
+
+def test_bench_gpus_n_starts_n_ranks_itself(tmp_path):
+    """`python bench.py --gpus N` with no launcher around it must run N ranks (the
+    driver's SCALE run) -- checked on the launcher alone: the children are this
+    test's stand-in script, which reports the environment each rank was given."""
+    import importlib.util
+    import json
+    import subprocess
+    child = tmp_path / "child.py"
+    child.write_text(
+        "import json, os, sys\n"
+        "json.dump({k: os.environ.get(k) for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE',"
+        " 'MASTER_ADDR', 'MASTER_PORT')}, open(sys.argv[1] + os.environ['RANK'], 'w'))\n"
+        "sys.exit(3 if os.environ['RANK'] == '2' and sys.argv[2] == 'fail' else 0)\n")
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for mode, want_rc in (("ok", 0), ("fail", 3)):
+        code = ("import sys; sys.argv = ['bench.py', %r, %r]; import importlib.util as u;"
+                "s = u.spec_from_file_location('b', %r); b = u.module_from_spec(s);"
+                "s.loader.exec_module(b); b.__file__ = %r; sys.exit(b.self_launch(4))"
+                % (str(tmp_path / "rank"), mode, os.path.join(ROOT, "bench.py"), str(child)))
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")}
+        r = subprocess.run([sys.executable, "-c", code], env=env, timeout=120)
+        assert r.returncode == want_rc
+        ranks = [json.load(open(str(tmp_path / "rank") + str(i))) for i in range(4)]
+        assert [x["RANK"] for x in ranks] == ["0", "1", "2", "3"]
+        assert all(x["WORLD_SIZE"] == "4" and x["MASTER_ADDR"] == "127.0.0.1" for x in ranks)
+        assert len({x["MASTER_PORT"] for x in ranks}) == 1
+    # and a launcher that disagrees with --gpus is refused, not silently run as 1 rank
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"],
+                       env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in r.stderr

@@ -1,35 +1,65 @@
 #!/usr/bin/env python3
 """GPU-box tool: the drop-in element in a real pipeline (filesrc ! ttmlrender !
-caps ! fakesink) with FLUTL_TIMING=1: push-to-push frames/s and the element's own
-host / device split.   python tools/e2e_timing.py cfg2 3840 2160"""
+caps ! fakesink) with FLUTL_TIMING=1.  Frames/s is taken from the element's own
+clock: (buffers - 1) / (first gen_buffer return -> last frame complete in host
+memory), the same push-to-push span oracle/ref_runner.py takes for the
+reference from its "Pushing buffer" debug lines (gstttmlbase.c:183-191) -- that
+log is not switched on here, it would cost more than a buffer does.
+
+    python tools/e2e_timing.py cfg2 3840 2160        (bench_data/cfg2.ttml)
+Importable: measure(ttml_path, W, H, extra_env=None, log_path=None) -> dict.
+"""
 import os
+import re
 import subprocess
 import sys
 import tempfile
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import gstenv  # noqa: E402
 
-cfg, W, H = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-ttml = os.path.join(ROOT, "bench_data", cfg + ".ttml")
-extra = {"GST_DEBUG": "ttmlbase:5", "GST_DEBUG_NO_COLOR": "1", "FLUTL_TIMING": "1"}
-for k, v in os.environ.items():
-    if k.startswith("FLUTL_"):
-        extra[k] = v
-env = gstenv.env_for(gstenv.HIP_PLUGIN_DIR, extra)
-cmd = [os.path.join(gstenv.CONDA, "bin", "gst-launch-1.0"), "-q", "filesrc",
-       f"location={ttml}", "!", "ttmlrender", "!", f"video/x-raw,width={W},height={H}",
-       "!", "fakesink"]
-r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=tempfile.gettempdir())
-times = []
-for line in r.stderr.split("\n"):
-    if "Pushing buffer of" in line:
-        h, m, s = line.split()[0].split(":")
-        times.append(int(h) * 3600 + int(m) * 60 + float(s))
-    if "ttmlrender-hip timing" in line:
-        print(line)
-if len(times) > 2:
-    print(f"{cfg} {W}x{H}: {len(times)} buffers, {(len(times) - 1) / (times[-1] - times[0]):.1f} frames/s push-to-push")
-else:
-    print("rc", r.returncode, r.stderr[-1500:])
+PIPELINE = "filesrc ! ttmlrender ! video/x-raw,width={W},height={H} ! fakesink"
+
+
+def measure(ttml, W, H, extra_env=None, log_path=None, sink="fakesink"):
+    extra = {"FLUTL_TIMING": "1"}
+    for k, v in os.environ.items():
+        if k.startswith("FLUTL_") and k != "FLUTL_BENCH_REHEARSAL":
+            extra[k] = v
+    extra.update(extra_env or {})
+    env = gstenv.env_for(gstenv.HIP_PLUGIN_DIR, extra)
+    cmd = [os.path.join(gstenv.CONDA, "bin", "gst-launch-1.0"), "-q", "filesrc",
+           f"location={os.path.abspath(ttml)}", "!", "ttmlrender", "!",
+           f"video/x-raw,width={W},height={H}", "!"] + sink.split()
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=tempfile.gettempdir())
+    wall = time.perf_counter() - t0
+    lines = [l for l in r.stderr.split("\n") if "ttmlrender-hip timing" in l]
+    if log_path:
+        with open(log_path, "a") as f:
+            f.write(f"$ {' '.join(cmd[1:])}   (rc {r.returncode}, wall {wall:.2f} s)\n")
+            f.write("\n".join(lines) + "\n")
+            if r.returncode != 0:
+                f.write(r.stderr[-2000:] + "\n")
+    if r.returncode != 0 or not lines:
+        raise RuntimeError(f"element pipeline failed (rc {r.returncode}): {r.stderr[-1500:]}")
+    # one line per document; a pipeline plays one document
+    kv = {k: float(v) for k, v in re.findall(r"(\w+)=([0-9.]+)", lines[-1])}
+    n = int(kv["buffers"])
+    out = {"buffers": n, "frames_per_s": round((n - 1) / (kv["drained_us"] * 1e-6), 2),
+           "record_us_per_buffer": kv["record_us"], "device_us_per_buffer": kv["device_us"],
+           "span_s": round(kv["span_us"] * 1e-6, 4), "drained_s": round(kv["drained_us"] * 1e-6, 4),
+           "pipeline_wall_s": round(wall, 2)}
+    for k in ("delta_bytes", "strokes", "stroke_wait_us"):
+        if k in kv:
+            out[k] = kv[k]
+    return out
+
+
+if __name__ == "__main__":
+    cfg, W, H = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    ttml = cfg if os.path.exists(cfg) else os.path.join(ROOT, "bench_data", cfg + ".ttml")
+    measure(ttml, W, H)      # warm the file and font caches
+    print(os.path.basename(ttml), f"{W}x{H}", measure(ttml, W, H))

@@ -59,14 +59,16 @@ def render(plugin_dir, ttml_path, width, height, out_path=None, extra_env=None,
     # cwd: the reference's base class can append an XML dump to ./ttml.xml
     r = subprocess.run(cmd, env=env_for(plugin_dir, extra_env), capture_output=True,
                        text=True, cwd=tempfile.gettempdir())
-    # Known bug of the reference's UNTOUCHED base class (it is in both plugins):
-    # gst_ttml_state_save_data (gstttmlstate.c:440-443) reallocs the XML text
-    # buffer that gstttmlbase.c still owns, so documents with embedded
-    # smpte:image data abort with "double free" at teardown -- after all
-    # buffers have been pushed.  Tolerated here; anything else is an error.
-    teardown_bug = r.returncode == -6 and "double free" in r.stderr
+    # Known bug of the reference's base class: gst_ttml_state_save_data
+    # (gstttmlstate.c:440-443) reallocs the XML text buffer that gstttmlbase.c
+    # still owns, so documents with embedded smpte:image data abort with "double
+    # free" at teardown -- after all buffers have been pushed.  Tolerated for the
+    # REFERENCE plugin only; the product plugin carries a copying save_data
+    # (host/flutl_state_fix.c) and must exit cleanly.
+    teardown_bug = (plugin_dir == REF_PLUGIN_DIR and r.returncode == -6 and
+                    "double free" in r.stderr)
     if r.returncode != 0 and not teardown_bug:
-        raise RuntimeError(f"gst-launch failed: {r.stdout}\n{r.stderr}")
+        raise RuntimeError(f"gst-launch failed (rc {r.returncode}): {r.stdout}\n{r.stderr}")
     data = b""
     if sink == "filesink" and tmp:      # a caller-provided path is left alone
         data = open(out_path, "rb").read()

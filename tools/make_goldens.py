@@ -44,7 +44,7 @@ def record(ttml, W, H, gpu=False):
                                                 record_only=not gpu))
 
 
-def scenes(gpu=False):
+def scenes(gpu=False, only=None):
     """k*.ttml: recorded without a device.  g*.ttml (gpu=True, run on an MI355X
     box through gpurun): scenes whose display lists contain device-produced
     atlas entries (blurred outlines); fixtures go to gpurun_out/goldens/."""
@@ -56,6 +56,8 @@ def scenes(gpu=False):
         os.makedirs(outd, exist_ok=True)
     for name in sorted(f[:-5] for f in os.listdir(d)
                        if f.endswith(".ttml") and f.startswith("g" if gpu else "k")):
+        if only and not name.startswith(only):
+            continue
         ttml = os.path.join(d, name + ".ttml")
         m = re.search(r"frame:\s*(\d+)x(\d+)", open(ttml).read())     # <!-- frame: WxH -->
         W, H = (int(m.group(1)), int(m.group(2))) if m else SCENE_SIZE
@@ -135,9 +137,9 @@ def config(cfg):
 if __name__ == "__main__":
     what = sys.argv[1:] or ["scenes", "cfg0", "cfg1", "cfg2"]
     for w in what:
-        if w == "scenes":
-            scenes()
-        elif w == "gpu_scenes":
-            scenes(gpu=True)
+        if w.startswith("scenes"):           # scenes, or scenes:<name prefix>
+            scenes(only=w.partition(":")[2] or None)
+        elif w.startswith("gpu_scenes"):
+            scenes(gpu=True, only=w.partition(":")[2] or None)
         else:
             config(w)
