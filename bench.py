@@ -245,7 +245,7 @@ def main():
     B = args.batch
     stride = W * 4 + args.row_pad
     frame_bytes = stride * H
-    ring = args.ring or max(2 * B, (640 << 20) // frame_bytes + 1)
+    ring = args.ring or max((3 if args.gather else 2) * B, (640 << 20) // frame_bytes + 1)
     ring = (ring + B - 1) // B * B
 
     # ---- make everything resident in HBM -----------------------------------
@@ -286,7 +286,9 @@ def main():
     # asynchronously into double-buffered slots so that it overlaps the next launch
     gatherer = (streams.FrameGatherer(B * frame_bytes, out.device, slots=2)
                 if args.gather and world > 1 else None)
-    assert ring >= 4 * B or gatherer is None
+    # (a block of the ring is overwritten ring/B steps after it was submitted; the
+    # gatherer has waited for everything but the last two submissions by then)
+    assert gatherer is None or ring >= 3 * B, "--ring too small for --gather"
 
     def step(s):
         if B == 1 and video is None:

@@ -32,6 +32,18 @@ struct flutl_list {
   void *mem;
 };
 
+// One submission in flight: its display list in page-locked host memory (the
+// caller's list memory is free again when submit returns, and a copy from
+// page-locked memory is a true asynchronous DMA) and in HBM.
+struct list_slot {
+  void *host;
+  void *dev;
+  size_t cap;
+  hipEvent_t done;     // recorded after the last kernel that reads `dev`
+  bool busy;
+};
+constexpr int kListSlots = 4;    // submissions in flight per context
+
 struct flutl_ctx {
   int device;
   hipStream_t stream;
@@ -42,6 +54,23 @@ struct flutl_ctx {
   size_t frame_cap;
   void *listbuf;       // reusable device buffer for transient display lists
   size_t listbuf_cap;
+  list_slot slots[kListSlots];
+  uint32_t next_slot;
+  uint8_t *stage;      // page-locked staging for atlas uploads (no wait per entry)
+  size_t stage_cap, stage_used;
+  uint64_t *delta_segments;   // device: 256-byte segments the delta read-backs wrote
+};
+
+struct flutl_frame {
+  int device;
+  uint32_t width, height;
+  void *host;          // page-locked, device mapped
+  void *host_dev;      // its device address
+  void *twin;          // device
+  hipEvent_t done;
+  bool pending;        // a submission has been queued since the last wait
+  int error;           // sticky: a submission failed, the content is undefined
+  uint32_t ext[4];     // x0, y0, x1, y1: what the frame holds lies inside (empty: nothing)
 };
 
 extern "C" int flutl_abi_version (void) { return FLUTL_ABI_VERSION; }
@@ -198,6 +227,12 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
   c->frame_cap = 0;
   c->listbuf = nullptr;
   c->listbuf_cap = 0;
+  for (auto &sl : c->slots)
+    sl = list_slot { nullptr, nullptr, 0, nullptr, false };
+  c->next_slot = 0;
+  c->stage = nullptr;
+  c->stage_cap = c->stage_used = 0;
+  c->delta_segments = nullptr;
   *out = c;
   return FLUTL_OK;
 }
@@ -214,6 +249,18 @@ extern "C" void flutl_ctx_destroy (flutl_ctx *c)
     (void) hipFree (c->frame);
   if (c->listbuf)
     (void) hipFree (c->listbuf);
+  for (auto &sl : c->slots) {
+    if (sl.host)
+      (void) hipHostFree (sl.host);
+    if (sl.dev)
+      (void) hipFree (sl.dev);
+    if (sl.done)
+      (void) hipEventDestroy (sl.done);
+  }
+  if (c->stage)
+    (void) hipHostFree (c->stage);
+  if (c->delta_segments)
+    (void) hipFree (c->delta_segments);
   (void) hipStreamDestroy (c->stream);
   delete c;
 }
@@ -222,7 +269,10 @@ extern "C" int flutl_ctx_sync (flutl_ctx *c)
 {
   if (!c)
     return FLUTL_EINVAL;
-  return hip_ok (hipStreamSynchronize (c->stream)) ? FLUTL_OK : FLUTL_ENODEV;
+  if (!hip_ok (hipStreamSynchronize (c->stream)))
+    return FLUTL_ENODEV;
+  c->stage_used = 0;       // every staged upload has landed
+  return FLUTL_OK;
 }
 
 static int atlas_reserve (flutl_ctx *c, size_t need)
@@ -267,12 +317,32 @@ extern "C" int flutl_atlas_put (flutl_ctx *c, const void *src, size_t bytes,
   int rc = atlas_reserve (c, end + kAtlasSlack);
   if (rc)
     return rc;
-  if (!hip_ok (hipMemcpyAsync (c->atlas + off, src, bytes, hipMemcpyHostToDevice,
-          c->stream)))
-    return FLUTL_ENODEV;
-  // src may be freed by the caller right after return
-  if (!hip_ok (hipStreamSynchronize (c->stream)))
-    return FLUTL_ENODEV;
+  // src may be freed by the caller right after return: small entries (glyph
+  // masks, outline masks) go through page-locked staging and are not waited
+  // for -- the stream orders them before whatever reads them; the staging
+  // memory is reclaimed when the stream is next drained
+  constexpr size_t kStageBytes = (size_t) 8 << 20;
+  if (!c->stage && hip_ok (hipHostMalloc (reinterpret_cast<void **> (&c->stage), kStageBytes,
+          hipHostMallocDefault)))
+    c->stage_cap = kStageBytes;
+  if (c->stage && bytes <= c->stage_cap / 2) {
+    if (c->stage_used + bytes > c->stage_cap) {
+      if (!hip_ok (hipStreamSynchronize (c->stream)))
+        return FLUTL_ENODEV;
+      c->stage_used = 0;
+    }
+    memcpy (c->stage + c->stage_used, src, bytes);
+    if (!hip_ok (hipMemcpyAsync (c->atlas + off, c->stage + c->stage_used, bytes,
+            hipMemcpyHostToDevice, c->stream)))
+      return FLUTL_ENODEV;
+    c->stage_used += (bytes + 63) & ~(size_t) 63;
+  } else {
+    if (!hip_ok (hipMemcpyAsync (c->atlas + off, src, bytes, hipMemcpyHostToDevice,
+            c->stream)) ||
+        !hip_ok (hipStreamSynchronize (c->stream)))
+      return FLUTL_ENODEV;
+    c->stage_used = 0;
+  }
   c->atlas_used = end;
   *offset_out = (uint32_t) off;
   return FLUTL_OK;
@@ -622,5 +692,205 @@ static int render_lists_to_host (flutl_ctx *c, uint32_t width, uint32_t height,
   }
   if (!hip_ok (hipStreamSynchronize (c->stream)) || !ok)
     return FLUTL_ENODEV;
+  return FLUTL_OK;
+}
+
+// ---- pooled output frames, completed asynchronously ---------------------------
+
+extern "C" int flutl_frame_create (flutl_ctx *c, uint32_t width, uint32_t height,
+    flutl_frame **out)
+{
+  if (!c || !out || width == 0 || height == 0 || width > 32767 || height > 32767)
+    return FLUTL_EINVAL;
+  *out = nullptr;
+  (void) hipSetDevice (c->device);
+  flutl_frame *f = new (std::nothrow) flutl_frame ();
+  if (!f)
+    return FLUTL_ENOMEM;
+  const size_t bytes = (size_t) width * height * 4;
+  f->device = c->device;
+  f->width = width;
+  f->height = height;
+  f->host = f->host_dev = f->twin = nullptr;
+  f->done = nullptr;
+  f->pending = false;
+  f->error = 0;
+  f->ext[0] = f->ext[1] = f->ext[2] = f->ext[3] = 0;
+  bool ok = hip_ok (hipHostMalloc (&f->host, bytes, hipHostMallocPortable | hipHostMallocMapped));
+  ok = ok && hip_ok (hipHostGetDevicePointer (&f->host_dev, f->host, 0));
+  ok = ok && hip_ok (hipMalloc (&f->twin, bytes));
+  // (system-scope release: what the kernel wrote to the host block is visible to
+  // the CPU once the event has been waited for)
+  ok = ok && hip_ok (hipEventCreateWithFlags (&f->done,
+      hipEventDisableTiming | hipEventReleaseToSystem));
+  if (ok) {
+    memset (f->host, 0, bytes);         // the transparent frame, in both copies
+    ok = hip_ok (hipMemsetAsync (f->twin, 0, bytes, c->stream)) &&
+        hip_ok (hipStreamSynchronize (c->stream));
+  }
+  if (!ok) {
+    flutl_frame_destroy (f);
+    return FLUTL_ENOMEM;
+  }
+  *out = f;
+  return FLUTL_OK;
+}
+
+extern "C" void flutl_frame_destroy (flutl_frame *f)
+{
+  if (!f)
+    return;
+  if (f->done) {
+    if (f->pending)
+      (void) hipEventSynchronize (f->done);
+    (void) hipEventDestroy (f->done);
+  }
+  if (f->twin)
+    (void) hipFree (f->twin);
+  if (f->host)
+    (void) hipHostFree (f->host);
+  delete f;
+}
+
+extern "C" void *flutl_frame_host (const flutl_frame *f) { return f ? f->host : nullptr; }
+
+extern "C" const void *flutl_frame_device (const flutl_frame *f)
+{
+  return f ? f->twin : nullptr;
+}
+
+extern "C" int flutl_frame_wait (flutl_frame *f)
+{
+  if (!f)
+    return FLUTL_EINVAL;
+  if (f->pending) {
+    // (hipEventSynchronize does not depend on the calling thread's device)
+    if (!hip_ok (hipEventSynchronize (f->done)))
+      f->error = FLUTL_ENODEV;
+    f->pending = false;
+  }
+  return f->error;
+}
+
+extern "C" uint64_t flutl_ctx_delta_bytes (flutl_ctx *c)
+{
+  uint64_t n = 0;
+  if (!c || !c->delta_segments)
+    return 0;
+  (void) hipSetDevice (c->device);
+  if (!hip_ok (hipMemcpyAsync (&n, c->delta_segments, sizeof n, hipMemcpyDeviceToHost, c->stream)) ||
+      !hip_ok (hipStreamSynchronize (c->stream)))
+    return 0;
+  return n * 256u;
+}
+
+extern "C" int flutl_frame_submit (flutl_ctx *c, flutl_frame *f,
+    const flutl_region *regions, uint32_t n_regions, const flutl_prim *prims,
+    uint32_t n_prims)
+{
+  if (!c || !f || f->device != c->device)
+    return FLUTL_EINVAL;
+  if (f->error)
+    return f->error;
+  const uint32_t width = f->width, height = f->height;
+  int rc = flutl_list_validate (width, height, regions, n_regions, prims, n_prims,
+      c->atlas_used + kAtlasSlack);
+  if (rc)
+    return rc;
+  (void) hipSetDevice (c->device);
+  // the rows the new content can occupy: the union of the region boxes
+  uint32_t now[4] = { width, height, 0, 0 };
+  for (uint32_t i = 0; i < n_regions; i++) {
+    if (regions[i].x1 <= regions[i].x0 || regions[i].y1 <= regions[i].y0)
+      continue;
+    now[0] = (uint32_t) regions[i].x0 < now[0] ? (uint32_t) regions[i].x0 : now[0];
+    now[1] = (uint32_t) regions[i].y0 < now[1] ? (uint32_t) regions[i].y0 : now[1];
+    now[2] = (uint32_t) regions[i].x1 > now[2] ? (uint32_t) regions[i].x1 : now[2];
+    now[3] = (uint32_t) regions[i].y1 > now[3] ? (uint32_t) regions[i].y1 : now[3];
+  }
+  if (now[2] <= now[0] || now[3] <= now[1])
+    now[0] = now[1] = now[2] = now[3] = 0;
+  // a list slot: the oldest submission must have finished with it
+  list_slot &sl = c->slots[c->next_slot];
+  c->next_slot = (c->next_slot + 1) % kListSlots;
+  if (sl.busy) {
+    if (!hip_ok (hipEventSynchronize (sl.done)))
+      return FLUTL_ENODEV;
+    sl.busy = false;
+  }
+  const size_t rb = ((size_t) n_regions * sizeof (flutl_region) + 31) & ~(size_t) 31;
+  const size_t pb = (size_t) n_prims * sizeof (flutl_prim);
+  if (rb + pb + 32 > sl.cap) {
+    if (sl.host)
+      (void) hipHostFree (sl.host);
+    if (sl.dev)
+      (void) hipFree (sl.dev);
+    sl.host = sl.dev = nullptr;
+    sl.cap = 0;
+    size_t cap = (size_t) 1 << 16;
+    while (cap < rb + pb + 32)
+      cap *= 2;
+    if (!hip_ok (hipHostMalloc (&sl.host, cap, hipHostMallocDefault)) ||
+        !hip_ok (hipMalloc (&sl.dev, cap)))
+      return FLUTL_ENOMEM;
+    sl.cap = cap;
+  }
+  if (!sl.done && !hip_ok (hipEventCreateWithFlags (&sl.done, hipEventDisableTiming)))
+    return FLUTL_ENODEV;
+  if (n_regions)
+    memcpy (sl.host, regions, (size_t) n_regions * sizeof (flutl_region));
+  if (n_prims)
+    memcpy (static_cast<uint8_t *> (sl.host) + rb, prims, pb);
+  // scratch frame of the context
+  const size_t need = (size_t) width * 4 * height;
+  if (need > c->frame_cap) {
+    (void) hipStreamSynchronize (c->stream);
+    if (c->frame)
+      (void) hipFree (c->frame);
+    c->frame = nullptr;
+    c->frame_cap = 0;
+    if (!hip_ok (hipMalloc (&c->frame, need)))
+      return FLUTL_ENOMEM;
+    c->frame_cap = need;
+  }
+  bool ok = true;
+  if (rb + pb)
+    ok = hip_ok (hipMemcpyAsync (sl.dev, sl.host, rb + pb, hipMemcpyHostToDevice, c->stream));
+  if (!ok)
+    return FLUTL_ENODEV;
+  const flutl_region *rd = static_cast<const flutl_region *> (sl.dev);
+  const flutl_prim *pd = reinterpret_cast<const flutl_prim *> (static_cast<uint8_t *> (sl.dev) + rb);
+  rc = flutl_launch_frame (c->stream, width, height, c->frame, (size_t) width * 4, rd,
+      n_regions, pd, c->atlas);
+  // rows of the delta: what the frame held before + what it holds now
+  uint32_t y0 = now[1], y1 = now[3];
+  if (f->ext[3] > f->ext[1]) {
+    if (y1 <= y0) {
+      y0 = f->ext[1];
+      y1 = f->ext[3];
+    } else {
+      y0 = f->ext[1] < y0 ? f->ext[1] : y0;
+      y1 = f->ext[3] > y1 ? f->ext[3] : y1;
+    }
+  }
+  if (rc == FLUTL_OK && !c->delta_segments) {
+    if (!hip_ok (hipMalloc (reinterpret_cast<void **> (&c->delta_segments), sizeof (uint64_t))) ||
+        !hip_ok (hipMemsetAsync (c->delta_segments, 0, sizeof (uint64_t), c->stream)))
+      rc = FLUTL_ENOMEM;
+  }
+  if (rc == FLUTL_OK)
+    rc = flutl_launch_delta (c->stream, c->frame, f->twin, f->host_dev, width, height, y0, y1,
+        c->delta_segments);
+  ok = rc == FLUTL_OK && hip_ok (hipEventRecord (sl.done, c->stream)) &&
+      hip_ok (hipEventRecord (f->done, c->stream));
+  sl.busy = true;
+  f->pending = true;
+  if (!ok) {
+    // whatever was queued: the frame's content is unknown from here on
+    (void) hipStreamSynchronize (c->stream);
+    f->error = rc ? rc : FLUTL_ENODEV;
+    return f->error;
+  }
+  memcpy (f->ext, now, sizeof now);
   return FLUTL_OK;
 }

@@ -65,29 +65,28 @@ enum
   PROP_WINDOW_HEIGHT
 };
 
-/* Pool of page-locked output frames.  Blocks are wrapped as GstMemory; when
- * downstream drops the buffer the block comes back here.  The pool is
- * reference counted because buffers may outlive the element.
+/* Pool of output frames.  A frame (flutl_frame, include/flutl.h) is a page-locked
+ * host block -- system memory as far as downstream is concerned -- plus its twin
+ * in HBM; it is wrapped as a GstMemory of our own allocator, and when downstream
+ * drops the buffer the frame comes back here.  The pool is reference counted
+ * because buffers may outlive the element.
  *
- * Dirty-rectangle read-back: a block is zeroed once, when it is
- * allocated, and remembers the row bands it was last written in.  A frame is
- * transparent outside its regions, so only the bands of the new frame's
- * regions plus the block's previous bands are copied from the device (which
- * renders the whole frame in HBM anyway): typical subtitles cover a fifth of
- * the frame, and the 33 MB PCIe copy is what bounds the element.  The memory is
- * handed out READONLY so that nobody scribbles outside the remembered bands and columns
- * (a downstream element that wants to write makes its copy, as GStreamer's
- * writability rules require anyway).  FLUTL_FULL_D2H=1 restores whole-frame
- * copies into writable memory. */
-#define MAX_BANDS 16
-
+ * Asynchronous completion + delta read-back: gen_buffer only QUEUES
+ * the device work of a buffer (list upload, composite, and a kernel that writes
+ * just the 256-byte segments that differ from what the frame held before, into
+ * the host block and the twin) and returns; the streaming thread records the
+ * next buffer meanwhile.  Mapping the memory waits for the frame (any thread).
+ * The memory is handed out READONLY so that nobody scribbles into the block --
+ * block and twin must stay equal (a downstream element that wants to write
+ * makes its copy, as GStreamer's writability rules require anyway).
+ * A HIP-aware consumer finds the device address of the twin as qdata
+ * "flutl-hip-device-frame" on the memory (valid once the memory has been mapped).
+ * FLUTL_FULL_D2H=1 restores synchronous whole-frame copies into writable memory. */
 typedef struct
 {
-  gpointer block;
-  guint n_bands;
-  guint32 bands[2 * MAX_BANDS];   /* [y0, y1) pairs, sorted, disjoint */
-  guint32 cols[2];                /* [x0, x1): the columns written in those rows */
-  gboolean stale;                 /* a copy into it failed: not to be recycled */
+  flutl_frame *frame;             /* asynchronous mode */
+  gpointer block;                 /* FLUTL_FULL_D2H: a plain page-locked block */
+  gboolean stale;                 /* a render into it failed: not to be recycled */
 } FrameSlot;
 
 typedef struct
@@ -118,7 +117,10 @@ frame_pool_new (void)
 static void
 frame_slot_free (FrameSlot *s)
 {
-  flutl_host_free (s->block);
+  if (s->frame)
+    flutl_frame_destroy (s->frame);
+  if (s->block)
+    flutl_host_free (s->block);
   g_free (s);
 }
 
@@ -150,14 +152,99 @@ frame_block_release (gpointer data)
   g_free (b);
 }
 
-/* A GstBuffer over a recycled page-locked block (system memory as far as
- * downstream is concerned), or NULL if page-locked memory is unavailable.
- * *slot_out: the block's band memory (all-zero block if n_bands == 0 and fresh). */
-static GstBuffer *
-frame_pool_acquire (FramePool *p, gsize size, gboolean readonly, FrameSlot **slot_out)
+/* ---- GstMemory over a frame: map = wait for the frame ------------------------- */
+typedef struct
 {
+  GstMemory mem;
+  FrameBlock *block;              /* NULL for sub-memories (they hold the parent) */
+  flutl_frame *frame;
+  guint8 *data;
+} FlutlMemory;
+
+typedef struct { GstAllocator parent; } FlutlAllocator;
+typedef struct { GstAllocatorClass parent_class; } FlutlAllocatorClass;
+GType flutl_allocator_get_type (void);
+G_DEFINE_TYPE (FlutlAllocator, flutl_allocator, GST_TYPE_ALLOCATOR);
+
+static gpointer
+flutl_mem_map (GstMemory *mem, gsize maxsize, GstMapFlags flags)
+{
+  FlutlMemory *m = (FlutlMemory *) mem;
+  if (flutl_frame_wait (m->frame) != FLUTL_OK) {
+    GST_ERROR ("ttmlrender: the frame behind this memory failed to render");
+    return NULL;
+  }
+  return m->data;
+}
+
+static void
+flutl_mem_unmap (GstMemory *mem)
+{
+}
+
+static GstMemory *
+flutl_mem_share (GstMemory *mem, gssize offset, gssize size)
+{
+  FlutlMemory *m = (FlutlMemory *) mem, *sub;
+  GstMemory *parent = mem->parent ? mem->parent : mem;
+  if (size == -1)
+    size = mem->size - offset;
+  sub = g_new0 (FlutlMemory, 1);
+  gst_memory_init (GST_MEMORY_CAST (sub),
+      GST_MINI_OBJECT_FLAGS (parent) | GST_MINI_OBJECT_FLAG_LOCK_READONLY, mem->allocator,
+      parent, mem->maxsize, mem->align, mem->offset + offset, size);
+  sub->frame = m->frame;
+  sub->data = m->data;
+  return GST_MEMORY_CAST (sub);
+}
+
+static void
+flutl_allocator_free (GstAllocator *allocator, GstMemory *mem)
+{
+  FlutlMemory *m = (FlutlMemory *) mem;
+  if (m->block)
+    frame_block_release (m->block);
+  g_free (m);
+}
+
+static void
+flutl_allocator_class_init (FlutlAllocatorClass *klass)
+{
+  GstAllocatorClass *ac = GST_ALLOCATOR_CLASS (klass);
+  ac->alloc = NULL;               /* frames come from the element's pool only */
+  ac->free = flutl_allocator_free;
+}
+
+static void
+flutl_allocator_init (FlutlAllocator *self)
+{
+  GstAllocator *a = GST_ALLOCATOR_CAST (self);
+  a->mem_type = "FlutlHipFrame";
+  a->mem_map = flutl_mem_map;
+  a->mem_unmap = flutl_mem_unmap;
+  a->mem_share = flutl_mem_share;
+  GST_OBJECT_FLAG_SET (self, GST_ALLOCATOR_FLAG_CUSTOM_ALLOC);
+}
+
+static GstAllocator *
+flutl_allocator_get (void)
+{
+  static gsize once = 0;
+  static GstAllocator *a = NULL;
+  if (g_once_init_enter (&once)) {
+    a = g_object_new (flutl_allocator_get_type (), NULL);
+    gst_object_ref_sink (a);
+    g_once_init_leave (&once, 1);
+  }
+  return a;
+}
+
+/* A slot of the pool (recycled, or made on `ctx`), or NULL. */
+static FrameSlot *
+frame_pool_take (FramePool *p, flutl_ctx *ctx, gint width, gint height, gboolean async)
+{
+  const gsize size = (gsize) width * height * 4;
   FrameSlot *slot = NULL;
-  FrameBlock *b;
   g_mutex_lock (&p->lock);
   if (p->block_size != size) {
     for (guint i = 0; i < p->free_slots->len; i++)
@@ -165,59 +252,54 @@ frame_pool_acquire (FramePool *p, gsize size, gboolean readonly, FrameSlot **slo
     g_ptr_array_set_size (p->free_slots, 0);
     p->block_size = size;
   }
-  if (p->free_slots->len)
-    slot = g_ptr_array_remove_index_fast (p->free_slots, p->free_slots->len - 1);
-  g_mutex_unlock (&p->lock);
-  if (!slot) {
-    gpointer block = NULL;
-    if (flutl_host_alloc (size, &block) != FLUTL_OK)
-      return NULL;
-    memset (block, 0, size);      /* once per block: the transparent frame */
-    slot = g_new0 (FrameSlot, 1);
-    slot->block = block;
+  for (guint i = p->free_slots->len; i-- > 0 && !slot;) {
+    FrameSlot *c = g_ptr_array_index (p->free_slots, i);
+    if ((c->frame != NULL) == async)
+      slot = g_ptr_array_remove_index_fast (p->free_slots, i);
   }
-  b = g_new0 (FrameBlock, 1);
+  g_mutex_unlock (&p->lock);
+  if (slot)
+    return slot;
+  slot = g_new0 (FrameSlot, 1);
+  if (async) {
+    if (flutl_frame_create (ctx, width, height, &slot->frame) != FLUTL_OK) {
+      g_free (slot);
+      return NULL;
+    }
+  } else {
+    if (flutl_host_alloc (size, &slot->block) != FLUTL_OK) {
+      g_free (slot);
+      return NULL;
+    }
+  }
+  return slot;
+}
+
+/* A GstBuffer over a pooled slot; the slot returns to the pool with the buffer. */
+static GstBuffer *
+frame_pool_wrap (FramePool *p, FrameSlot *slot, gsize size)
+{
+  FrameBlock *b = g_new0 (FrameBlock, 1);
+  GstBuffer *buffer;
   b->pool = p;
   b->slot = slot;
   b->size = size;
   g_atomic_int_inc (&p->refs);
-  *slot_out = slot;
-  return gst_buffer_new_wrapped_full (readonly ? GST_MEMORY_FLAG_READONLY : 0, slot->block,
-      size, 0, size, b, frame_block_release);
-}
-
-/* Sort + merge [y0, y1) pairs in place (also bands closer than 8 rows: fewer,
- * larger copies); more than MAX_BANDS collapse into one.  Returns the count. */
-static guint
-bands_normalise (guint32 *bands, guint n)
-{
-  guint i, j, out = 0;
-  for (i = 1; i < n; i++) {     /* insertion sort by y0: n is small */
-    guint32 a = bands[2 * i], c = bands[2 * i + 1];
-    for (j = i; j > 0 && bands[2 * (j - 1)] > a; j--) {
-      bands[2 * j] = bands[2 * (j - 1)];
-      bands[2 * j + 1] = bands[2 * (j - 1) + 1];
-    }
-    bands[2 * j] = a;
-    bands[2 * j + 1] = c;
+  if (slot->frame) {
+    FlutlMemory *m = g_new0 (FlutlMemory, 1);
+    gst_memory_init (GST_MEMORY_CAST (m), GST_MEMORY_FLAG_READONLY, flutl_allocator_get (),
+        NULL, size, 0, 0, size);
+    m->block = b;
+    m->frame = slot->frame;
+    m->data = flutl_frame_host (slot->frame);
+    gst_mini_object_set_qdata (GST_MINI_OBJECT_CAST (m),
+        g_quark_from_static_string ("flutl-hip-device-frame"),
+        (gpointer) flutl_frame_device (slot->frame), NULL);
+    buffer = gst_buffer_new ();
+    gst_buffer_append_memory (buffer, GST_MEMORY_CAST (m));
+    return buffer;
   }
-  for (i = 0; i < n; i++) {
-    if (bands[2 * i] >= bands[2 * i + 1])
-      continue;
-    if (out && bands[2 * i] <= bands[2 * (out - 1) + 1] + 8) {
-      if (bands[2 * i + 1] > bands[2 * (out - 1) + 1])
-        bands[2 * (out - 1) + 1] = bands[2 * i + 1];
-    } else {
-      bands[2 * out] = bands[2 * i];
-      bands[2 * out + 1] = bands[2 * i + 1];
-      out++;
-    }
-  }
-  if (out > MAX_BANDS) {
-    bands[1] = bands[2 * (out - 1) + 1];
-    out = 1;
-  }
-  return out;
+  return gst_buffer_new_wrapped_full (0, slot->block, size, 0, size, b, frame_block_release);
 }
 
 /* Device-side state of one element instance. */
@@ -251,6 +333,7 @@ typedef struct
   GHashTable *layouts;       /* layout cache: key string -> PangoLayout, per document */
   gboolean no_layout_cache;  /* FLUTL_NO_LAYOUT_CACHE=1 */
   guint skipped;             /* outlines of this buffer that could not be drawn */
+  guint64 delta_reported;
 } GstTTMLRenderPrivate;
 
 static GstStaticPadTemplate ttmlrender_src_template =
@@ -1559,61 +1642,29 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
     return NULL;
   {
     GstMapInfo map;
-    FrameSlot *slot = NULL;
+    const gsize size = (gsize) width * height * 4;
+    FrameSlot *slot = frame_pool_take (priv->pool, priv->ctx, width, height, !priv->full_d2h);
     int rc;
-    buffer = frame_pool_acquire (priv->pool, (gsize) width * height * 4, !priv->full_d2h,
-        &slot);
-    if (buffer && !priv->full_d2h) {
-      /* rows to read back: this frame's regions + what the block held before */
-      guint32 *bands = g_new (guint32, 2 * (n_rg + slot->n_bands) + 2);
-      guint32 now[2 * MAX_BANDS + 2];
-      guint n = 0, n_now, i;
-      for (i = 0; i < n_rg; i++) {
-        bands[2 * n] = (guint32) CLAMP (rg[i].y0, 0, height);
-        bands[2 * n + 1] = (guint32) CLAMP (rg[i].y1, 0, height);
-        n++;
-      }
-      n_now = bands_normalise (bands, n);
-      memcpy (now, bands, sizeof (guint32) * 2 * n_now);
-      memcpy (bands + 2 * n_now, slot->bands, sizeof (guint32) * 2 * slot->n_bands);
-      n = bands_normalise (bands, n_now + slot->n_bands);
-      /* ... and of those rows the columns any region reaches, now or before */
-      guint32 c0 = (guint32) width, c1 = 0, c0_now, c1_now;
-      for (i = 0; i < n_rg; i++) {
-        c0 = MIN (c0, (guint32) CLAMP (rg[i].x0, 0, width));
-        c1 = MAX (c1, (guint32) CLAMP (rg[i].x1, 0, width));
-      }
-      c0_now = c0;
-      c1_now = c1;
-      if (slot->n_bands) {
-        c0 = MIN (c0, slot->cols[0]);
-        c1 = MAX (c1, slot->cols[1]);
-      }
-      if (n == 0 || c0 >= c1)     /* nothing now, nothing before: the block is already the frame */
-        rc = FLUTL_OK;
-      else
-        rc = flutl_render_frame_window_to_host (priv->ctx, width, height, rg, n_rg, pr, n_pr,
-            slot->block, (size_t) width * 4, bands, n, c0, c1);
-      if (rc != FLUTL_OK)         /* what the block holds is unknown now */
-        slot->stale = TRUE;
-      memcpy (slot->bands, now, sizeof (guint32) * 2 * n_now);
-      slot->n_bands = n_now;
-      slot->cols[0] = c0_now;
-      slot->cols[1] = c1_now;
-      g_free (bands);
-    } else if (buffer) {
+    if (slot && slot->frame) {
+      /* queue the frame and go on: the buffer is complete when its memory is mapped */
+      buffer = frame_pool_wrap (priv->pool, slot, size);
+      rc = flutl_frame_submit (priv->ctx, slot->frame, rg, n_rg, pr, n_pr);
+    } else if (slot) {
+      buffer = frame_pool_wrap (priv->pool, slot, size);
       rc = flutl_render_frame_to_host (priv->ctx, width, height, rg, n_rg, pr, n_pr,
           slot->block, (size_t) width * 4);
     } else {                    /* no page-locked memory: plain system buffer */
-      buffer = gst_buffer_new_and_alloc ((gsize) width * height * 4);
+      buffer = gst_buffer_new_and_alloc (size);
       gst_buffer_map (buffer, &map, GST_MAP_WRITE);
       rc = flutl_render_frame_to_host (priv->ctx, width, height, rg, n_rg, pr, n_pr,
           map.data, (size_t) width * 4);
       gst_buffer_unmap (buffer, &map);
     }
     if (rc != FLUTL_OK) {
+      if (slot)
+        slot->stale = TRUE;     /* what it holds is unknown now */
       GST_ELEMENT_ERROR (render, LIBRARY, FAILED, ("ttmlrender: HIP render failed"),
-          ("flutl_render_frame_to_host: %s", flutl_strerror (rc)));
+          ("%s", flutl_strerror (rc)));
       gst_buffer_unref (buffer);
       return NULL;
     }
@@ -1637,10 +1688,14 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
   }
   if (priv->timing) {
     gint64 t_end = g_get_monotonic_time ();
-    priv->t_record += t_recorded - t_start;
-    priv->t_device += t_end - t_recorded;
-    if (priv->n_timed++ == 0)
+    /* (averages from the second buffer on, like the span: the first one makes
+     * every mask of the document) */
+    if (priv->n_timed++ == 0) {
       priv->t_first_return = t_end;
+    } else {
+      priv->t_record += t_recorded - t_start;
+      priv->t_device += t_end - t_recorded;
+    }
     priv->t_last_return = t_end;
   }
   return buffer;
@@ -1744,19 +1799,33 @@ gst_ttmlrender_set_property (GObject *object, guint id, const GValue *value,
 }
 
 /* FLUTL_TIMING=1: one line per document on stderr (tools/e2e_timing.py reads it).
- * span = end of the first gen_buffer to end of the last; drained = to the moment
- * every frame of the document was complete in host memory. */
+ * record = host time per buffer from scene state to display list; device = host
+ * time per buffer spent queuing the device work (or, with FLUTL_FULL_D2H, waiting
+ * for it); span = end of the first gen_buffer to end of the last; drained = to
+ * the moment every frame of the document was complete in host memory. */
 static void
 timing_report (GstTTMLRender *render)
 {
   GstTTMLRenderPrivate *priv = get_priv (render);
+  gint64 t_drained;
+  guint64 delta = 0;
   if (!priv->timing || !priv->n_timed)
     return;
+  if (priv->ctx) {
+    flutl_ctx_sync (priv->ctx);
+    t_drained = g_get_monotonic_time ();
+    delta = flutl_ctx_delta_bytes (priv->ctx) - priv->delta_reported;
+    priv->delta_reported += delta;
+  } else {
+    t_drained = priv->t_last_return;
+  }
   g_printerr ("ttmlrender-hip timing: buffers=%u record_us=%.1f device_us=%.1f "
-      "span_us=%" G_GINT64_FORMAT " drained_us=%" G_GINT64_FORMAT "\n", priv->n_timed,
-      (double) priv->t_record / priv->n_timed, (double) priv->t_device / priv->n_timed,
+      "span_us=%" G_GINT64_FORMAT " drained_us=%" G_GINT64_FORMAT " delta_bytes=%.0f\n",
+      priv->n_timed, (double) priv->t_record / MAX (priv->n_timed - 1, 1),
+      (double) priv->t_device / MAX (priv->n_timed - 1, 1),
       priv->t_last_return - priv->t_first_return,
-      priv->t_last_return - priv->t_first_return);   /* (gen_buffer is synchronous) */
+      MAX (t_drained, priv->t_last_return) - priv->t_first_return,
+      (double) delta / priv->n_timed);
   priv->n_timed = 0;
   priv->t_record = priv->t_device = 0;
 }
@@ -1767,6 +1836,7 @@ gst_ttmlrender_reset (GstTTMLBase *base)
 {
   GstTTMLRender *render = GST_TTMLRENDER (base);
   GstTTMLRenderPrivate *priv = get_priv (render);
+  timing_report (render);       /* (the document ends here: its frames are drained) */
   /* per-document caches: decoded images, layouts, glyph/outline atlas (host + HBM) */
   if (priv->images) {
     g_hash_table_unref (priv->images);

@@ -51,6 +51,8 @@ EXPORTS = [
     "flutl_host_alloc", "flutl_host_free", "flutl_render_frame_to_host",
     "flutl_render_frame_rows_to_host", "flutl_render_frame_window_to_host",
     "flutl_atlas_put_blurred",
+    "flutl_launch_delta", "flutl_frame_create", "flutl_frame_destroy", "flutl_frame_host",
+    "flutl_frame_device", "flutl_frame_submit", "flutl_frame_wait", "flutl_ctx_delta_bytes",
 ]
 
 
@@ -106,6 +108,18 @@ def lib():
                                               vp, ctypes.POINTER(u32)]
         L.flutl_launch_rotate_cw.argtypes = [vp, vp, vp, u32, u32, sz, sz, vp]
         L.flutl_launch_resample.argtypes = [vp, vp, vp, u32, u32, sz, sz, u32, u32, vp]
+        L.flutl_launch_delta.argtypes = [vp, vp, vp, vp, u32, u32, u32, u32, vp]
+        L.flutl_frame_create.argtypes = [vp, u32, u32, ctypes.POINTER(vp)]
+        L.flutl_frame_destroy.argtypes = [vp]
+        L.flutl_frame_destroy.restype = None
+        L.flutl_frame_host.argtypes = [vp]
+        L.flutl_frame_host.restype = vp
+        L.flutl_frame_device.argtypes = [vp]
+        L.flutl_frame_device.restype = vp
+        L.flutl_frame_submit.argtypes = [vp, vp, vp, u32, vp, u32]
+        L.flutl_frame_wait.argtypes = [vp]
+        L.flutl_ctx_delta_bytes.argtypes = [vp]
+        L.flutl_ctx_delta_bytes.restype = ctypes.c_uint64
         L.flutl_host_alloc.argtypes = [sz, ctypes.POINTER(vp)]
         L.flutl_host_free.argtypes = [vp]
         L.flutl_host_free.restype = None
@@ -193,6 +207,15 @@ def launch_blur(stream, src, dst, w, h, kernel_dev, radius, stride=None):
     _check(lib().flutl_launch_blur(ctypes.c_void_p(stream), p(src), p(dst), w, h,
                                    stride or w * 4, p(kernel_dev), radius),
            "flutl_launch_blur")
+
+
+def launch_delta(stream, fresh, twin, host, width, height, row0, row1, counter=None):
+    """segments of rows [row0, row1) where fresh != twin are written to twin and host"""
+    p = _dev_ptr
+    _check(lib().flutl_launch_delta(ctypes.c_void_p(stream), p(fresh), p(twin), p(host),
+                                    width, height, row0, row1,
+                                    None if counter is None else p(counter)),
+           "flutl_launch_delta")
 
 
 # ---- context API (library-owned HBM), as the GStreamer element uses it ----
@@ -312,3 +335,43 @@ class Context:
 
     def sync(self):
         _check(lib().flutl_ctx_sync(self._h), "flutl_ctx_sync")
+
+    def delta_bytes(self):
+        return int(lib().flutl_ctx_delta_bytes(self._h))
+
+    def frame(self, width, height):
+        return Frame(self, width, height)
+
+
+class Frame:
+    """A pooled output frame of the element: page-locked host block + HBM twin,
+    filled asynchronously (flutl_frame_submit) by delta read-back."""
+
+    def __init__(self, ctx, width, height):
+        h = ctypes.c_void_p()
+        _check(lib().flutl_frame_create(ctx._h, width, height, ctypes.byref(h)),
+               "flutl_frame_create")
+        self._h, self.ctx, self.width, self.height = h, ctx, width, height
+
+    def close(self):
+        if self._h:
+            lib().flutl_frame_destroy(self._h)
+            self._h = None
+
+    def submit(self, regions, prims):
+        regions = np.ascontiguousarray(regions, REGION_DTYPE)
+        prims = np.ascontiguousarray(prims, PRIM_DTYPE)
+        _check(lib().flutl_frame_submit(self.ctx._h, self._h, _np_ptr(regions), len(regions),
+                                        _np_ptr(prims), len(prims)), "flutl_frame_submit")
+
+    def wait(self):
+        _check(lib().flutl_frame_wait(self._h), "flutl_frame_wait")
+
+    def host(self):
+        """the host block as a (height, width) uint32 array (a view, not a copy)"""
+        ptr = lib().flutl_frame_host(self._h)
+        return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint32)),
+                                     shape=(self.height, self.width))
+
+    def device_ptr(self):
+        return int(lib().flutl_frame_device(self._h))

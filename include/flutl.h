@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FLUTL_ABI_VERSION 1
+#define FLUTL_ABI_VERSION 2
 
 /* ---- error codes --------------------------------------------------------- */
 #define FLUTL_OK       0
@@ -196,6 +196,20 @@ int flutl_launch_rotate_cw (void *stream, const void *src, void *dst,
     uint32_t w, uint32_t h, size_t src_stride_bytes, size_t dst_stride_bytes,
     const int32_t *box);
 
+/* Delta read-back: compares the rows [row0, row1) of a freshly composited frame
+ * (`fresh`, device, tight rows of 4*width bytes) with `twin` (device, same
+ * layout) 256 bytes at a time and writes the segments that differ into `twin`
+ * and into `host` -- page-locked host memory mapped into the device (the device
+ * address of a flutl_host_alloc block), same layout.  With twin == host's
+ * content before the call, both equal `fresh` on those rows afterwards; only
+ * what changed crosses PCIe.  This is the "dirty-rect D2H into pre-zeroed
+ * buffers" of a pooled output frame (replaces the whole-frame write of
+ * gstttmlrender.c:1442-1452).  changed_segments (device, or NULL): incremented
+ * by the number of 256-byte segments written. */
+int flutl_launch_delta (void *stream, const void *fresh, void *twin, void *host,
+    uint32_t width, uint32_t height, uint32_t row0, uint32_t row1,
+    uint64_t *changed_segments);
+
 /* ---- context API (library-owned HBM; what the GStreamer element uses) ---- */
 
 typedef struct flutl_ctx flutl_ctx;     /* one per element instance / thread  */
@@ -282,6 +296,35 @@ int  flutl_render_frame_window_to_host (flutl_ctx *ctx, uint32_t width, uint32_t
     const flutl_prim *prims, uint32_t n_prims,
     void *dst_host, size_t dst_stride_bytes,
     const uint32_t *row_bands, uint32_t n_bands, uint32_t col0, uint32_t col1);
+
+/* ---- pooled output frames, completed asynchronously ----------------------
+ * A flutl_frame is one output frame of the element: a page-locked host block
+ * (what downstream maps: system memory, tight rows of 4*width bytes, initially
+ * transparent) and its twin in HBM (what a HIP-aware consumer reads: the same
+ * pixels, device resident).  flutl_frame_submit queues, on the context's
+ * stream and without waiting: the display list's upload, the composite into the
+ * context's scratch frame and the delta read-back into block + twin
+ * (flutl_launch_delta over the rows this or the previous content of the frame
+ * can occupy); it returns as soon as the work is queued, so the caller records
+ * the next buffer while this one renders (the reference renders synchronously
+ * inside gen_buffer, gstttmlrender.c:1446-1477).  flutl_frame_wait blocks until
+ * the last submission into the frame has completed (any thread; this is what
+ * the element's GstMemory map does).  At most a few submissions are in flight
+ * per context; a further one waits for the oldest.  A frame may outlive its
+ * context.  The list memory may be reused by the caller right after submit. */
+typedef struct flutl_frame flutl_frame;
+int   flutl_frame_create (flutl_ctx *ctx, uint32_t width, uint32_t height,
+    flutl_frame **out);
+void  flutl_frame_destroy (flutl_frame *frame);
+void *flutl_frame_host (const flutl_frame *frame);
+const void *flutl_frame_device (const flutl_frame *frame);
+int   flutl_frame_submit (flutl_ctx *ctx, flutl_frame *frame,
+    const flutl_region *regions, uint32_t n_regions,
+    const flutl_prim *prims, uint32_t n_prims);
+int   flutl_frame_wait (flutl_frame *frame);
+/* bytes all submissions on this context have written to host blocks so far
+ * (drains the context's stream; statistics) */
+uint64_t flutl_ctx_delta_bytes (flutl_ctx *ctx);
 
 /* Page-locked host memory for output frames: a D2H copy into it is a true
  * asynchronous DMA at PCIe rate (pageable memory goes through a bounce buffer

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(F.LIB_PATH)
     for name in _declared_symbols():
         assert hasattr(L, name), name
-    assert L.flutl_abi_version() == 1
+    assert L.flutl_abi_version() == 2
 
 
 def test_struct_layout_matches_header():

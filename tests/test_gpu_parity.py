@@ -391,3 +391,82 @@ def test_context_blurred_atlas_entries(gpu):
         exp = O.group(np.ascontiguousarray(turned).reshape(-1), cov.astype(np.uint32).reshape(-1),
                       np.zeros(turned.size, np.uint32)).reshape(turned.shape)
         assert both.shape == (W + 1, H + 1) and np.array_equal(both, exp)
+
+
+def _twin_of(frame):
+    """the HBM twin of a frame, brought out with the library's own stateless delta
+    launch: against an all-zero "twin" every non-zero 256-byte segment is copied"""
+    import torch
+    n = frame.width * frame.height * 4
+    a = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    b = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    frame.ctx.sync()
+    F.launch_delta(torch.cuda.current_stream().cuda_stream, frame.device_ptr(), a, b,
+                   frame.width, frame.height, 0, frame.height)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    return b.cpu().numpy().view(np.uint32).reshape(frame.height, frame.width)
+
+
+@pytest.mark.parametrize("size", [(320, 180), (333, 77), (1920, 1080)])
+def test_frame_submit_delta_readback_tracks_every_state(gpu, size):
+    """The element's asynchronous per-buffer path (flutl_frame_submit): a sequence of
+    different lists into ONE pooled frame -- host block and HBM twin must equal the
+    oracle's frame after each, whatever the frame held before (delta read-back),
+    including an empty list in between and widths whose rows are not 16-byte
+    multiples."""
+    W, H = size
+    lists = [scenes.random_scene(100 + i, W, H, n_regions=1 + i % 5) for i in range(6)]
+    Rm, Pm, A, _ = _concat_lists(lists, W, H)
+    with F.Context(0) as ctx:
+        assert ctx.atlas_put(A[F.ATLAS_SLACK:]) == F.ATLAS_SLACK
+        fr = ctx.frame(W, H)
+        try:
+            assert not fr.host().any()
+            first = 0
+            order = [0, 1, 1, None, 2, 3, 0, 4, None, None, 5]
+            for k in order:
+                if k is None:
+                    R, P = Rm[:0], Pm[:0]
+                else:
+                    nr = len(lists[k][0])
+                    lo = sum(len(l[0]) for l in lists[:k])
+                    R = Rm[lo:lo + nr].copy()
+                    P = Pm
+                fr.submit(R, P)
+                fr.wait()
+                exp = O.render(W, H, R, P, A) if k is not None else np.zeros((H, W), np.uint32)
+                assert np.array_equal(fr.host(), exp), f"host block differs after state {k}"
+                assert np.array_equal(_twin_of(fr), exp), f"twin differs after state {k}"
+        finally:
+            fr.close()
+
+
+def test_frame_submit_pipelines_without_waiting_in_between(gpu):
+    """Submissions are queued, not waited for: many frames in flight through the
+    list-slot ring (deeper than the ring), several pooled frames in rotation, one
+    wait at the end of each -- every frame must hold ITS state; and the bytes
+    moved to the host are far fewer than whole frames when little changes."""
+    W, H = 640, 360
+    R, P, A = scenes.subtitle_like_scene(7, W, H, n_regions=4, font_px=24, outline_px=2, lines=1)
+    glyph = np.nonzero((P["op"] == F.OP_MASK) & (P["rule"] == F.RULE_PIXMAN))[0]
+    states = []
+    for s in range(12):            # recolour a handful of glyphs: a <set> on tts:color
+        Ps = P.copy()
+        Ps["color"][glyph[s % len(glyph)::7]] = 0xff000000 | (0x123457 * (s + 1) & 0xffffff)
+        states.append(Ps)
+    with F.Context(0) as ctx:
+        ctx.atlas_put(A[F.ATLAS_SLACK:])
+        frames = [ctx.frame(W, H) for _ in range(3)]
+        try:
+            for s, Ps in enumerate(states):
+                frames[s % 3].submit(R, Ps)
+            for k in (0, 1, 2):      # the last state each frame received
+                last = max(s for s in range(len(states)) if s % 3 == k)
+                frames[k].wait()
+                assert np.array_equal(frames[k].host(), O.render(W, H, R, states[last], A))
+            moved = ctx.delta_bytes()
+            assert 0 < moved < len(states) * W * H * 4 // 2
+        finally:
+            for f in frames:
+                f.close()
