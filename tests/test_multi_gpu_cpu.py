@@ -102,6 +102,8 @@ def test_bench_gpus_n_starts_n_ranks_itself(tmp_path):
         env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")}
         r = subprocess.run([sys.executable, "-c", code], env=env, timeout=120)
         assert r.returncode == want_rc
+        if mode == "fail":      # (the launcher ends the other ranks when one dies)
+            continue
         ranks = [json.load(open(str(tmp_path / "rank") + str(i))) for i in range(4)]
         assert [x["RANK"] for x in ranks] == ["0", "1", "2", "3"]
         assert all(x["WORLD_SIZE"] == "4" and x["MASTER_ADDR"] == "127.0.0.1" for x in ranks)
