@@ -65,11 +65,15 @@ typedef struct
   cairo_matrix_t m;
 } PathOp;
 
+struct StrokeJob;
+
 typedef struct
 {
   uint64_t hash;
   uint8_t *key;
   size_t key_len;
+  struct StrokeJob *job;     /* being rasterised on a worker thread: offset, x, y, w, h
+                              * are not known yet (see "deferred strokes" below) */
   int base_x, base_y;        /* integer base the key is relative to, raster coordinates */
   int translatable;          /* made clear of its limits: valid at any integer
                               * translation that stays clear of the limits there */
@@ -116,6 +120,15 @@ struct FlutlRecorder
   cairo_scaled_font_t **key_fonts;
   uint32_t n_key_fonts, cap_key_fonts;
 
+  /* deferred strokes (root recorder only): what the streaming thread and the
+   * thread that resolves frames share -- atlas, mask table, stroke cache, the
+   * log of new atlas entries -- is guarded by `lock` */
+  GRecMutex lock;
+  int defer;
+  FlutlPatch *patches;
+  uint32_t n_patches, cap_patches;
+  int region_deferred;        /* the open region holds a placeholder */
+
   int has_clip, clip[4];      /* x0,y0,x1,y1 */
   int in_group, group[4];
   int shift[2];                 /* frame = CTM coordinates + shift (integers) */
@@ -130,6 +143,10 @@ struct FlutlRecorder
 
 static void path_ops_clear (FlutlRecorder *rec);
 static void raster_origin (const FlutlRecorder *rec, int *ox, int *oy);
+static void stroke_job_wait (struct StrokeJob *j);
+static void stroke_job_unref (struct StrokeJob *j);
+static int effective_clip (FlutlRecorder *rec, int c[4]);
+static int mask_prim_place (flutl_prim *p, const StrokeEntry *e, int ox, int oy, const int c[4]);
 
 /* ---- small helpers --------------------------------------------------------- */
 
@@ -142,8 +159,31 @@ xrealloc (void *p, size_t n)
   return q;
 }
 
+static FlutlRecorder *
+root_of (FlutlRecorder *rec)
+{
+  while (rec->parent)
+    rec = rec->parent;
+  return rec;
+}
+
+void
+flutl_recorder_lock (FlutlRecorder *rec)
+{
+  g_rec_mutex_lock (&root_of (rec)->lock);
+}
+
+void
+flutl_recorder_unlock (FlutlRecorder *rec)
+{
+  g_rec_mutex_unlock (&root_of (rec)->lock);
+}
+
 static uint32_t
 atlas_put_ex (FlutlRecorder *rec, const void *src, size_t bytes, int on_device);
+
+static uint32_t
+atlas_put_locked (FlutlRecorder *rec, const void *src, size_t bytes, int on_device);
 
 static uint32_t
 atlas_put (FlutlRecorder *rec, const void *src, size_t bytes)
@@ -156,6 +196,15 @@ atlas_put_ex (FlutlRecorder *rec, const void *src, size_t bytes, int on_device)
 {
   if (rec->parent)
     return atlas_put_ex (rec->parent, src, bytes, on_device);
+  g_rec_mutex_lock (&rec->lock);
+  uint32_t r = atlas_put_locked (rec, src, bytes, on_device);
+  g_rec_mutex_unlock (&rec->lock);
+  return r;
+}
+
+static uint32_t
+atlas_put_locked (FlutlRecorder *rec, const void *src, size_t bytes, int on_device)
+{
   size_t off = (rec->atlas_size + ATLAS_ALIGN - 1) & ~(size_t) (ATLAS_ALIGN - 1);
   size_t end = off + bytes;
   if (end + ATLAS_SLACK > rec->atlas_cap) {
@@ -204,13 +253,15 @@ atlas_put_dedup (FlutlRecorder *rec, const uint8_t *src, size_t bytes)
   uint64_t h = hash_bytes (src, bytes);
   /* (a child recorder keeps its own table of masks, but the bytes live in the
    * parent's atlas, see atlas_put_ex) */
-  const FlutlRecorder *root = rec;
-  while (root->parent)
-    root = root->parent;
+  FlutlRecorder *root = root_of (rec);
+  g_rec_mutex_lock (&root->lock);
   for (uint32_t i = 0; i < rec->n_masks; i++)
     if (rec->masks[i].hash == h && rec->masks[i].bytes == bytes &&
-        memcmp (root->atlas + rec->masks[i].offset, src, bytes) == 0)
-      return rec->masks[i].offset;
+        memcmp (root->atlas + rec->masks[i].offset, src, bytes) == 0) {
+      uint32_t found = rec->masks[i].offset;
+      g_rec_mutex_unlock (&root->lock);
+      return found;
+    }
   if (rec->n_masks == rec->cap_masks) {
     rec->cap_masks = rec->cap_masks ? rec->cap_masks * 2 : 64;
     rec->masks = xrealloc (rec->masks, rec->cap_masks * sizeof (MaskEntry));
@@ -220,6 +271,7 @@ atlas_put_dedup (FlutlRecorder *rec, const uint8_t *src, size_t bytes)
   rec->masks[rec->n_masks].offset = off;
   rec->masks[rec->n_masks].bytes = (uint32_t) bytes;
   rec->n_masks++;
+  g_rec_mutex_unlock (&root->lock);
   return off;
 }
 
@@ -371,6 +423,7 @@ flutl_recorder_new (void)
     abort ();
   rec->atlas_size = ATLAS_SLACK;
   rec->line_split = g_getenv ("FLUTL_LINE_SPLIT") != NULL;
+  g_rec_mutex_init (&rec->lock);
   return rec;
 }
 
@@ -432,8 +485,13 @@ drop_caches (FlutlRecorder *rec)
     cairo_surface_destroy (rec->images[i].surface);
   rec->n_images = 0;
   rec->n_masks = 0;
-  for (uint32_t i = 0; i < rec->n_strokes; i++)
+  for (uint32_t i = 0; i < rec->n_strokes; i++) {
     free (rec->strokes[i].key);
+    if (rec->strokes[i].job) {      /* (the caller has resolved every frame: it is done) */
+      stroke_job_wait (rec->strokes[i].job);
+      stroke_job_unref (rec->strokes[i].job);
+    }
+  }
   rec->n_strokes = 0;
   for (uint32_t i = 0; i < rec->n_key_fonts; i++)
     cairo_scaled_font_destroy (rec->key_fonts[i]);
@@ -471,6 +529,8 @@ flutl_recorder_free (FlutlRecorder *rec)
   free (rec->ops);
   free (rec->strokes);
   free (rec->key_fonts);
+  free (rec->patches);
+  g_rec_mutex_clear (&rec->lock);
   free (rec);
 }
 
@@ -499,6 +559,8 @@ flutl_recorder_begin_frame (FlutlRecorder *rec, int width, int height)
   rec->frame_clear = 1;
   rec->group_clear = 1;
   rec->unsupported = 0;
+  rec->n_patches = 0;
+  rec->region_deferred = 0;
   path_ops_clear (rec);
   flutl_recorder_set_color (rec, 0, 0, 0, 1);
 }
@@ -538,6 +600,7 @@ flutl_recorder_region_begin (FlutlRecorder *rec)
 {
   rec->region_first = rec->n_prims;
   rec->in_region = 1;
+  rec->region_deferred = 0;
   rec->shift[0] = rec->shift[1] = 0;
 }
 
@@ -573,7 +636,11 @@ flutl_recorder_region_end (FlutlRecorder *rec)
     x1 = imax (x1, p->cx1);
     y1 = imax (y1, p->cy1);
   }
-  if (x1 <= x0 || y1 <= y0) {   /* nothing visible */
+  if ((x1 <= x0 || y1 <= y0) && rec->region_deferred) {
+    /* nothing visible YET: a placeholder's mask is still being made;
+     * flutl_recorder_resolve gives the region its box */
+    x0 = y0 = x1 = y1 = 0;
+  } else if (x1 <= x0 || y1 <= y0) {   /* nothing visible */
     rec->n_prims = rec->region_first;
     return;
   }
@@ -1101,25 +1168,39 @@ stroke_emit (FlutlRecorder *rec, const StrokeEntry *e, int dx, int dy)
   if (box_hits_target (rec, e->ext[0] + dx + gx, e->ext[1] + dy + gy,
           e->ext[2] + dx + gx, e->ext[3] + dy + gy))
     target_touched (rec);
-  if (e->w == 0)
+  if (e->w == 0 && !e->job)
     return;
-  int ox = e->x + dx + gx, oy = e->y + dy + gy;
-  int x0 = ox, y0 = oy, x1 = ox + e->w, y1 = oy + e->h;
-  if (!clip_box (rec, &x0, &y0, &x1, &y1))
+  int c[4];
+  if (!effective_clip (rec, c))
     return;
-  flutl_prim *p = push_prim (rec);
-  p->op = FLUTL_OP_MASK;
-  p->rule = (rec->color_opaque || was_clear) ? FLUTL_RULE_LERP : FLUTL_RULE_PIXMAN;
-  p->cx0 = (int16_t) x0;
-  p->cy0 = (int16_t) y0;
-  p->cx1 = (int16_t) x1;
-  p->cy1 = (int16_t) y1;
-  p->color = rec->pixel;
-  p->param = (x0 > ox || x1 < ox + e->w) ? FLUTL_MASK_XCLIP : 0;
-  p->a = (int32_t) e->offset;
-  p->b = e->w + MASK_PAD;
-  p->c = ox;
-  p->d = oy;
+  flutl_prim tmp;
+  memset (&tmp, 0, sizeof tmp);
+  tmp.op = FLUTL_OP_MASK;
+  tmp.rule = (rec->color_opaque || was_clear) ? FLUTL_RULE_LERP : FLUTL_RULE_PIXMAN;
+  tmp.color = rec->pixel;
+  if (e->job) {
+    /* the mask is still being made: a placeholder (an empty primitive, valid as
+     * it stands) and a note of how to fill it in */
+    tmp.b = 1;
+    flutl_prim *p = push_prim (rec);
+    *p = tmp;
+    if (rec->n_patches == rec->cap_patches) {
+      rec->cap_patches = rec->cap_patches ? rec->cap_patches * 2 : 16;
+      rec->patches = xrealloc (rec->patches, rec->cap_patches * sizeof (FlutlPatch));
+    }
+    FlutlPatch *pt = &rec->patches[rec->n_patches++];
+    pt->prim = rec->n_prims - 1;
+    pt->entry = (uint32_t) (e - rec->strokes);
+    pt->ox = dx + gx;
+    pt->oy = dy + gy;
+    for (int k = 0; k < 4; k++)
+      pt->clip[k] = c[k];
+    rec->region_deferred = 1;
+    return;
+  }
+  if (!mask_prim_place (&tmp, e, dx + gx, dy + gy, c))
+    return;
+  *push_prim (rec) = tmp;
 }
 
 /* ---- rasterisation of a path into an A8 mask, in three steps ------------------
@@ -1264,13 +1345,15 @@ raster_prepare (FlutlRecorder *rec, int fill, RasterBox *rb)
   rb->by1 = imin (imin ((int) ceil (ey2) + 2, rb->lim[3]), rec->sh);
 }
 
-static void
-raster_crop (FlutlRecorder *rec, StrokeEntry *e, const RasterBox *rb)
+/* The covered part of the box, cut out of an A8 surface (which is left clear
+ * again): malloc'd tight w x h bytes at (x, y), or NULL if nothing is covered. */
+static uint8_t *
+crop_coverage (cairo_surface_t *surf, const RasterBox *rb, int *ox, int *oy, int *ow, int *oh)
 {
   const int bx0 = rb->bx0, by0 = rb->by0, bx1 = rb->bx1, by1 = rb->by1;
-  cairo_surface_flush (rec->scratch);
-  uint8_t *data = cairo_image_surface_get_data (rec->scratch);
-  int stride = cairo_image_surface_get_stride (rec->scratch);
+  cairo_surface_flush (surf);
+  uint8_t *data = cairo_image_surface_get_data (surf);
+  int stride = cairo_image_surface_get_stride (surf);
   int tx0 = bx1, ty0 = by1, tx1 = -1, ty1 = -1;
   for (int y = by0; y < by1; y++) {
     const uint8_t *row = data + (size_t) y * stride;
@@ -1305,8 +1388,9 @@ raster_crop (FlutlRecorder *rec, StrokeEntry *e, const RasterBox *rb)
       ty1 = y;
     }
   }
+  *ox = *oy = *ow = *oh = 0;
   if (tx1 < tx0)
-    return;
+    return NULL;
   int w = tx1 - tx0 + 1, h = ty1 - ty0 + 1;
   uint8_t *tight = malloc ((size_t) w * h);
   if (!tight)
@@ -1315,11 +1399,25 @@ raster_crop (FlutlRecorder *rec, StrokeEntry *e, const RasterBox *rb)
     memcpy (tight + (size_t) y * w, data + (size_t) (ty0 + y) * stride + tx0, w);
     memset (data + (size_t) (ty0 + y) * stride + tx0, 0, (size_t) w);
   }
-  cairo_surface_mark_dirty_rectangle (rec->scratch, tx0, ty0, w, h);
+  cairo_surface_mark_dirty_rectangle (surf, tx0, ty0, w, h);
+  *ox = tx0;
+  *oy = ty0;
+  *ow = w;
+  *oh = h;
+  return tight;
+}
+
+static void
+raster_crop (FlutlRecorder *rec, StrokeEntry *e, const RasterBox *rb)
+{
+  int x, y, w, h;
+  uint8_t *tight = crop_coverage (rec->scratch, rb, &x, &y, &w, &h);
+  if (!tight)
+    return;
   e->offset = atlas_put_mask (rec, tight, w, h, 1);
   free (tight);
-  e->x = tx0;
-  e->y = ty0;
+  e->x = x;
+  e->y = y;
   e->w = w;
   e->h = h;
 }
@@ -1436,6 +1534,299 @@ raster_thread_count (void)
   return raster_threads;
 }
 
+/* ---- deferred strokes ------------------------------------------------------------
+ * cairo_stroke is > 90 % of the reference's time on outlined text
+ * (gstttmlrender.c:1212) and was 88 % of this element's for a cue with NEW text.
+ * With flutl_recorder_set_defer the streaming thread only PREPARES a stroke it
+ * has no mask for -- the path is built by the very calls the reference makes,
+ * under the reference's bounds, and its exact extents are taken (they decide
+ * "clear" bookkeeping and mask reuse, see stroke_emit) -- and hands the path, in
+ * device coordinates, to a worker thread, which strokes it under the same CTM,
+ * line width and limits onto a surface of the same size.  The whole stroke, as
+ * one cairo_stroke: its rows are not independent (see path_to_mask).  The frame's
+ * display list gets a placeholder primitive and a FlutlPatch; the element
+ * resolves the patches (flutl_recorder_resolve: wait, put the mask into the
+ * atlas, fill the primitive in, recompute the region boxes) when it finishes
+ * the frame -- on another thread, while the streaming thread records the next
+ * buffers and more strokes run beside this one. */
+typedef struct StrokeJob
+{
+  gint refs;
+  cairo_path_t *path;            /* device coordinates */
+  cairo_matrix_t ctm;            /* in force at cairo_stroke */
+  double line_width;
+  RasterBox rb;
+  int sw, sh;                    /* size of the surface to stroke on */
+  uint8_t *tight;                /* result: w x h coverage at (x, y), or NULL */
+  int x, y, w, h;
+  GMutex lock;
+  GCond cond;
+  int done;
+} StrokeJob;
+
+typedef struct
+{
+  cairo_surface_t *s;
+  int w, h;
+} WorkerSurface;
+
+static void
+worker_surface_free (gpointer data)
+{
+  WorkerSurface *ws = data;
+  if (ws->s)
+    cairo_surface_destroy (ws->s);
+  free (ws);
+}
+
+static GPrivate worker_surface_key = G_PRIVATE_INIT (worker_surface_free);
+
+static void
+stroke_job_unref (StrokeJob *j)
+{
+  if (!g_atomic_int_dec_and_test (&j->refs))
+    return;
+  if (j->path)
+    cairo_path_destroy (j->path);
+  free (j->tight);
+  g_mutex_clear (&j->lock);
+  g_cond_clear (&j->cond);
+  free (j);
+}
+
+static void
+stroke_job_wait (StrokeJob *j)
+{
+  g_mutex_lock (&j->lock);
+  while (!j->done)
+    g_cond_wait (&j->cond, &j->lock);
+  g_mutex_unlock (&j->lock);
+}
+
+static void
+stroke_job_run (gpointer data, gpointer user_data)
+{
+  StrokeJob *j = data;
+  WorkerSurface *ws = g_private_get (&worker_surface_key);
+  if (!ws) {
+    ws = calloc (1, sizeof *ws);
+    if (!ws)
+      abort ();
+    g_private_set (&worker_surface_key, ws);
+  }
+  if (!ws->s || ws->w != j->sw || ws->h != j->sh) {
+    /* the surface is one more bound of the rasteriser (flutl_recorder_reserve):
+     * the same size as the recorder's, no device offset */
+    if (ws->s)
+      cairo_surface_destroy (ws->s);
+    ws->s = cairo_image_surface_create (CAIRO_FORMAT_A8, j->sw, j->sh);
+    ws->w = j->sw;
+    ws->h = j->sh;
+  }
+  cairo_t *cr = cairo_create (ws->s);
+  if (!j->rb.inside) {          /* under the reference's limits, see current_limits */
+    cairo_rectangle (cr, j->rb.lim[0], j->rb.lim[1], j->rb.lim[2] - j->rb.lim[0],
+        j->rb.lim[3] - j->rb.lim[1]);
+    cairo_clip (cr);
+  }
+  cairo_append_path (cr, j->path);      /* (identity CTM: device coordinates) */
+  cairo_set_matrix (cr, &j->ctm);
+  cairo_set_line_width (cr, j->line_width);
+  cairo_set_source_rgba (cr, 1, 1, 1, 1);
+  cairo_stroke (cr);
+  cairo_destroy (cr);
+  j->tight = crop_coverage (ws->s, &j->rb, &j->x, &j->y, &j->w, &j->h);
+  g_mutex_lock (&j->lock);
+  j->done = 1;
+  g_cond_broadcast (&j->cond);
+  g_mutex_unlock (&j->lock);
+  stroke_job_unref (j);
+  (void) user_data;
+}
+
+static GThreadPool *stroke_pool;
+static GMutex stroke_pool_lock;
+
+static GThreadPool *
+stroke_pool_get (void)
+{
+  g_mutex_lock (&stroke_pool_lock);
+  if (!stroke_pool) {
+    const char *e = g_getenv ("FLUTL_STROKE_THREADS");
+    int n = e ? atoi (e) : (int) g_get_num_processors () - 1;
+    n = n < 1 ? 1 : (n > 32 ? 32 : n);
+    stroke_pool = g_thread_pool_new (stroke_job_run, NULL, n, FALSE, NULL);
+  }
+  g_mutex_unlock (&stroke_pool_lock);
+  return stroke_pool;
+}
+
+void
+flutl_recorder_set_defer (FlutlRecorder *rec, int on)
+{
+  rec->defer = on && !rec->parent;
+}
+
+/* The stroke of the pending ops, prepared here and drawn elsewhere. */
+static void
+stroke_defer (FlutlRecorder *rec, StrokeEntry *e)
+{
+  cairo_t *cr = rec->cr;
+  RasterBox rb;
+  raster_prepare (rec, 0, &rb);
+  e->w = e->h = 0;
+  memcpy (e->ext, rb.ext, sizeof e->ext);
+  e->translatable = rb.inside;
+  if (rb.bx1 <= rb.bx0 || rb.by1 <= rb.by0) {
+    cairo_new_path (cr);
+    return;
+  }
+  memcpy (e->lim, rb.lim, sizeof e->lim);
+  StrokeJob *j = calloc (1, sizeof *j);
+  if (!j)
+    abort ();
+  j->refs = 2;                  /* the cache entry's and the worker's */
+  g_mutex_init (&j->lock);
+  g_cond_init (&j->cond);
+  cairo_get_matrix (cr, &j->ctm);
+  j->line_width = cairo_get_line_width (cr);
+  cairo_save (cr);
+  cairo_identity_matrix (cr);
+  j->path = cairo_copy_path (cr);
+  cairo_restore (cr);
+  cairo_new_path (cr);
+  if (!j->path || j->path->status != CAIRO_STATUS_SUCCESS)
+    abort ();
+  j->rb = rb;
+  j->sw = rec->sw;
+  j->sh = rec->sh;
+  e->job = j;
+  g_thread_pool_push (stroke_pool_get (), j, NULL);
+}
+
+/* The frame rectangle a stroke emitted now may reach: frame x clip x group. */
+static int
+effective_clip (FlutlRecorder *rec, int c[4])
+{
+  c[0] = -(1 << 20);
+  c[1] = -(1 << 20);
+  c[2] = 1 << 20;
+  c[3] = 1 << 20;
+  return clip_box (rec, &c[0], &c[1], &c[2], &c[3]);
+}
+
+/* Fill a MASK primitive in from its cache entry (the rule and the colour were
+ * chosen when it was emitted).  Returns 0 if nothing of the mask is visible. */
+static int
+mask_prim_place (flutl_prim *p, const StrokeEntry *e, int ox, int oy, const int c[4])
+{
+  if (e->w == 0)
+    return 0;
+  ox += e->x;
+  oy += e->y;
+  int x0 = imax (ox, c[0]), y0 = imax (oy, c[1]);
+  int x1 = imin (ox + e->w, c[2]), y1 = imin (oy + e->h, c[3]);
+  if (x1 <= x0 || y1 <= y0)
+    return 0;
+  p->cx0 = (int16_t) x0;
+  p->cy0 = (int16_t) y0;
+  p->cx1 = (int16_t) x1;
+  p->cy1 = (int16_t) y1;
+  p->param = (x0 > ox || x1 < ox + e->w) ? FLUTL_MASK_XCLIP : 0;
+  p->a = (int32_t) e->offset;
+  p->b = e->w + MASK_PAD;
+  p->c = ox;
+  p->d = oy;
+  return 1;
+}
+
+const FlutlPatch *
+flutl_recorder_patches (FlutlRecorder *rec, uint32_t *n)
+{
+  *n = rec->n_patches;
+  return rec->patches;
+}
+
+/* Finish a frame's display list (a copy of the recorder's arrays, or the arrays
+ * themselves): wait for the masks its placeholders stand for, store them, fill
+ * the primitives in and give the regions their boxes -- the same results the
+ * synchronous path produces.  Any thread; the recorder may be recording the
+ * next frame meanwhile. */
+void
+flutl_recorder_resolve (FlutlRecorder *rec, flutl_region *regions, uint32_t n_regions,
+    flutl_prim *prims, uint32_t n_prims, const FlutlPatch *patches, uint32_t n_patches)
+{
+  if (n_patches == 0)
+    return;
+  for (uint32_t k = 0; k < n_patches; k++) {
+    const FlutlPatch *pt = &patches[k];
+    StrokeEntry snap;
+    StrokeJob *j;
+    g_rec_mutex_lock (&rec->lock);
+    j = rec->strokes[pt->entry].job;
+    if (j)
+      g_atomic_int_inc (&j->refs);
+    g_rec_mutex_unlock (&rec->lock);
+    if (j)
+      stroke_job_wait (j);
+    g_rec_mutex_lock (&rec->lock);
+    StrokeEntry *e = &rec->strokes[pt->entry];    /* (the array may have moved) */
+    if (j && e->job == j) {     /* first to get here: the mask goes into the atlas */
+      if (j->tight) {
+        e->offset = atlas_put_mask (rec, j->tight, j->w, j->h, 1);
+        e->x = j->x;
+        e->y = j->y;
+        e->w = j->w;
+        e->h = j->h;
+      }
+      e->job = NULL;
+      stroke_job_unref (j);     /* the entry's reference */
+    }
+    snap = *e;
+    g_rec_mutex_unlock (&rec->lock);
+    if (j)
+      stroke_job_unref (j);     /* ours */
+    if (pt->prim < n_prims) {
+      const int c[4] = { pt->clip[0], pt->clip[1], pt->clip[2], pt->clip[3] };
+      mask_prim_place (&prims[pt->prim], &snap, pt->ox, pt->oy, c);
+    }
+  }
+  /* region boxes, as flutl_recorder_region_end makes them */
+  for (uint32_t r = 0; r < n_regions; r++) {
+    flutl_region *rg = &regions[r];
+    int touched = 0;
+    for (uint32_t k = 0; k < n_patches && !touched; k++)
+      touched = patches[k].prim >= rg->first && patches[k].prim < rg->first + rg->count;
+    if (!touched)
+      continue;
+    int x0 = 32767, y0 = 32767, x1 = 0, y1 = 0;
+    for (uint32_t i = rg->first; i < rg->first + rg->count; i++) {
+      const flutl_prim *p = &prims[i];
+      if (p->cx1 <= p->cx0 || p->cy1 <= p->cy0)
+        continue;
+      x0 = imin (x0, p->cx0);
+      y0 = imin (y0, p->cy0);
+      x1 = imax (x1, p->cx1);
+      y1 = imax (y1, p->cy1);
+    }
+    if (x1 <= x0 || y1 <= y0) {         /* nothing visible after all */
+      x0 = y0 = x1 = y1 = 0;
+      rg->count = 0;
+    }
+    for (uint32_t i = rg->first; i < rg->first + rg->count; i++) {
+      flutl_prim *p = &prims[i];
+      if (p->cx1 <= p->cx0 || p->cy1 <= p->cy0) {
+        p->cx0 = p->cx1 = (int16_t) x0;
+        p->cy0 = p->cy1 = (int16_t) y0;
+      }
+    }
+    rg->x0 = (int16_t) x0;
+    rg->y0 = (int16_t) y0;
+    rg->x1 = (int16_t) x1;
+    rg->y1 = (int16_t) y1;
+  }
+}
+
 /* The cache entry of one stroke / fill of the ops [rec->ops, rec->ops + rec->n_ops).
  * *dx, *dy = where the mask goes relative to where it was made.  A new entry
  * (*is_new) has no mask yet: the caller rasterises.  (The pointer is valid
@@ -1465,9 +1856,10 @@ ops_find_mask (FlutlRecorder *rec, int fill, int *dx, int *dy, int *is_new)
       int lim[4];
       current_limits (rec, lim);
       const int same = tx == 0 && ty == 0 && memcmp (lim, e->lim, sizeof lim) == 0;
-      const int clear = e->w == 0 ||
+      /* (a mask still in the making has no box yet: good at its own place only) */
+      const int clear = !e->job && (e->w == 0 ||
           (e->x + tx >= lim[0] + 2 && e->y + ty >= lim[1] + 2 &&
-           e->x + tx + e->w <= lim[2] - 2 && e->y + ty + e->h <= lim[3] - 2);
+           e->x + tx + e->w <= lim[2] - 2 && e->y + ty + e->h <= lim[3] - 2));
       if (same || (e->translatable && clear && ty == 0)) {
         free (key);
         *dx = tx;
@@ -1498,8 +1890,12 @@ ops_get_mask (FlutlRecorder *rec, int fill, int *dx, int *dy)
 {
   int is_new;
   StrokeEntry *e = ops_find_mask (rec, fill, dx, dy, &is_new);
-  if (is_new)
-    e->translatable = stroke_rasterise (rec, e, fill);
+  if (is_new) {
+    if (rec->defer && !fill)
+      stroke_defer (rec, e);
+    else
+      e->translatable = stroke_rasterise (rec, e, fill);
+  }
   return e;
 }
 
@@ -1507,8 +1903,11 @@ static void
 ops_to_mask (FlutlRecorder *rec, int fill)
 {
   int dx, dy;
+  /* (the stroke cache is shared with the thread that resolves frames) */
+  g_rec_mutex_lock (&root_of (rec)->lock);
   StrokeEntry *e = ops_get_mask (rec, fill, &dx, &dy);
   stroke_emit (rec, e, dx, dy);
+  g_rec_mutex_unlock (&root_of (rec)->lock);
 }
 
 /* Device rows an op's stroke can touch: its outline's bounding box under the

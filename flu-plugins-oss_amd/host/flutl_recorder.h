@@ -117,4 +117,29 @@ uint32_t flutl_recorder_new_atlas_entries (FlutlRecorder *rec,
 /* number of primitives dropped because a feature is not implemented yet */
 uint32_t flutl_recorder_unsupported (FlutlRecorder *rec);
 
+/* ---- deferred strokes (flutl_recorder.c, "deferred strokes") -----------------
+ * With set_defer (root recorders only) a stroke the cache has no mask for is
+ * prepared on the calling thread and rasterised on a worker thread; the frame's
+ * list then holds placeholder primitives, described by patches, and is finished
+ * by flutl_recorder_resolve -- typically on another thread, on a COPY of the
+ * frame's arrays, while the recorder goes on with the next frame.  What the two
+ * threads share is guarded by the recorder's lock; whoever reads the atlas or
+ * the list of new atlas entries while frames are being resolved elsewhere holds
+ * it (flutl_recorder_lock).  flutl_recorder_reset must only be called when every
+ * frame has been resolved. */
+typedef struct
+{
+  uint32_t prim;             /* index of the placeholder in the frame's prims */
+  uint32_t entry;            /* stroke cache entry whose mask it takes */
+  int32_t ox, oy;            /* frame position of the mask's raster origin */
+  int16_t clip[4];           /* frame x clip x group surface, when it was emitted */
+} FlutlPatch;
+
+void flutl_recorder_set_defer (FlutlRecorder *rec, int on);
+const FlutlPatch *flutl_recorder_patches (FlutlRecorder *rec, uint32_t *n);
+void flutl_recorder_resolve (FlutlRecorder *rec, flutl_region *regions, uint32_t n_regions,
+    flutl_prim *prims, uint32_t n_prims, const FlutlPatch *patches, uint32_t n_patches);
+void flutl_recorder_lock (FlutlRecorder *rec);
+void flutl_recorder_unlock (FlutlRecorder *rec);
+
 #endif /* FLUTL_RECORDER_H */

@@ -82,6 +82,9 @@ enum
  * A HIP-aware consumer finds the device address of the twin as qdata
  * "flutl-hip-device-frame" on the memory (valid once the memory has been mapped).
  * FLUTL_FULL_D2H=1 restores synchronous whole-frame copies into writable memory. */
+#define MAX_IN_FLIGHT 12           /* buffers handed out but not yet queued on the device */
+#define POOL_MAX_FREE 16
+
 typedef struct
 {
   flutl_frame *frame;             /* asynchronous mode */
@@ -143,7 +146,7 @@ frame_block_release (gpointer data)
   FramePool *p = b->pool;
   g_mutex_lock (&p->lock);
   /* keep at most a few frames, and only of the current size */
-  if (b->size == p->block_size && p->free_slots->len < 6 && !b->slot->stale)
+  if (b->size == p->block_size && p->free_slots->len < POOL_MAX_FREE && !b->slot->stale)
     g_ptr_array_add (p->free_slots, b->slot);
   else
     frame_slot_free (b->slot);
@@ -152,12 +155,74 @@ frame_block_release (gpointer data)
   g_free (b);
 }
 
+/* A buffer's promise: gen_buffer hands the buffer out when its display list is
+ * recorded; the finisher thread (below) queues it on the device when the masks
+ * of its outlines are there, and says so here. */
+typedef struct
+{
+  gint refs;
+  GMutex lock;
+  GCond cond;
+  gboolean ready;
+  int error;
+} Ticket;
+
+static Ticket *
+ticket_new (void)
+{
+  Ticket *t = g_new0 (Ticket, 1);
+  t->refs = 1;
+  g_mutex_init (&t->lock);
+  g_cond_init (&t->cond);
+  return t;
+}
+
+static Ticket *
+ticket_ref (Ticket *t)
+{
+  g_atomic_int_inc (&t->refs);
+  return t;
+}
+
+static void
+ticket_unref (Ticket *t)
+{
+  if (!g_atomic_int_dec_and_test (&t->refs))
+    return;
+  g_mutex_clear (&t->lock);
+  g_cond_clear (&t->cond);
+  g_free (t);
+}
+
+static void
+ticket_complete (Ticket *t, int error)
+{
+  g_mutex_lock (&t->lock);
+  t->ready = TRUE;
+  t->error = error;
+  g_cond_broadcast (&t->cond);
+  g_mutex_unlock (&t->lock);
+}
+
+static int
+ticket_wait (Ticket *t)
+{
+  int error;
+  g_mutex_lock (&t->lock);
+  while (!t->ready)
+    g_cond_wait (&t->cond, &t->lock);
+  error = t->error;
+  g_mutex_unlock (&t->lock);
+  return error;
+}
+
 /* ---- GstMemory over a frame: map = wait for the frame ------------------------- */
 typedef struct
 {
   GstMemory mem;
   FrameBlock *block;              /* NULL for sub-memories (they hold the parent) */
   flutl_frame *frame;
+  Ticket *ticket;                 /* NULL: queued on the device before it was handed out */
   guint8 *data;
 } FlutlMemory;
 
@@ -170,7 +235,8 @@ static gpointer
 flutl_mem_map (GstMemory *mem, gsize maxsize, GstMapFlags flags)
 {
   FlutlMemory *m = (FlutlMemory *) mem;
-  if (flutl_frame_wait (m->frame) != FLUTL_OK) {
+  if ((m->ticket && ticket_wait (m->ticket) != FLUTL_OK) ||
+      flutl_frame_wait (m->frame) != FLUTL_OK) {
     GST_ERROR ("ttmlrender: the frame behind this memory failed to render");
     return NULL;
   }
@@ -194,6 +260,7 @@ flutl_mem_share (GstMemory *mem, gssize offset, gssize size)
       GST_MINI_OBJECT_FLAGS (parent) | GST_MINI_OBJECT_FLAG_LOCK_READONLY, mem->allocator,
       parent, mem->maxsize, mem->align, mem->offset + offset, size);
   sub->frame = m->frame;
+  sub->ticket = m->ticket ? ticket_ref (m->ticket) : NULL;
   sub->data = m->data;
   return GST_MEMORY_CAST (sub);
 }
@@ -204,6 +271,8 @@ flutl_allocator_free (GstAllocator *allocator, GstMemory *mem)
   FlutlMemory *m = (FlutlMemory *) mem;
   if (m->block)
     frame_block_release (m->block);
+  if (m->ticket)
+    ticket_unref (m->ticket);
   g_free (m);
 }
 
@@ -277,7 +346,7 @@ frame_pool_take (FramePool *p, flutl_ctx *ctx, gint width, gint height, gboolean
 
 /* A GstBuffer over a pooled slot; the slot returns to the pool with the buffer. */
 static GstBuffer *
-frame_pool_wrap (FramePool *p, FrameSlot *slot, gsize size)
+frame_pool_wrap (FramePool *p, FrameSlot *slot, gsize size, Ticket *ticket)
 {
   FrameBlock *b = g_new0 (FrameBlock, 1);
   GstBuffer *buffer;
@@ -291,6 +360,7 @@ frame_pool_wrap (FramePool *p, FrameSlot *slot, gsize size)
         NULL, size, 0, 0, size);
     m->block = b;
     m->frame = slot->frame;
+    m->ticket = ticket ? ticket_ref (ticket) : NULL;
     m->data = flutl_frame_host (slot->frame);
     gst_mini_object_set_qdata (GST_MINI_OBJECT_CAST (m),
         g_quark_from_static_string ("flutl-hip-device-frame"),
@@ -319,6 +389,7 @@ typedef struct
   gboolean ctx_failed;
   FlutlPackWriter *dump;     /* FLUTL_DUMP_PACK=<file>: scene-pack dump */
   gboolean dump_only;        /* FLUTL_DUMP_ONLY=1: record, do not render */
+  gboolean dump_defer;       /* FLUTL_DUMP_DEFER=1: dump with strokes made on worker threads */
   gsize atlas_limit;         /* FLUTL_ATLAS_LIMIT_MB (default 256): see gen_buffer */
   gboolean overlay_meta;     /* FLUTL_OVERLAY_COMPOSITION=1: also attach the frame as a
                               * GstVideoOverlayCompositionMeta (the reference has none,
@@ -333,6 +404,17 @@ typedef struct
   GHashTable *layouts;       /* layout cache: key string -> PangoLayout, per document */
   gboolean no_layout_cache;  /* FLUTL_NO_LAYOUT_CACHE=1 */
   guint skipped;             /* outlines of this buffer that could not be drawn */
+  /* the finisher: buffers are handed out when their list is recorded; this thread
+   * waits for the outline masks still being rasterised (flutl_recorder_resolve),
+   * uploads new atlas entries and queues the frame on the device, in order.
+   * While it has work, it alone uses `ctx`. */
+  gboolean sync_mode;        /* FLUTL_SYNC=1: everything on the streaming thread */
+  GThread *finisher;
+  GAsyncQueue *jobs;
+  GMutex flight_lock;
+  GCond flight_cond;
+  guint in_flight;
+  gint64 t_submit;           /* (finisher's clock, read when it is idle) */
   guint64 delta_reported;
 } GstTTMLRenderPrivate;
 
@@ -1206,6 +1288,7 @@ walk_layout (GstTTMLRender *render, FlutlRecorder *rec, PangoLayout *layout,
 
 static gboolean flush_atlas (GstTTMLRender *render);
 static gboolean ensure_ctx (GstTTMLRender *render);
+static void pipeline_drain (GstTTMLRender *render);
 
 /* Glyph / outline / blurred-image masks, host copy and HBM: everything that is
  * re-made on demand. */
@@ -1213,6 +1296,7 @@ static void
 caches_drop (GstTTMLRender *render)
 {
   GstTTMLRenderPrivate *priv = get_priv (render);
+  pipeline_drain (render);      /* no frame may still want a mask or the device */
   if (priv->rec)
     flutl_recorder_reset (priv->rec);
   if (priv->sub)
@@ -1329,6 +1413,7 @@ blurred_outline (GstTTMLRender *render, HipRegion *r, PangoLayout *layout, guint
     priv->skipped++;
     return;
   }
+  pipeline_drain (render);      /* this path uses the device from the streaming thread */
 
   /* ---- record the temporary surface --------------------------------------- */
   flutl_recorder_begin_frame (sub, tw, th);
@@ -1542,18 +1627,138 @@ flush_atlas (GstTTMLRender *render)
   GstTTMLRenderPrivate *priv = get_priv (render);
   const uint32_t *off, *size;
   size_t atlas_size;
-  const uint8_t *atlas = flutl_recorder_atlas (priv->rec, &atlas_size);
-  uint32_t i, n = flutl_recorder_new_atlas_entries (priv->rec, &off, &size);
-  for (i = 0; i < n; i++) {
+  const uint8_t *atlas;
+  uint32_t i, n;
+  gboolean ok = TRUE;
+  /* (the streaming thread may be adding glyph masks: entries are uploaded in
+   * the order they were given their offsets, whichever frame they belong to) */
+  flutl_recorder_lock (priv->rec);
+  atlas = flutl_recorder_atlas (priv->rec, &atlas_size);
+  n = flutl_recorder_new_atlas_entries (priv->rec, &off, &size);
+  for (i = 0; i < n && ok; i++) {
     uint32_t dev_off = 0;
     int rc = flutl_atlas_put (priv->ctx, atlas + off[i], size[i], &dev_off);
     if (rc != FLUTL_OK || dev_off != off[i]) {
       GST_ELEMENT_ERROR (render, LIBRARY, FAILED, ("ttmlrender: atlas upload failed"),
           ("flutl_atlas_put: %s (offset %u vs %u)", flutl_strerror (rc), dev_off, off[i]));
-      return FALSE;
+      ok = FALSE;
     }
   }
-  return TRUE;
+  flutl_recorder_unlock (priv->rec);
+  return ok;
+}
+
+/* ---- the finisher thread ------------------------------------------------------- */
+typedef struct
+{
+  gint width, height;
+  flutl_region *regions;
+  flutl_prim *prims;
+  FlutlPatch *patches;
+  guint32 n_rg, n_pr, n_patches;
+  GstMemory *mem;              /* keeps the frame out of the pool until it is queued */
+  FrameSlot *slot;
+  Ticket *ticket;
+} FrameJob;
+
+static gpointer
+finisher_main (gpointer data)
+{
+  GstTTMLRender *render = data;
+  GstTTMLRenderPrivate *priv = get_priv (render);
+  FrameJob *job;
+  while ((job = g_async_queue_pop (priv->jobs)) != NULL) {
+    gint64 t0;
+    int rc;
+    if (job->slot == NULL) {   /* the stop sentinel */
+      g_free (job);
+      break;
+    }
+    flutl_recorder_resolve (priv->rec, job->regions, job->n_rg, job->prims, job->n_pr,
+        job->patches, job->n_patches);
+    t0 = priv->timing ? g_get_monotonic_time () : 0;
+    rc = flush_atlas (render) ? FLUTL_OK : FLUTL_ENODEV;
+    if (rc == FLUTL_OK)
+      rc = flutl_frame_submit (priv->ctx, job->slot->frame, job->regions, job->n_rg,
+          job->prims, job->n_pr);
+    if (priv->timing)
+      priv->t_submit += g_get_monotonic_time () - t0;
+    if (rc != FLUTL_OK) {
+      job->slot->stale = TRUE;
+      GST_ELEMENT_ERROR (render, LIBRARY, FAILED, ("ttmlrender: HIP render failed"),
+          ("%s", flutl_strerror (rc)));
+    }
+    ticket_complete (job->ticket, rc);
+    ticket_unref (job->ticket);
+    gst_memory_unref (job->mem);
+    g_free (job->regions);
+    g_free (job->prims);
+    g_free (job->patches);
+    g_free (job);
+    g_mutex_lock (&priv->flight_lock);
+    priv->in_flight--;
+    g_cond_broadcast (&priv->flight_cond);
+    g_mutex_unlock (&priv->flight_lock);
+  }
+  return NULL;
+}
+
+/* Wait until every buffer handed out so far has been queued on the device: the
+ * finisher is idle then and the calling (streaming) thread may use `ctx`. */
+static void
+pipeline_drain (GstTTMLRender *render)
+{
+  GstTTMLRenderPrivate *priv = get_priv (render);
+  if (!priv->finisher)
+    return;
+  g_mutex_lock (&priv->flight_lock);
+  while (priv->in_flight > 0)
+    g_cond_wait (&priv->flight_cond, &priv->flight_lock);
+  g_mutex_unlock (&priv->flight_lock);
+}
+
+static void
+pipeline_stop (GstTTMLRender *render)
+{
+  GstTTMLRenderPrivate *priv = get_priv (render);
+  if (!priv->finisher)
+    return;
+  pipeline_drain (render);
+  g_async_queue_push (priv->jobs, g_new0 (FrameJob, 1));    /* slot == NULL: stop */
+  g_thread_join (priv->finisher);
+  priv->finisher = NULL;
+}
+
+/* Hand a recorded frame to the finisher.  The lists are copied: the recorder's
+ * arrays are reused by the next buffer. */
+static void
+pipeline_push (GstTTMLRender *render, gint width, gint height, const flutl_region *rg,
+    guint32 n_rg, const flutl_prim *pr, guint32 n_pr, FrameSlot *slot, GstBuffer *buffer,
+    Ticket *ticket)
+{
+  GstTTMLRenderPrivate *priv = get_priv (render);
+  FrameJob *job = g_new0 (FrameJob, 1);
+  uint32_t n_patches = 0;
+  const FlutlPatch *patches = flutl_recorder_patches (priv->rec, &n_patches);
+  job->width = width;
+  job->height = height;
+  job->n_rg = n_rg;
+  job->n_pr = n_pr;
+  job->n_patches = n_patches;
+  job->regions = g_memdup (rg, n_rg * sizeof *rg);
+  job->prims = g_memdup (pr, n_pr * sizeof *pr);
+  job->patches = g_memdup (patches, n_patches * sizeof *patches);
+  job->mem = gst_memory_ref (gst_buffer_peek_memory (buffer, 0));
+  job->slot = slot;
+  job->ticket = ticket_ref (ticket);
+  if (!priv->finisher)
+    priv->finisher = g_thread_new ("ttmlrender-finish", finisher_main, render);
+  g_mutex_lock (&priv->flight_lock);
+  while (priv->in_flight >= MAX_IN_FLIGHT)
+    g_cond_wait (&priv->flight_cond, &priv->flight_lock);
+  priv->in_flight++;
+  g_mutex_unlock (&priv->flight_lock);
+  g_async_queue_push (priv->jobs, job);
 }
 
 static GstBuffer *
@@ -1582,13 +1787,19 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
      * stream is one endless document with new text in every cue: bound the
      * atlas by starting over (masks are re-made on demand) at a frame boundary. */
     size_t atlas_bytes = 0;
+    flutl_recorder_lock (rec);
     (void) flutl_recorder_atlas (rec, &atlas_bytes);
+    flutl_recorder_unlock (rec);
     if (atlas_bytes > priv->atlas_limit && !priv->dump) {   /* (a dump keeps one atlas) */
       GST_INFO_OBJECT (render, "atlas at %" G_GSIZE_FORMAT " bytes: dropping the mask caches",
           atlas_bytes);
       caches_drop (render);
     }
   }
+  /* outlines without a mask yet are rasterised on worker threads and waited for
+   * by the finisher, unless the frame is needed complete right here */
+  flutl_recorder_set_defer (rec, !priv->sync_mode && !priv->full_d2h &&
+      (!priv->dump || priv->dump_defer));
   flutl_recorder_begin_frame (rec, width, height);
   if (base->state.saved_region_attr_stacks) {
     gpointer ctx[2] = { render, &regions };
@@ -1622,7 +1833,14 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
 
   if (priv->dump) {
     size_t atlas_size;
-    const uint8_t *atlas = flutl_recorder_atlas (rec, &atlas_size);
+    const uint8_t *atlas;
+    uint32_t n_patches = 0;
+    const FlutlPatch *patches = flutl_recorder_patches (rec, &n_patches);
+    /* (FLUTL_DUMP_DEFER=1, tests: the worker-thread rasteriser, finished right here) */
+    GST_LOG_OBJECT (render, "dump: %u placeholder(s) to resolve", n_patches);
+    flutl_recorder_resolve (rec, (flutl_region *) rg, n_rg, (flutl_prim *) pr, n_pr, patches,
+        n_patches);
+    atlas = flutl_recorder_atlas (rec, &atlas_size);
     flutl_pack_writer_add (priv->dump, width, height, rg, n_rg, pr, n_pr, atlas,
         atlas_size);
   }
@@ -1638,27 +1856,45 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
   if (!ensure_ctx (render))
     return NULL;
   t_recorded = priv->timing ? g_get_monotonic_time () : 0;
-  if (!flush_atlas (render))
-    return NULL;
   {
     GstMapInfo map;
     const gsize size = (gsize) width * height * 4;
-    FrameSlot *slot = frame_pool_take (priv->pool, priv->ctx, width, height, !priv->full_d2h);
-    int rc;
-    if (slot && slot->frame) {
-      /* queue the frame and go on: the buffer is complete when its memory is mapped */
-      buffer = frame_pool_wrap (priv->pool, slot, size);
-      rc = flutl_frame_submit (priv->ctx, slot->frame, rg, n_rg, pr, n_pr);
-    } else if (slot) {
-      buffer = frame_pool_wrap (priv->pool, slot, size);
-      rc = flutl_render_frame_to_host (priv->ctx, width, height, rg, n_rg, pr, n_pr,
-          slot->block, (size_t) width * 4);
-    } else {                    /* no page-locked memory: plain system buffer */
-      buffer = gst_buffer_new_and_alloc (size);
-      gst_buffer_map (buffer, &map, GST_MAP_WRITE);
-      rc = flutl_render_frame_to_host (priv->ctx, width, height, rg, n_rg, pr, n_pr,
-          map.data, (size_t) width * 4);
-      gst_buffer_unmap (buffer, &map);
+    const gboolean async = !priv->full_d2h;
+    FrameSlot *slot = frame_pool_take (priv->pool, priv->ctx, width, height, async);
+    int rc = FLUTL_OK;
+    if (slot && slot->frame && !priv->sync_mode && !priv->dump) {
+      /* hand the buffer out now; the finisher queues it on the device when its
+       * masks are there (mapping the memory waits for both) */
+      Ticket *ticket = ticket_new ();
+      buffer = frame_pool_wrap (priv->pool, slot, size, ticket);
+      pipeline_push (render, width, height, rg, n_rg, pr, n_pr, slot, buffer, ticket);
+      ticket_unref (ticket);
+    } else {
+      uint32_t n_patches = 0;
+      const FlutlPatch *patches = flutl_recorder_patches (rec, &n_patches);
+      pipeline_drain (render);
+      /* (only if page-locked memory ran out after strokes were deferred) */
+      flutl_recorder_resolve (rec, (flutl_region *) rg, n_rg, (flutl_prim *) pr, n_pr,
+          patches, n_patches);
+      if (!flush_atlas (render)) {
+        if (slot)
+          frame_slot_free (slot);
+        return NULL;
+      }
+      if (slot && slot->frame) {
+        buffer = frame_pool_wrap (priv->pool, slot, size, NULL);
+        rc = flutl_frame_submit (priv->ctx, slot->frame, rg, n_rg, pr, n_pr);
+      } else if (slot) {
+        buffer = frame_pool_wrap (priv->pool, slot, size, NULL);
+        rc = flutl_render_frame_to_host (priv->ctx, width, height, rg, n_rg, pr, n_pr,
+            slot->block, (size_t) width * 4);
+      } else {                    /* no page-locked memory: plain system buffer */
+        buffer = gst_buffer_new_and_alloc (size);
+        gst_buffer_map (buffer, &map, GST_MAP_WRITE);
+        rc = flutl_render_frame_to_host (priv->ctx, width, height, rg, n_rg, pr, n_pr,
+            map.data, (size_t) width * 4);
+        gst_buffer_unmap (buffer, &map);
+      }
     }
     if (rc != FLUTL_OK) {
       if (slot)
@@ -1799,9 +2035,9 @@ gst_ttmlrender_set_property (GObject *object, guint id, const GValue *value,
 }
 
 /* FLUTL_TIMING=1: one line per document on stderr (tools/e2e_timing.py reads it).
- * record = host time per buffer from scene state to display list; device = host
- * time per buffer spent queuing the device work (or, with FLUTL_FULL_D2H, waiting
- * for it); span = end of the first gen_buffer to end of the last; drained = to
+ * record = streaming-thread time per buffer from scene state to display list;
+ * device = host time per buffer spent queuing the device work, mostly on the
+ * finisher thread (or, with FLUTL_FULL_D2H, waiting for it); span = end of the first gen_buffer to end of the last; drained = to
  * the moment every frame of the document was complete in host memory. */
 static void
 timing_report (GstTTMLRender *render)
@@ -1811,6 +2047,7 @@ timing_report (GstTTMLRender *render)
   guint64 delta = 0;
   if (!priv->timing || !priv->n_timed)
     return;
+  pipeline_drain (render);
   if (priv->ctx) {
     flutl_ctx_sync (priv->ctx);
     t_drained = g_get_monotonic_time ();
@@ -1822,12 +2059,12 @@ timing_report (GstTTMLRender *render)
   g_printerr ("ttmlrender-hip timing: buffers=%u record_us=%.1f device_us=%.1f "
       "span_us=%" G_GINT64_FORMAT " drained_us=%" G_GINT64_FORMAT " delta_bytes=%.0f\n",
       priv->n_timed, (double) priv->t_record / MAX (priv->n_timed - 1, 1),
-      (double) priv->t_device / MAX (priv->n_timed - 1, 1),
+      (double) (priv->t_device + priv->t_submit) / MAX (priv->n_timed - 1, 1),
       priv->t_last_return - priv->t_first_return,
       MAX (t_drained, priv->t_last_return) - priv->t_first_return,
       (double) delta / priv->n_timed);
   priv->n_timed = 0;
-  priv->t_record = priv->t_device = 0;
+  priv->t_record = priv->t_device = priv->t_submit = 0;
 }
 
 /* ---- reset / dispose / init (reference :1610-1750) ------------------------------- */
@@ -1859,6 +2096,7 @@ gst_ttmlrender_dispose (GObject *object)
 
   gst_ttmlrender_reset (GST_TTMLBASE (render));
   timing_report (render);
+  pipeline_stop (render);
   if (priv->dump) {
     flutl_pack_writer_free (priv->dump);
     priv->dump = NULL;
@@ -1878,6 +2116,12 @@ gst_ttmlrender_dispose (GObject *object)
   if (priv->pool) {
     frame_pool_unref (priv->pool);
     priv->pool = NULL;
+  }
+  if (priv->jobs) {
+    g_async_queue_unref (priv->jobs);
+    priv->jobs = NULL;
+    g_mutex_clear (&priv->flight_lock);
+    g_cond_clear (&priv->flight_cond);
   }
   g_clear_pointer (&render->default_font_family, g_free);
   g_clear_pointer (&render->default_font_size, g_free);
@@ -1977,6 +2221,7 @@ gst_ttmlrender_init (GstTTMLRender *render)
   dump = g_getenv ("FLUTL_DUMP_PACK");
   priv->dump = dump ? flutl_pack_writer_new (dump) : NULL;
   priv->dump_only = g_getenv ("FLUTL_DUMP_ONLY") != NULL;
+  priv->dump_defer = g_getenv ("FLUTL_DUMP_DEFER") != NULL;
   priv->timing = g_getenv ("FLUTL_TIMING") != NULL;
   priv->full_d2h = g_getenv ("FLUTL_FULL_D2H") != NULL;
   priv->atlas_limit = (gsize) (g_getenv ("FLUTL_ATLAS_LIMIT_MB")
@@ -1984,5 +2229,9 @@ gst_ttmlrender_init (GstTTMLRender *render)
   if (g_getenv ("FLUTL_ATLAS_LIMIT_BYTES"))     /* tests: force the start-over path */
     priv->atlas_limit = (gsize) g_ascii_strtoull (g_getenv ("FLUTL_ATLAS_LIMIT_BYTES"), NULL, 10);
   priv->overlay_meta = g_getenv ("FLUTL_OVERLAY_COMPOSITION") != NULL;
+  priv->sync_mode = g_getenv ("FLUTL_SYNC") != NULL;
+  priv->jobs = g_async_queue_new ();
+  g_mutex_init (&priv->flight_lock);
+  g_cond_init (&priv->flight_cond);
   priv->no_layout_cache = g_getenv ("FLUTL_NO_LAYOUT_CACHE") != NULL;
 }

@@ -67,3 +67,29 @@ def test_embedded_images_record_like_file_images(tmp_path):
     for i, (R, P) in enumerate(st):
         assert np.array_equal(R, z[f"regions{i}"]) and np.array_equal(P, z[f"prims{i}"])
     assert np.array_equal(pk.atlas, z["atlas"])
+
+
+OUTLINED = [s for s in SCENES if os.path.basename(s)[:3] in
+            ("k04", "k07", "k10", "k12", "k13", "k14", "k15")]
+
+
+@pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
+                    reason="fluttml-hip plugin / GStreamer runtime not present")
+@pytest.mark.parametrize("ttml", OUTLINED, ids=[os.path.basename(s)[:-5] for s in OUTLINED])
+def test_outlines_stroked_on_worker_threads_are_the_reference_s(ttml, tmp_path):
+    """The element rasterises outline masks on worker threads (deferred strokes:
+    placeholder primitives resolved later).  Recorded that way (FLUTL_DUMP_DEFER=1)
+    the lists must still composite -- through the oracle -- to the REFERENCE's
+    frames, i.e. a stroke made on a worker's surface from the copied path is the
+    stroke Cairo makes in place."""
+    import oracle_lib as O
+    z = np.load(ttml[:-5] + ".npz")
+    W, H = int(z["width"]), int(z["height"])
+    pk = scene_pack.load(gstenv.dump_pack(ttml, W, H, str(tmp_path / "p.flpk"),
+                                          extra_env={"FLUTL_DUMP_DEFER": "1"}))
+    st = pk.states()
+    assert len(st) == int(z["n_states"])
+    for i, (R, P) in enumerate(st):
+        import pyflutl as F
+        assert F.validate(W, H, R, P, pk.atlas.size) == 0
+        assert np.array_equal(O.render(W, H, R, P, pk.atlas), z["frames"][i]), i

@@ -76,7 +76,7 @@ def render(plugin_dir, ttml_path, width, height, out_path=None, extra_env=None,
     return data
 
 
-def dump_pack(ttml_path, width, height, pack_path, record_only=True):
+def dump_pack(ttml_path, width, height, pack_path, record_only=True, extra_env=None):
     """Run the fluttml-hip element and return the path of the scene pack it
     wrote.  record_only (default) works without a GPU; with record_only=False
     the element also renders, and device-produced atlas entries (blurred
@@ -86,5 +86,6 @@ def dump_pack(ttml_path, width, height, pack_path, record_only=True):
     env = {"FLUTL_DUMP_PACK": pack_path}
     if record_only:
         env["FLUTL_DUMP_ONLY"] = "1"
+    env.update(extra_env or {})
     render(HIP_PLUGIN_DIR, ttml_path, width, height, sink="fakesink", extra_env=env)
     return pack_path
