@@ -723,11 +723,14 @@ extern "C" int flutl_frame_create (flutl_ctx *c, uint32_t width, uint32_t height
   // the CPU once the event has been waited for)
   ok = ok && hip_ok (hipEventCreateWithFlags (&f->done,
       hipEventDisableTiming | hipEventReleaseToSystem));
-  if (ok) {
-    memset (f->host, 0, bytes);         // the transparent frame, in both copies
-    ok = hip_ok (hipMemsetAsync (f->twin, 0, bytes, c->stream)) &&
-        hip_ok (hipStreamSynchronize (c->stream));
-  }
+  // the transparent frame, in both copies: cleared by the device in stream order
+  // (the host block over PCIe: no 33 MB memset on the caller's thread, and no
+  // wait -- whatever is submitted into the frame comes later on the same stream)
+  ok = ok && hip_ok (hipMemsetAsync (f->twin, 0, bytes, c->stream)) &&
+      hip_ok (hipMemsetAsync (f->host_dev, 0, bytes, c->stream)) &&
+      hip_ok (hipEventRecord (f->done, c->stream));
+  if (ok)
+    f->pending = true;
   if (!ok) {
     flutl_frame_destroy (f);
     return FLUTL_ENOMEM;

@@ -82,7 +82,7 @@ enum
  * A HIP-aware consumer finds the device address of the twin as qdata
  * "flutl-hip-device-frame" on the memory (valid once the memory has been mapped).
  * FLUTL_FULL_D2H=1 restores synchronous whole-frame copies into writable memory. */
-#define MAX_IN_FLIGHT 12           /* buffers handed out but not yet queued on the device */
+#define MAX_IN_FLIGHT 8            /* buffers handed out but not yet queued on the device */
 #define POOL_MAX_FREE 16
 
 typedef struct
@@ -96,7 +96,7 @@ typedef struct
 {
   gint refs;
   GMutex lock;
-  gsize block_size;
+  gsize block_size, prefilled_size;
   GPtrArray *free_slots;          /* FrameSlot* */
 } FramePool;
 
@@ -308,40 +308,75 @@ flutl_allocator_get (void)
   return a;
 }
 
-/* A slot of the pool (recycled, or made on `ctx`), or NULL. */
 static FrameSlot *
-frame_pool_take (FramePool *p, flutl_ctx *ctx, gint width, gint height, gboolean async)
+frame_slot_new (flutl_ctx *ctx, gint width, gint height, gboolean async)
 {
-  const gsize size = (gsize) width * height * 4;
-  FrameSlot *slot = NULL;
-  g_mutex_lock (&p->lock);
-  if (p->block_size != size) {
-    for (guint i = 0; i < p->free_slots->len; i++)
-      frame_slot_free (g_ptr_array_index (p->free_slots, i));
-    g_ptr_array_set_size (p->free_slots, 0);
-    p->block_size = size;
-  }
-  for (guint i = p->free_slots->len; i-- > 0 && !slot;) {
-    FrameSlot *c = g_ptr_array_index (p->free_slots, i);
-    if ((c->frame != NULL) == async)
-      slot = g_ptr_array_remove_index_fast (p->free_slots, i);
-  }
-  g_mutex_unlock (&p->lock);
-  if (slot)
-    return slot;
-  slot = g_new0 (FrameSlot, 1);
+  FrameSlot *slot = g_new0 (FrameSlot, 1);
   if (async) {
     if (flutl_frame_create (ctx, width, height, &slot->frame) != FLUTL_OK) {
       g_free (slot);
       return NULL;
     }
   } else {
-    if (flutl_host_alloc (size, &slot->block) != FLUTL_OK) {
+    if (flutl_host_alloc ((gsize) width * height * 4, &slot->block) != FLUTL_OK) {
       g_free (slot);
       return NULL;
     }
   }
   return slot;
+}
+
+/* (pool lock held) frames of another size go */
+static void
+frame_pool_set_size (FramePool *p, gsize size)
+{
+  if (p->block_size == size)
+    return;
+  for (guint i = 0; i < p->free_slots->len; i++)
+    frame_slot_free (g_ptr_array_index (p->free_slots, i));
+  g_ptr_array_set_size (p->free_slots, 0);
+  p->block_size = size;
+}
+
+/* A slot of the pool (recycled, or made on `ctx`), or NULL. */
+static FrameSlot *
+frame_pool_take (FramePool *p, flutl_ctx *ctx, gint width, gint height, gboolean async)
+{
+  FrameSlot *slot = NULL;
+  g_mutex_lock (&p->lock);
+  frame_pool_set_size (p, (gsize) width * height * 4);
+  for (guint i = p->free_slots->len; i-- > 0 && !slot;) {
+    FrameSlot *c = g_ptr_array_index (p->free_slots, i);
+    if ((c->frame != NULL) == async)
+      slot = g_ptr_array_remove_index_fast (p->free_slots, i);
+  }
+  g_mutex_unlock (&p->lock);
+  return slot ? slot : frame_slot_new (ctx, width, height, async);
+}
+
+/* Frames of a new size are made ahead, when the first one is asked for: a frame
+ * costs milliseconds (page-locking 4 bytes per pixel), which belongs to start-up
+ * and not between two buffers of a running stream. */
+static void
+frame_pool_prefill (FramePool *p, flutl_ctx *ctx, gint width, gint height, guint n)
+{
+  const gsize size = (gsize) width * height * 4;
+  g_mutex_lock (&p->lock);
+  if (p->prefilled_size == size) {
+    g_mutex_unlock (&p->lock);
+    return;
+  }
+  p->prefilled_size = size;
+  frame_pool_set_size (p, size);
+  g_mutex_unlock (&p->lock);
+  for (guint i = 0; i < n; i++) {
+    FrameSlot *slot = frame_slot_new (ctx, width, height, TRUE);
+    if (!slot)
+      break;
+    g_mutex_lock (&p->lock);
+    g_ptr_array_add (p->free_slots, slot);
+    g_mutex_unlock (&p->lock);
+  }
 }
 
 /* A GstBuffer over a pooled slot; the slot returns to the pool with the buffer. */
@@ -409,12 +444,14 @@ typedef struct
    * uploads new atlas entries and queues the frame on the device, in order.
    * While it has work, it alone uses `ctx`. */
   gboolean sync_mode;        /* FLUTL_SYNC=1: everything on the streaming thread */
+  guint pool_prefill;        /* FLUTL_POOL_PREFILL (default 8): frames made ahead */
   GThread *finisher;
   GAsyncQueue *jobs;
   GMutex flight_lock;
   GCond flight_cond;
   guint in_flight;
-  gint64 t_submit;           /* (finisher's clock, read when it is idle) */
+  gint64 t_submit, t_flush, t_resolve;   /* (finisher's clocks, read when it is idle) */
+  guint n_deferred;          /* buffers that went through the finisher */
   guint64 delta_reported;
 } GstTTMLRenderPrivate;
 
@@ -1674,10 +1711,20 @@ finisher_main (gpointer data)
       g_free (job);
       break;
     }
+    t0 = priv->timing ? g_get_monotonic_time () : 0;
     flutl_recorder_resolve (priv->rec, job->regions, job->n_rg, job->prims, job->n_pr,
         job->patches, job->n_patches);
-    t0 = priv->timing ? g_get_monotonic_time () : 0;
+    if (priv->timing) {
+      gint64 t1 = g_get_monotonic_time ();
+      priv->t_resolve += t1 - t0;
+      t0 = t1;
+    }
     rc = flush_atlas (render) ? FLUTL_OK : FLUTL_ENODEV;
+    if (priv->timing) {
+      gint64 t1 = g_get_monotonic_time ();
+      priv->t_flush += t1 - t0;
+      t0 = t1;
+    }
     if (rc == FLUTL_OK)
       rc = flutl_frame_submit (priv->ctx, job->slot->frame, job->regions, job->n_rg,
           job->prims, job->n_pr);
@@ -1860,12 +1907,23 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
     GstMapInfo map;
     const gsize size = (gsize) width * height * 4;
     const gboolean async = !priv->full_d2h;
+    if (async && !priv->sync_mode && !priv->dump)
+      frame_pool_prefill (priv->pool, priv->ctx, width, height, priv->pool_prefill);
     FrameSlot *slot = frame_pool_take (priv->pool, priv->ctx, width, height, async);
     int rc = FLUTL_OK;
-    if (slot && slot->frame && !priv->sync_mode && !priv->dump) {
+    uint32_t n_deferred = 0;
+    (void) flutl_recorder_patches (rec, &n_deferred);
+    g_mutex_lock (&priv->flight_lock);
+    const gboolean finisher_idle = priv->in_flight == 0;
+    g_mutex_unlock (&priv->flight_lock);
+    /* (a frame with all its masks there, and nothing ahead of it: queued on the
+     * device right here -- a thread hop would only cost) */
+    if (slot && slot->frame && !priv->sync_mode && !priv->dump &&
+        (n_deferred > 0 || !finisher_idle)) {
       /* hand the buffer out now; the finisher queues it on the device when its
        * masks are there (mapping the memory waits for both) */
       Ticket *ticket = ticket_new ();
+      priv->n_deferred++;
       buffer = frame_pool_wrap (priv->pool, slot, size, ticket);
       pipeline_push (render, width, height, rg, n_rg, pr, n_pr, slot, buffer, ticket);
       ticket_unref (ticket);
@@ -2057,14 +2115,17 @@ timing_report (GstTTMLRender *render)
     t_drained = priv->t_last_return;
   }
   g_printerr ("ttmlrender-hip timing: buffers=%u record_us=%.1f device_us=%.1f "
-      "span_us=%" G_GINT64_FORMAT " drained_us=%" G_GINT64_FORMAT " delta_bytes=%.0f\n",
+      "span_us=%" G_GINT64_FORMAT " drained_us=%" G_GINT64_FORMAT " delta_bytes=%.0f "
+      "deferred=%u resolve_wait_us=%.1f atlas_upload_us=%.1f\n",
       priv->n_timed, (double) priv->t_record / MAX (priv->n_timed - 1, 1),
       (double) (priv->t_device + priv->t_submit) / MAX (priv->n_timed - 1, 1),
       priv->t_last_return - priv->t_first_return,
       MAX (t_drained, priv->t_last_return) - priv->t_first_return,
-      (double) delta / priv->n_timed);
-  priv->n_timed = 0;
-  priv->t_record = priv->t_device = priv->t_submit = 0;
+      (double) delta / priv->n_timed, priv->n_deferred,
+      (double) priv->t_resolve / MAX (priv->n_deferred, 1),
+      (double) priv->t_flush / MAX (priv->n_deferred, 1));
+  priv->n_timed = priv->n_deferred = 0;
+  priv->t_record = priv->t_device = priv->t_submit = priv->t_flush = priv->t_resolve = 0;
 }
 
 /* ---- reset / dispose / init (reference :1610-1750) ------------------------------- */
@@ -2230,6 +2291,8 @@ gst_ttmlrender_init (GstTTMLRender *render)
     priv->atlas_limit = (gsize) g_ascii_strtoull (g_getenv ("FLUTL_ATLAS_LIMIT_BYTES"), NULL, 10);
   priv->overlay_meta = g_getenv ("FLUTL_OVERLAY_COMPOSITION") != NULL;
   priv->sync_mode = g_getenv ("FLUTL_SYNC") != NULL;
+  priv->pool_prefill = g_getenv ("FLUTL_POOL_PREFILL")
+      ? (guint) CLAMP (atoi (g_getenv ("FLUTL_POOL_PREFILL")), 0, POOL_MAX_FREE) : 8;
   priv->jobs = g_async_queue_new ();
   g_mutex_init (&priv->flight_lock);
   g_cond_init (&priv->flight_cond);
