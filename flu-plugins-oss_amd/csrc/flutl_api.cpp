@@ -182,7 +182,7 @@ extern "C" int flutl_list_validate (uint32_t width, uint32_t height,
 
 extern "C" int flutl_blur_kernel (int radius, double sigma, int32_t *out)
 {
-  if (radius < 0 || radius > 128 || !out || !(sigma > 0.0))
+  if (radius < 0 || radius > FLUTL_BLUR_MAX_RADIUS || !out || !(sigma > 0.0))
     return FLUTL_EINVAL;
   const double scale2 = 2.0 * sigma * sigma;
   const double scale1 = 1.0 / (M_PI * scale2);
@@ -357,8 +357,10 @@ extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
     const int32_t *box, int rotate_cw, void *host_copy, uint32_t *offset_out)
 {
   if (!c || !offset_out || w == 0 || h == 0 || w > 32766 || h > 32766 || radius < 0 ||
-      radius > 128 || distx > 127 || disty > 127)
+      radius > FLUTL_BLUR_MAX_RADIUS || distx > 127 || disty > 127)
     return FLUTL_EINVAL;
+  if ((long long) w * h * (2ll * radius + 1) * (2ll * radius + 1) > FLUTL_BLUR_MAX_TAPS)
+    return FLUTL_ERANGE;
   int rc = flutl_list_validate (w, h, regions, n_regions, prims, n_prims,
       c->atlas_used + kAtlasSlack);
   if (rc)

@@ -968,7 +968,7 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
 //   acc_c += chan_c * f;  out_c = clip ((acc_c + 0x8000) >> 16, 0, 255).
 constexpr int kBlurTW = 32, kBlurTH = 8;
 constexpr int kBlurMaxR = 16;      // LDS-tiled kernel (<= 18 KB of LDS)
-constexpr int kBlurMaxRWide = 128; // flutl_blur_wide_kernel_dev: taps straight from L1/L2
+constexpr int kBlurMaxRWide = FLUTL_BLUR_MAX_RADIUS;   // flutl_blur_wide_kernel_dev: taps straight from L1/L2
 
 __global__ __launch_bounds__ (256) void flutl_blur_kernel_dev (
     const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int w, int h,

@@ -963,30 +963,16 @@ glyph_lookup (FlutlRecorder *rec, cairo_scaled_font_t *sf, uint32_t glyph,
   return e;
 }
 
-void
-flutl_recorder_show_glyph (FlutlRecorder *rec, PangoFont *font,
-    const PangoGlyphInfo *gi)
+/* One glyph of a scaled font at the user-space point (ux, uy): what
+ * cairo_show_glyphs / cairo_show_text do on the image backend -- the point goes
+ * through the CTM (a plain addition for a translation) and is rounded half up
+ * (_cairo_lround); the mask comes from the scaled font's glyph cache. */
+static void
+show_scaled_glyph (FlutlRecorder *rec, cairo_scaled_font_t *sf, uint32_t glyph, double cx,
+    double cy)
 {
   cairo_matrix_t m;
-  if (gi->glyph == PANGO_GLYPH_EMPTY)
-    return;
-  if (gi->glyph & PANGO_GLYPH_UNKNOWN_FLAG) {
-    rec->unsupported++;   /* hex-box rendering of unknown glyphs */
-    return;
-  }
   cairo_get_matrix (rec->cr, &m);
-  if (rec->color_clear)
-    return;
-  cairo_scaled_font_t *sf =
-      pango_cairo_font_get_scaled_font ((PangoCairoFont *) font);
-  if (!sf)
-    return;
-  /* pango_cairo_renderer: position = current point (none -> 0,0) + offsets;
-   * cairo maps it through the CTM (a plain addition for a translation) and the
-   * image backend rounds half up (_cairo_lround). */
-  double cx = (double) gi->geometry.x_offset / PANGO_SCALE;
-  double cy = gi->geometry.y_offset == 0
-      ? 0.0 : (double) gi->geometry.y_offset / PANGO_SCALE;
   if (m.xx == 1.0 && m.yy == 1.0 && m.xy == 0.0 && m.yx == 0.0) {
     cx += m.x0;
     cy += m.y0;
@@ -995,7 +981,7 @@ flutl_recorder_show_glyph (FlutlRecorder *rec, PangoFont *font,
   }
   int ix = (int) floor (cx + 0.5) + rec->shift[0];
   int iy = (int) floor (cy + 0.5) + rec->shift[1];
-  GlyphEntry *e = glyph_lookup (rec, sf, gi->glyph, &m);
+  GlyphEntry *e = glyph_lookup (rec, sf, glyph, &m);
   if (box_hits_target (rec, ix + e->mbox[0], iy + e->mbox[1], ix + e->mbox[2],
           iy + e->mbox[3]))
     target_touched (rec);
@@ -1018,6 +1004,226 @@ flutl_recorder_show_glyph (FlutlRecorder *rec, PangoFont *font,
   p->b = e->w + MASK_PAD;
   p->c = ox;
   p->d = oy;
+}
+
+/* ---- unknown glyphs: Pango's hex box -------------------------------------------
+ * For a code point no font covers, pango_cairo_show_glyph_string (reference
+ * gstttmlrender.c:1149-1151) draws a box with the code point's hex digits in it.
+ * Third-party arithmetic, not in /root/reference: Pango 1.45.3, pangocairo-
+ * font.c (_pango_cairo_font_private_get_hex_box_info: the metrics, from a
+ * "monospace" mini font of size / 2.2) and pangocairo-render.c
+ * (_pango_cairo_renderer_draw_unknown_glyph: a stroked rectangle, then one
+ * cairo_show_text per digit), restated here; pinned by the cairo-trace of the
+ * reference (oracle/hexbox_trace.md) and by scene k16 (frames of the reference).
+ * On an image with DejaVu only this is every CJK / Arabic / Hebrew cue. */
+typedef struct
+{
+  PangoFont *mini;
+  int rows;
+  double digit_width, digit_height, pad_x, pad_y, line_width, box_height, box_descent;
+} HexBox;
+
+static void
+hexbox_free (gpointer data)
+{
+  HexBox *hb = data;
+  if (hb->mini)
+    g_object_unref (hb->mini);
+  g_free (hb);
+}
+
+static HexBox *
+hexbox_info (PangoFont *font)
+{
+  static GQuark quark;
+  if (!quark)
+    quark = g_quark_from_static_string ("flutl-hexbox-info");
+  HexBox *hb = g_object_get_qdata (G_OBJECT (font), quark);
+  if (hb)
+    return hb->mini ? hb : NULL;
+  hb = g_new0 (HexBox, 1);
+  g_object_set_qdata_full (G_OBJECT (font), quark, hb, hexbox_free);
+
+  cairo_scaled_font_t *sf = pango_cairo_font_get_scaled_font ((PangoCairoFont *) font);
+  PangoFontMap *fontmap = pango_font_get_font_map (font);
+  if (!sf || cairo_scaled_font_status (sf) != CAIRO_STATUS_SUCCESS || !fontmap)
+    return NULL;
+  cairo_font_options_t *options = cairo_font_options_create ();
+  cairo_matrix_t ctm;
+  cairo_scaled_font_get_ctm (sf, &ctm);
+  cairo_scaled_font_get_font_options (sf, options);
+  const int hinted = cairo_font_options_get_hint_metrics (options) != CAIRO_HINT_METRICS_OFF;
+  double scale_x = 1., scale_x_inv = 1., scale_y = 1., scale_y_inv = 1.;
+  if (hinted) {
+    double x = 1., y = 0.;
+    cairo_matrix_transform_distance (&ctm, &x, &y);
+    scale_x = sqrt (x * x + y * y);
+    scale_x_inv = 1 / scale_x;
+    x = 0.;
+    y = 1.;
+    cairo_matrix_transform_distance (&ctm, &x, &y);
+    scale_y = sqrt (x * x + y * y);
+    scale_y_inv = 1 / scale_y;
+  }
+#define HB_HINT(v, sc, inv) (ceil (((v) - 1e-5) * (sc)) * (inv))
+  PangoFontDescription *desc = pango_font_describe_with_absolute_size (font);
+  const double size = pango_font_description_get_size (desc) / (1. * PANGO_SCALE);
+  pango_font_description_unset_fields (desc, PANGO_FONT_MASK_GRAVITY);
+  pango_font_description_set_family_static (desc, "monospace");
+  int rows = 2;
+  double mini_size = size / 2.2;
+  if (hinted) {
+    mini_size = HB_HINT (mini_size, scale_y, scale_y_inv);
+    if (mini_size < 6.0) {
+      rows = 1;
+      mini_size = MIN (MAX (size - 1, 0), 6.0);
+    }
+  }
+  pango_font_description_set_absolute_size (desc, pango_units_from_double (mini_size));
+  {
+    PangoContext *context = pango_font_map_create_context (fontmap);
+    PangoMatrix pm = { ctm.xx, ctm.xy, ctm.yx, ctm.yy, ctm.x0, ctm.y0 };
+    pango_context_set_matrix (context, &pm);
+    pango_context_set_language (context, pango_script_get_sample_language (PANGO_SCRIPT_LATIN));
+    pango_cairo_context_set_font_options (context, options);
+    hb->mini = pango_font_map_load_font (fontmap, context, desc);
+    g_object_unref (context);
+  }
+  pango_font_description_free (desc);
+  cairo_font_options_destroy (options);
+  cairo_scaled_font_t *smini = hb->mini
+      ? pango_cairo_font_get_scaled_font ((PangoCairoFont *) hb->mini) : NULL;
+  if (!smini || cairo_scaled_font_status (smini) != CAIRO_STATUS_SUCCESS) {
+    g_clear_object (&hb->mini);
+    return NULL;
+  }
+  double width = 0, height = 0;
+  for (int i = 0; i < 16; i++) {
+    const char c[2] = { "0123456789ABCDEF"[i], 0 };
+    cairo_text_extents_t ext;
+    cairo_scaled_font_text_extents (smini, c, &ext);
+    width = MAX (width, ext.width);
+    height = MAX (height, ext.height);
+  }
+  cairo_font_extents_t fe;
+  cairo_scaled_font_extents (sf, &fe);
+  if (fe.ascent + fe.descent <= 0) {
+    fe.ascent = 14;               /* PANGO_UNKNOWN_GLYPH_HEIGHT */
+    fe.descent = 0;
+  }
+  double pad = (fe.ascent + fe.descent) / 43;
+  pad = MIN (pad, mini_size);
+  hb->rows = rows;
+  hb->digit_width = width;
+  hb->digit_height = height;
+  hb->pad_x = hb->pad_y = pad;
+  if (hinted) {
+    hb->digit_width = HB_HINT (hb->digit_width, scale_x, scale_x_inv);
+    hb->digit_height = HB_HINT (hb->digit_height, scale_y, scale_y_inv);
+    hb->pad_x = HB_HINT (hb->pad_x, scale_x, scale_x_inv);
+    hb->pad_y = HB_HINT (hb->pad_y, scale_y, scale_y_inv);
+  }
+  hb->line_width = MIN (hb->pad_x, hb->pad_y);
+  hb->box_height = 3 * hb->pad_y + rows * (hb->pad_y + hb->digit_height);
+  if (rows == 1 || hb->box_height <= fe.ascent)
+    hb->box_descent = 2 * hb->pad_y;
+  else if (hb->box_height <= fe.ascent + fe.descent - 2 * hb->pad_y)
+    hb->box_descent = 2 * hb->pad_y + hb->box_height - fe.ascent;
+  else
+    hb->box_descent = fe.descent * hb->box_height / (fe.ascent + fe.descent);
+  if (hinted)
+    hb->box_descent = HB_HINT (hb->box_descent, scale_y, scale_y_inv);
+#undef HB_HINT
+  return hb;
+}
+
+/* Code points Pango 1.45 does NOT draw as a hex box when they come as unknown
+ * glyphs: spaces (a centred dot), default ignorables (a short name), tab and
+ * line breaks.  Not reproduced: the buffer fails instead (flutl_recorder_unsupported). */
+static int
+hexbox_is_special (gunichar ch)
+{
+  return ch == 0x2423 || g_unichar_type (ch) == G_UNICODE_SPACE_SEPARATOR || ch == '\t' ||
+      ch == '\n' || ch == 0x2028 || ch == 0x2029 || ch == 0x00ad || ch == 0x034f ||
+      ch == 0x061c || (ch >= 0x200b && ch <= 0x200f) || (ch >= 0x202a && ch <= 0x202e) ||
+      (ch >= 0x2060 && ch <= 0x2069) || ch == 0xfeff;
+}
+
+static void
+hexbox_show (FlutlRecorder *rec, PangoFont *font, const PangoGlyphInfo *gi)
+{
+  const gunichar ch = gi->glyph & ~PANGO_GLYPH_UNKNOWN_FLAG;
+  /* the point pango_cairo_renderer_show_text_glyphs hands to the box */
+  const double cx = (double) gi->geometry.x_offset / PANGO_SCALE;
+  const double cy = gi->geometry.y_offset == 0
+      ? 0.0 : (double) gi->geometry.y_offset / PANGO_SCALE;
+  HexBox *hb;
+  if (gi->glyph == (0x20 | PANGO_GLYPH_UNKNOWN_FLAG))
+    return;                     /* "no hex boxes for space, please" */
+  if (gi->glyph == PANGO_GLYPH_INVALID_INPUT || ch > 0x10FFFF || hexbox_is_special (ch) ||
+      !(hb = hexbox_info (font))) {
+    rec->unsupported++;
+    return;
+  }
+  if (rec->color_clear)
+    return;
+  cairo_scaled_font_t *smini = pango_cairo_font_get_scaled_font ((PangoCairoFont *) hb->mini);
+  const int rows = hb->rows, cols = (ch > 0xffff ? 6 : 4) / rows;
+  char buf[8];
+  g_snprintf (buf, sizeof buf, ch > 0xffff ? "%06X" : "%04X", ch);
+  const double width = 3 * hb->pad_x + cols * (hb->digit_width + hb->pad_x);
+  double lsb = ((double) gi->geometry.width / PANGO_SCALE - width) * .5;
+  lsb = floor (lsb / hb->pad_x) * hb->pad_x;
+  /* the frame: cairo_rectangle + cairo_stroke (line join miter, limit 2) */
+  {
+    cairo_t *cr = rec->cr;
+    cairo_save (cr);
+    cairo_set_line_width (cr, hb->line_width);
+    cairo_set_miter_limit (cr, 2.);
+    flutl_recorder_path_rect (rec, cx + lsb + .5 * hb->pad_x,
+        cy + hb->box_descent - hb->box_height + hb->line_width * 0.5, width - hb->pad_x,
+        hb->box_height - hb->line_width);
+    flutl_recorder_stroke (rec);
+    cairo_restore (cr);
+  }
+  /* the digits: cairo_move_to + cairo_show_text with the mini font */
+  const double x0 = cx + lsb + hb->pad_x * 2;
+  const double y0 = cy + hb->box_descent - hb->pad_y * 2;
+  for (int row = 0; row < rows; row++) {
+    const double y = y0 - (rows - 1 - row) * (hb->digit_height + hb->pad_y);
+    for (int col = 0; col < cols; col++) {
+      const double x = x0 + col * (hb->digit_width + hb->pad_x);
+      cairo_glyph_t *glyphs = NULL;
+      int n = 0;
+      if (cairo_scaled_font_text_to_glyphs (smini, x, y, &buf[row * cols + col], 1, &glyphs,
+              &n, NULL, NULL, NULL) != CAIRO_STATUS_SUCCESS)
+        continue;
+      for (int k = 0; k < n; k++)
+        show_scaled_glyph (rec, smini, (uint32_t) glyphs[k].index, glyphs[k].x, glyphs[k].y);
+      cairo_glyph_free (glyphs);
+    }
+  }
+}
+
+void
+flutl_recorder_show_glyph (FlutlRecorder *rec, PangoFont *font,
+    const PangoGlyphInfo *gi)
+{
+  if (gi->glyph == PANGO_GLYPH_EMPTY)
+    return;
+  if (gi->glyph & PANGO_GLYPH_UNKNOWN_FLAG) {
+    hexbox_show (rec, font, gi);
+    return;
+  }
+  if (rec->color_clear)
+    return;
+  cairo_scaled_font_t *sf =
+      pango_cairo_font_get_scaled_font ((PangoCairoFont *) font);
+  if (!sf)
+    return;
+  /* pango_cairo_renderer: position = current point (none -> 0,0) + offsets */
+  show_scaled_glyph (rec, sf, gi->glyph, (double) gi->geometry.x_offset / PANGO_SCALE,
+      gi->geometry.y_offset == 0 ? 0.0 : (double) gi->geometry.y_offset / PANGO_SCALE);
 }
 
 /* ---- strokes ---------------------------------------------------------------
@@ -1123,11 +1329,14 @@ stroke_key (FlutlRecorder *rec, double line_width, int base_x, int base_y,
     uint8_t **out)
 {
   size_t per = 10 * sizeof (double) + 2 * sizeof (uint64_t);
-  size_t n = sizeof (double) + rec->n_ops * per;
+  size_t n = 2 * sizeof (double) + rec->n_ops * per;
   uint8_t *k = malloc (n), *p = k;
   if (!k)
     abort ();
+  double miter = cairo_get_miter_limit (rec->cr);
   memcpy (p, &line_width, sizeof (double));
+  p += sizeof (double);
+  memcpy (p, &miter, sizeof (double));
   p += sizeof (double);
   for (uint32_t i = 0; i < rec->n_ops; i++) {
     const PathOp *op = &rec->ops[i];
@@ -1554,7 +1763,7 @@ typedef struct StrokeJob
   gint refs;
   cairo_path_t *path;            /* device coordinates */
   cairo_matrix_t ctm;            /* in force at cairo_stroke */
-  double line_width;
+  double line_width, miter_limit;
   RasterBox rb;
   int sw, sh;                    /* size of the surface to stroke on */
   uint8_t *tight;                /* result: w x h coverage at (x, y), or NULL */
@@ -1632,6 +1841,7 @@ stroke_job_run (gpointer data, gpointer user_data)
   cairo_append_path (cr, j->path);      /* (identity CTM: device coordinates) */
   cairo_set_matrix (cr, &j->ctm);
   cairo_set_line_width (cr, j->line_width);
+  cairo_set_miter_limit (cr, j->miter_limit);
   cairo_set_source_rgba (cr, 1, 1, 1, 1);
   cairo_stroke (cr);
   cairo_destroy (cr);
@@ -1690,6 +1900,7 @@ stroke_defer (FlutlRecorder *rec, StrokeEntry *e)
   g_cond_init (&j->cond);
   cairo_get_matrix (cr, &j->ctm);
   j->line_width = cairo_get_line_width (cr);
+  j->miter_limit = cairo_get_miter_limit (cr);
   cairo_save (cr);
   cairo_identity_matrix (cr);
   j->path = cairo_copy_path (cr);

@@ -21,7 +21,7 @@
  * the odd ones; each is marked "reference:" below.
  *
  * Not implemented yet (counted and logged, never silently approximated):
- * blurred outlines with a blur above 64 px, unknown-glyph boxes.
+ * (nothing the reference can render in a sane time; what is beyond a limit fails the buffer).
  */
 #ifdef HAVE_CONFIG_H
 #include "config.h"
@@ -1384,10 +1384,14 @@ blurred_outline (GstTTMLRender *render, HipRegion *r, PangoLayout *layout, guint
    * cos (pi/2) is 6e-17 there, not 0) */
   rotated = fabs (m.xx) < 1e-9 && fabs (m.yy) < 1e-9 && m.xy == -1.0 && m.yx == 1.0;
   if ((!rotated && (m.xx != 1.0 || m.yy != 1.0 || m.xy != 0.0 || m.yx != 0.0)) ||
-      radius > 128 || radius < 0 || !(sigma > 0.0) || tw <= 0 || th <= 0 || tw > 32766 ||
-      th > 32766 || fabs (m.x0) > 30000.0 || fabs (m.y0) > 30000.0) {
-    GST_FIXME_OBJECT (render, "blurred textOutline under this CTM, or with a blur length "
-        "above 64 px, is not implemented; outline of region '%s' not drawn", r->id);
+      radius > FLUTL_BLUR_MAX_RADIUS || radius < 0 || !(sigma > 0.0) || tw <= 0 || th <= 0 ||
+      tw > 32766 || th > 32766 || fabs (m.x0) > 30000.0 || fabs (m.y0) > 30000.0 ||
+      (gint64) tw * th * (2 * radius + 1) * (2 * radius + 1) > FLUTL_BLUR_MAX_TAPS) {
+    /* (no CTM other than a translation or the quarter turn of the vertical writing
+     * modes ever reaches this point; the blur limits are the library's, flutl.h) */
+    GST_FIXME_OBJECT (render, "blurred textOutline of region '%s': a blur of %g px over "
+        "%dx%d px is beyond what is implemented; the buffer is dropped", r->id,
+        r->outline.length[1].f, tw, th);
     priv->skipped++;
     return;
   }

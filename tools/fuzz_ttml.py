@@ -16,6 +16,9 @@ import compare_ref  # noqa: E402
 
 WORDS = ("subtitle overlay Glyph MAVERICK jumpy quiz, fix & go; Why? 12:45 öäü naïve "
          "Test_under line ÆØ x y z").split()
+# FUZZ_UNKNOWN=1: words no font of this image covers (Pango's hex boxes)
+if os.environ.get("FUZZ_UNKNOWN"):
+    WORDS += ["字幕", "한글", "テ", "\U00020000x", "中"]
 FAMS = ["DejaVu Sans", "DejaVu Serif", "DejaVu Sans Mono", "sansSerif", "serif", "monospace",
         "default"]
 
