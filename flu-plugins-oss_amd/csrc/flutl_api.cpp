@@ -865,8 +865,11 @@ extern "C" int flutl_frame_submit (flutl_ctx *c, flutl_frame *f,
     return FLUTL_ENODEV;
   const flutl_region *rd = static_cast<const flutl_region *> (sl.dev);
   const flutl_prim *pd = reinterpret_cast<const flutl_prim *> (static_cast<uint8_t *> (sl.dev) + rb);
-  rc = flutl_launch_frame (c->stream, width, height, c->frame, (size_t) width * 4, rd,
-      n_regions, pd, c->atlas);
+  // only the rows the regions span are composited (whole supertiles of 16 rows);
+  // the delta takes the new frame as transparent everywhere else
+  const uint32_t fy0 = now[1] & ~15u, fy1 = now[3] > now[1] ? ((now[3] + 15u) & ~15u) : fy0;
+  rc = flutl_launch_frame_rows (c->stream, width, height, c->frame, (size_t) width * 4, rd,
+      n_regions, pd, c->atlas, now[1], now[3]);
   // rows of the delta: what the frame held before + what it holds now
   uint32_t y0 = now[1], y1 = now[3];
   if (f->ext[3] > f->ext[1]) {
@@ -884,8 +887,8 @@ extern "C" int flutl_frame_submit (flutl_ctx *c, flutl_frame *f,
       rc = FLUTL_ENOMEM;
   }
   if (rc == FLUTL_OK)
-    rc = flutl_launch_delta (c->stream, c->frame, f->twin, f->host_dev, width, height, y0, y1,
-        c->delta_segments);
+    rc = flutl_launch_delta_window (c->stream, c->frame, f->twin, f->host_dev, width, height,
+        y0, y1, fy0, fy1 < height ? fy1 : height, c->delta_segments);
   ok = rc == FLUTL_OK && hip_ok (hipEventRecord (sl.done, c->stream)) &&
       hip_ok (hipEventRecord (f->done, c->stream));
   sl.busy = true;

@@ -111,6 +111,7 @@ struct FrameParams {
   uint32_t region_first, region_count;  // used when frames == nullptr
   uint32_t frame_first;                 // first frame of this launch
   uint32_t xcd_frames, row_mul, row_add;   // workgroup mapping, see the kernel
+  uint32_t row_base, row_end;           // supertile rows [row_base, row_end) are rendered
   uint32_t magic_stx;                   // ceil(2^32 / st_x), 0 if st_x == 1
   uint64_t stride;                      // bytes
 };
@@ -467,8 +468,8 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
   const uint32_t i = blockIdx.x >> 3;
   const uint32_t g = fp.magic_stx ? __umulhi (i, fp.magic_stx) : i;   // i / st_x
   const uint32_t stx = i - g * fp.st_x;
-  const uint32_t sty = g * fp.row_mul + xcd * fp.row_add;
-  if (sty >= fp.st_y)
+  const uint32_t sty = fp.row_base + g * fp.row_mul + xcd * fp.row_add;
+  if (sty >= fp.row_end)
     return;
   const uint32_t frame = fp.frame_first + xcd * fp.xcd_frames + blockIdx.y;
 
@@ -804,7 +805,6 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
             for (int r = 0; r < kRG; r++) {
               if (((((sg | (sg >> 8)) & ~um) >> r) & 1u) == 0u)
                 continue;
-              const int ry0 = sy0 + 4 * r;
               const bool src_solid = (sg >> (8 + r)) & 1u;
               const bool frame_lds = (lds_frame >> r) & 1u;
               const bool frame_solid = (solid_frame >> r) & 1u;
@@ -1152,7 +1152,8 @@ template <bool WIDE>
 __global__ __launch_bounds__ (256) void flutl_delta_kernel (
     const uint8_t *__restrict__ fresh, uint8_t *__restrict__ twin,
     uint8_t *__restrict__ host, uint32_t row_bytes, uint32_t chunks_per_row,
-    uint32_t y0, uint32_t n_rows, unsigned long long *__restrict__ changed_segments)
+    uint32_t y0, uint32_t n_rows, uint32_t fresh_y0, uint32_t fresh_y1,
+    unsigned long long *__restrict__ changed_segments)
 {
   // thread -> (row, 16-byte chunk); a wave covers 4 segments of 16 chunks, which
   // may lie in two rows (chunks_per_row is padded to a multiple of 16 so that a
@@ -1161,12 +1162,16 @@ __global__ __launch_bounds__ (256) void flutl_delta_kernel (
   const uint32_t row = idx / chunks_per_row, c = idx - row * chunks_per_row;
   const bool live = row < n_rows && c * 16u < row_bytes;
   const size_t off = (size_t) (y0 + row) * row_bytes + (size_t) c * 16u;
+  // rows outside [fresh_y0, fresh_y1) were not composited this time: the new
+  // frame is transparent there, whatever `fresh` still holds
+  const bool drawn = y0 + row >= fresh_y0 && y0 + row < fresh_y1;
   uint4 v = make_uint4 (0, 0, 0, 0), t = v;
   uint32_t n_dw = 0;              // dwords of this chunk that exist (WIDE: 4)
   if (live) {
     if (WIDE) {
       n_dw = 4;
-      v = *reinterpret_cast<const uint4 *> (fresh + off);
+      if (drawn)
+        v = *reinterpret_cast<const uint4 *> (fresh + off);
       t = *reinterpret_cast<const uint4 *> (twin + off);
     } else {
       n_dw = min (4u, (row_bytes - c * 16u) / 4u);
@@ -1174,7 +1179,7 @@ __global__ __launch_bounds__ (256) void flutl_delta_kernel (
       const uint32_t *tv = reinterpret_cast<const uint32_t *> (twin + off);
       uint32_t a[4] = { 0, 0, 0, 0 }, b[4] = { 0, 0, 0, 0 };
       for (uint32_t k = 0; k < n_dw; k++) {
-        a[k] = fv[k];
+        a[k] = drawn ? fv[k] : 0u;
         b[k] = tv[k];
       }
       v = make_uint4 (a[0], a[1], a[2], a[3]);
@@ -1207,7 +1212,7 @@ __global__ __launch_bounds__ (256) void flutl_delta_kernel (
 int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst,
     const void *video, size_t stride, const flutl_frame_desc *frames, uint32_t n_frames,
     uint32_t region_first, uint32_t region_count, const flutl_region *regions,
-    const flutl_prim *prims, const uint8_t *atlas)
+    const flutl_prim *prims, const uint8_t *atlas, uint32_t row0 = 0, uint32_t row1 = 0)
 {
   if (!dst || width == 0 || height == 0 || n_frames == 0 || width > 32767 ||
       height > 32767 || (stride & 3) || stride < (size_t) width * 4)
@@ -1217,12 +1222,18 @@ int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst
   fp.height = height;
   fp.st_x = (width + kSuperW - 1) / kSuperW;
   fp.st_y = (height + kSuperH - 1) / kSuperH;
+  // rows [row0, row1) only (row1 == 0: all), widened to whole supertiles
+  fp.row_base = row1 ? row0 / kSuperH : 0u;
+  fp.row_end = row1 ? (min (row1, height) + kSuperH - 1) / kSuperH : fp.st_y;
+  if (fp.row_end <= fp.row_base)
+    return FLUTL_OK;
+  const uint32_t n_rows = fp.row_end - fp.row_base;
   fp.n_frames = n_frames;
   fp.region_first = region_first;
   fp.region_count = region_count;
   if (n_frames > 8u * 65535u)
     return FLUTL_EINVAL;
-  const uint32_t per_frame = fp.st_x * fp.st_y;     // <= 512 * 2048
+  const uint32_t per_frame = fp.st_x * n_rows;      // <= 512 * 2048
   fp.magic_stx = fp.st_x > 1u
       ? (uint32_t) ((0x100000000ull + fp.st_x - 1u) / fp.st_x) : 0u;
   fp.stride = stride;
@@ -1255,7 +1266,7 @@ int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst
     fp.xcd_frames = 0;
     fp.row_mul = 8;
     fp.row_add = 1;
-    LAUNCH (dim3 ((fp.st_y + 7u) / 8u * fp.st_x * 8u, rest));
+    LAUNCH (dim3 ((n_rows + 7u) / 8u * fp.st_x * 8u, rest));
   }
 #undef LAUNCH
   return hipGetLastError () == hipSuccess ? FLUTL_OK : FLUTL_ENODEV;
@@ -1269,6 +1280,19 @@ extern "C" int flutl_launch_frame (void *stream, uint32_t width, uint32_t height
 {
   return launch_tiles (static_cast<hipStream_t> (stream), width, height, dst, nullptr,
       dst_stride_bytes, nullptr, 1, 0, n_regions, regions, prims, atlas);
+}
+
+extern "C" int flutl_launch_frame_rows (void *stream, uint32_t width, uint32_t height,
+    void *dst, size_t dst_stride_bytes, const flutl_region *regions,
+    uint32_t n_regions, const flutl_prim *prims, const uint8_t *atlas, uint32_t row0,
+    uint32_t row1)
+{
+  if (row0 > row1 || row1 > height)
+    return FLUTL_EINVAL;
+  if (row0 == row1)
+    return FLUTL_OK;
+  return launch_tiles (static_cast<hipStream_t> (stream), width, height, dst, nullptr,
+      dst_stride_bytes, nullptr, 1, 0, n_regions, regions, prims, atlas, row0, row1);
 }
 
 extern "C" int flutl_launch_batch (void *stream, uint32_t width, uint32_t height,
@@ -1368,8 +1392,16 @@ extern "C" int flutl_launch_delta (void *stream, const void *fresh, void *twin, 
     uint32_t width, uint32_t height, uint32_t row0, uint32_t row1,
     uint64_t *changed_segments)
 {
+  return flutl_launch_delta_window (stream, fresh, twin, host, width, height, row0, row1, 0,
+      height, changed_segments);
+}
+
+extern "C" int flutl_launch_delta_window (void *stream, const void *fresh, void *twin,
+    void *host, uint32_t width, uint32_t height, uint32_t row0, uint32_t row1,
+    uint32_t fresh_row0, uint32_t fresh_row1, uint64_t *changed_segments)
+{
   if (!fresh || !twin || !host || width == 0 || height == 0 || width > 32767 ||
-      height > 32767 || row0 > row1 || row1 > height)
+      height > 32767 || row0 > row1 || row1 > height || fresh_row0 > fresh_row1)
     return FLUTL_EINVAL;
   if (row0 == row1)
     return FLUTL_OK;
@@ -1384,11 +1416,13 @@ extern "C" int flutl_launch_delta (void *stream, const void *fresh, void *twin, 
     hipLaunchKernelGGL (flutl_delta_kernel<true>, grid, dim3 (256), 0,
         static_cast<hipStream_t> (stream), static_cast<const uint8_t *> (fresh),
         static_cast<uint8_t *> (twin), static_cast<uint8_t *> (host), row_bytes, chunks,
-        row0, row1 - row0, reinterpret_cast<unsigned long long *> (changed_segments));
+        row0, row1 - row0, fresh_row0, fresh_row1,
+        reinterpret_cast<unsigned long long *> (changed_segments));
   else
     hipLaunchKernelGGL (flutl_delta_kernel<false>, grid, dim3 (256), 0,
         static_cast<hipStream_t> (stream), static_cast<const uint8_t *> (fresh),
         static_cast<uint8_t *> (twin), static_cast<uint8_t *> (host), row_bytes, chunks,
-        row0, row1 - row0, reinterpret_cast<unsigned long long *> (changed_segments));
+        row0, row1 - row0, fresh_row0, fresh_row1,
+        reinterpret_cast<unsigned long long *> (changed_segments));
   return hipGetLastError () == hipSuccess ? FLUTL_OK : FLUTL_ENODEV;
 }

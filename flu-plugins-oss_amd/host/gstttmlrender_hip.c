@@ -451,6 +451,7 @@ typedef struct
   GCond flight_cond;
   guint in_flight;
   gint64 t_submit, t_flush, t_resolve;   /* (finisher's clocks, read when it is idle) */
+  gint64 t_build, t_layout;  /* parts of t_record: spans -> regions, paragraphs -> layouts */
   guint n_deferred;          /* buffers that went through the finisher */
   guint64 delta_reported;
 } GstTTMLRenderPrivate;
@@ -1561,8 +1562,13 @@ record_region (HipRegion *r, GstTTMLRender *render)
   gboolean grouped = r->opacity < 1.0;
   GList *l;
 
-  if (r->par)
+  if (r->par) {
+    GstTTMLRenderPrivate *priv = get_priv (render);
+    gint64 t0 = priv->timing ? g_get_monotonic_time () : 0;
     region_flush_paragraph (render, r);
+    if (priv->timing && priv->n_timed)
+      priv->t_layout += g_get_monotonic_time () - t0;
+  }
 
   flutl_recorder_region_begin (rec);
   cairo_save (cr);
@@ -1859,6 +1865,8 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
   }
   for (l = base->active_spans; l; l = l->next)
     span_to_region (render, &regions, l->data);
+  if (priv->timing && priv->n_timed)
+    priv->t_build += g_get_monotonic_time () - t_start;
   for (l = regions; l; l = l->next) {
     /* a region with an opacity is drawn on a surface of its own size */
     const HipRegion *r = l->data;
@@ -1898,6 +1906,14 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
   if (priv->dump_only) {
     /* record-only test facility (no GPU needed): the base class must see a
      * buffer or its timeline bookkeeping diverges; the frame is left blank */
+    if (priv->timing) {         /* (host-side profile without a device) */
+      gint64 t = g_get_monotonic_time ();
+      if (priv->n_timed++ == 0)
+        priv->t_first_return = t;
+      else
+        priv->t_record += t - t_start;
+      priv->t_last_return = t;
+    }
     buffer = gst_buffer_new_and_alloc ((gsize) width * height * 4);
     gst_buffer_memset (buffer, 0, 0, (gsize) width * height * 4);
     return buffer;
@@ -2120,16 +2136,19 @@ timing_report (GstTTMLRender *render)
   }
   g_printerr ("ttmlrender-hip timing: buffers=%u record_us=%.1f device_us=%.1f "
       "span_us=%" G_GINT64_FORMAT " drained_us=%" G_GINT64_FORMAT " delta_bytes=%.0f "
-      "deferred=%u resolve_wait_us=%.1f atlas_upload_us=%.1f\n",
+      "deferred=%u resolve_wait_us=%.1f atlas_upload_us=%.1f build_us=%.1f layout_us=%.1f\n",
       priv->n_timed, (double) priv->t_record / MAX (priv->n_timed - 1, 1),
       (double) (priv->t_device + priv->t_submit) / MAX (priv->n_timed - 1, 1),
       priv->t_last_return - priv->t_first_return,
       MAX (t_drained, priv->t_last_return) - priv->t_first_return,
       (double) delta / priv->n_timed, priv->n_deferred,
       (double) priv->t_resolve / MAX (priv->n_deferred, 1),
-      (double) priv->t_flush / MAX (priv->n_deferred, 1));
+      (double) priv->t_flush / MAX (priv->n_deferred, 1),
+      (double) priv->t_build / MAX (priv->n_timed - 1, 1),
+      (double) priv->t_layout / MAX (priv->n_timed - 1, 1));
   priv->n_timed = priv->n_deferred = 0;
   priv->t_record = priv->t_device = priv->t_submit = priv->t_flush = priv->t_resolve = 0;
+  priv->t_build = priv->t_layout = 0;
 }
 
 /* ---- reset / dispose / init (reference :1610-1750) ------------------------------- */

@@ -51,7 +51,8 @@ EXPORTS = [
     "flutl_host_alloc", "flutl_host_free", "flutl_render_frame_to_host",
     "flutl_render_frame_rows_to_host", "flutl_render_frame_window_to_host",
     "flutl_atlas_put_blurred",
-    "flutl_launch_delta", "flutl_frame_create", "flutl_frame_destroy", "flutl_frame_host",
+    "flutl_launch_delta", "flutl_launch_delta_window", "flutl_launch_frame_rows",
+    "flutl_frame_create", "flutl_frame_destroy", "flutl_frame_host",
     "flutl_frame_device", "flutl_frame_submit", "flutl_frame_wait", "flutl_ctx_delta_bytes",
 ]
 
@@ -109,6 +110,8 @@ def lib():
         L.flutl_launch_rotate_cw.argtypes = [vp, vp, vp, u32, u32, sz, sz, vp]
         L.flutl_launch_resample.argtypes = [vp, vp, vp, u32, u32, sz, sz, u32, u32, vp]
         L.flutl_launch_delta.argtypes = [vp, vp, vp, vp, u32, u32, u32, u32, vp]
+        L.flutl_launch_delta_window.argtypes = [vp, vp, vp, vp, u32, u32, u32, u32, u32, u32, vp]
+        L.flutl_launch_frame_rows.argtypes = [vp, u32, u32, vp, sz, vp, u32, vp, vp, u32, u32]
         L.flutl_frame_create.argtypes = [vp, u32, u32, ctypes.POINTER(vp)]
         L.flutl_frame_destroy.argtypes = [vp]
         L.flutl_frame_destroy.restype = None
@@ -168,6 +171,16 @@ def launch_frame(stream, width, height, dst, regions_dev, n_regions, prims_dev,
                                     stride or width * 4, p(regions_dev), n_regions,
                                     p(prims_dev), p(atlas_dev)),
            "flutl_launch_frame")
+
+
+def launch_frame_rows(stream, width, height, dst, regions_dev, n_regions, prims_dev,
+                      atlas_dev, row0, row1, stride=None):
+    """only the supertile rows that [row0, row1) touches are written"""
+    p = _dev_ptr
+    _check(lib().flutl_launch_frame_rows(ctypes.c_void_p(stream), width, height, p(dst),
+                                         stride or width * 4, p(regions_dev), n_regions,
+                                         p(prims_dev), p(atlas_dev), row0, row1),
+           "flutl_launch_frame_rows")
 
 
 def launch_batch(stream, width, height, dst, frames_dev, n_frames, regions_dev,

@@ -131,6 +131,16 @@ int flutl_launch_frame (void *stream, uint32_t width, uint32_t height,
     const flutl_region *regions, uint32_t n_regions,
     const flutl_prim *prims, const uint8_t *atlas);
 
+/* The same, compositing only the rows [row0, row1) of the frame, widened to
+ * whole 16-row supertiles (FLUTL_TILE_H * 2); nothing else of dst is written.
+ * A subtitle frame is transparent outside its regions: the element composites
+ * the rows its regions span and lets flutl_launch_delta_window take the rest as
+ * transparent. */
+int flutl_launch_frame_rows (void *stream, uint32_t width, uint32_t height,
+    void *dst, size_t dst_stride_bytes,
+    const flutl_region *regions, uint32_t n_regions,
+    const flutl_prim *prims, const uint8_t *atlas, uint32_t row0, uint32_t row1);
+
 /* A batch of independent frames (different scene states / streams) in ONE
  * launch: frame i uses regions[region_first[i] .. +region_count[i]) and is
  * written to dst + i*dst_frame_bytes.  Prim indices inside regions are
@@ -209,6 +219,11 @@ int flutl_launch_rotate_cw (void *stream, const void *src, void *dst,
 int flutl_launch_delta (void *stream, const void *fresh, void *twin, void *host,
     uint32_t width, uint32_t height, uint32_t row0, uint32_t row1,
     uint64_t *changed_segments);
+/* ... where only the rows [fresh_row0, fresh_row1) of `fresh` were composited
+ * (flutl_launch_frame_rows): the new frame counts as transparent on the others. */
+int flutl_launch_delta_window (void *stream, const void *fresh, void *twin, void *host,
+    uint32_t width, uint32_t height, uint32_t row0, uint32_t row1,
+    uint32_t fresh_row0, uint32_t fresh_row1, uint64_t *changed_segments);
 
 /* ---- context API (library-owned HBM; what the GStreamer element uses) ---- */
 

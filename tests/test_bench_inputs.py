@@ -49,3 +49,14 @@ def test_profiled_traffic_of_the_default_command_is_committed():
     batch = int(re.search(r'"--batch", type=int, default=(\d+)', src).group(1))
     t = b.profiled_traffic("cfg2_2160p_8regions_outline", batch)
     assert t is not None and t > batch * 3840 * 2160 * 4 * 0.99
+
+
+def test_every_stream_of_config3_has_reference_hashes():
+    """cfg3 = cfg2 with seeds 20..27, one stream per GPU: each pack comes with the
+    SHA-256 of the frames the reference rendered (checked on the GPU by
+    tests/test_gpu_scenes.py::test_full_size_config_matches_reference_sha256)."""
+    import json
+    for seed in range(20, 28):
+        meta = json.load(open(os.path.join(ROOT, "bench_data", f"cfg2_seed{seed}.sha256.json")))
+        assert meta["states"] == 64 and len(meta["sha256"]) == 64
+        assert (meta["width"], meta["height"]) == (3840, 2160)

@@ -470,3 +470,24 @@ def test_frame_submit_pipelines_without_waiting_in_between(gpu):
         finally:
             for f in frames:
                 f.close()
+
+
+@pytest.mark.parametrize("size,rows", [((320, 180), (37, 101)), ((333, 77), (0, 5)),
+                                       ((640, 360), (350, 360)), ((640, 360), (16, 32))])
+def test_row_window_launch_writes_only_its_supertile_rows(gpu, size, rows):
+    """flutl_launch_frame_rows: the supertile rows (16 px) that [row0, row1) touches
+    hold the frame's pixels; nothing else of the destination is written."""
+    import torch
+    W, H = size
+    r0, r1 = rows
+    R, P, A = scenes.random_scene(31, W, H, n_regions=6)
+    exp = O.render(W, H, R, P, A)
+    rd, pd, ad = gpu.to_dev(R), gpu.to_dev(P), gpu.to_dev(A)
+    dst = torch.full((H * W * 4,), 0xAB, dtype=torch.uint8, device="cuda")
+    F.launch_frame_rows(torch.cuda.current_stream().cuda_stream, W, H, dst, rd, len(R), pd, ad,
+                        r0, r1)
+    torch.cuda.synchronize()
+    got = dst.cpu().numpy().view(np.uint32).reshape(H, W)
+    y0, y1 = r0 // 16 * 16, min(H, (r1 + 15) // 16 * 16)
+    assert np.array_equal(got[y0:y1], exp[y0:y1])
+    assert (got[:y0] == 0xABABABAB).all() and (got[y1:] == 0xABABABAB).all()

@@ -22,7 +22,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import gstenv  # noqa: E402
 
 SCENES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "scenes", "*.npz")))
-CONFIGS = [c for c in ("cfg0", "cfg1", "cfg2", "cfg4")
+# cfg2_seed20..27: the eight streams of BASELINE config 3, one per GPU at N = 8
+CONFIGS = [c for c in ["cfg0", "cfg1", "cfg2", "cfg4"] + [f"cfg2_seed{s}" for s in range(20, 28)]
            if os.path.exists(os.path.join(ROOT, "bench_data", c + ".flpk.z"))]
 
 

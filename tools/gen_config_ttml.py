@@ -112,6 +112,14 @@ def gen(cfg, seed):
         for i in range(n):
             ox, oy = rng.rint(0, 45), rng.rint(0, 80)
             extra = ' tts:zIndex="%d"' % (i + 1)
+            # An explicit base opacity: the reference gives an attribute that only
+            # <set> children define a zero-filled base value (gstttmlbase.c:697-705,
+            # "FIXME: This can be certainly improved"), i.e. opacity 0 outside the
+            # set's interval -- without this line every frame of the document is
+            # blank in the reference (as round 1's cfg4 was).  Half of the regions
+            # are translucent, so that opacity groups overlap.
+            extra += ' tts:opacity="%s"' % ("1.0" if i % 4 in (0, 3)
+                                            else "0.%d" % rng.rint(55, 90))
             if i % 2:
                 extra += ' tts:textOutline="black 4px"'
             sets = []

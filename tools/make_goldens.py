@@ -77,19 +77,30 @@ def scenes(gpu=False, only=None):
         print(f"{name}: {len(st)} states, oracle-vs-reference mismatching px: {bad}")
 
 
-def config(cfg):
-    W, H = gen_config_ttml.SIZES[cfg]
+def config(cfg, seed=None, keep_states=None, keep_ttml=True):
+    """cfg with its canonical seed -> bench_data/<cfg>.*; with another seed (the
+    streams of BASELINE config 3) -> bench_data/<cfg>_seed<seed>.* (no .ttml kept)"""
+    kind = cfg
+    W, H = gen_config_ttml.SIZES[kind]
     d = os.path.join(ROOT, "bench_data")
     os.makedirs(d, exist_ok=True)
-    ttml = os.path.join(d, cfg + ".ttml")
-    open(ttml, "w").write(gen_config_ttml.gen(
-        cfg, {"cfg0": 0, "cfg1": 1, "cfg2": 2, "cfg4": 4}[cfg]))
+    if seed is None:
+        seed = {"cfg0": 0, "cfg1": 1, "cfg2": 2, "cfg4": 4}[kind]
+    else:
+        cfg = f"{kind}_seed{seed}"
+    tmpd = None
+    if keep_ttml:
+        ttml = os.path.join(d, cfg + ".ttml")
+    else:
+        tmpd = tempfile.mkdtemp()
+        ttml = os.path.join(tmpd, cfg + ".ttml")
+    open(ttml, "w").write(gen_config_ttml.gen(kind, seed))
     pk = record(ttml, W, H)
     st = pk.states()
     # reference frames -> SHA-256, streamed through a FIFO (cfg4 is 64 GB raw)
     import threading
     fb = W * H * 4
-    keep = min(len(st), MAX_STATES[cfg])
+    keep = min(len(st), keep_states or MAX_STATES[kind])
     shas, nz, counts = [], [], {"n": 0, "bad": 0}
     fifo = os.path.join(tempfile.mkdtemp(), "frames.fifo")
     os.mkfifo(fifo)
@@ -132,6 +143,9 @@ def config(cfg):
               open(os.path.join(d, cfg + ".sha256.json"), "w"), indent=0)
     print(f"{cfg}: {n} reference frames, kept {keep}; pack {len(blob)/1e6:.2f} MB "
           f"(atlas {pk.atlas.size/1e6:.2f} MB raw); oracle spot-check mismatching px: {bad}")
+    if tmpd:
+        import shutil
+        shutil.rmtree(tmpd)
 
 
 if __name__ == "__main__":
