@@ -697,6 +697,62 @@ static int render_lists_to_host (flutl_ctx *c, uint32_t width, uint32_t height,
   return FLUTL_OK;
 }
 
+// ---- fused over-video on a host frame ---------------------------------------------
+
+extern "C" int flutl_blend_over_host (flutl_ctx *c, uint32_t width, uint32_t height,
+    const flutl_region *regions, uint32_t n_regions, const flutl_prim *prims,
+    uint32_t n_prims, void *video_host, size_t stride_bytes)
+{
+  if (!c || !video_host || stride_bytes < (size_t) width * 4 || (stride_bytes & 3))
+    return FLUTL_EINVAL;
+  int rc = flutl_list_validate (width, height, regions, n_regions, prims, n_prims,
+      c->atlas_used + kAtlasSlack);
+  if (rc)
+    return rc;
+  uint32_t y0 = height, y1 = 0;
+  for (uint32_t i = 0; i < n_regions; i++) {
+    if (regions[i].x1 <= regions[i].x0 || regions[i].y1 <= regions[i].y0 || !regions[i].count)
+      continue;
+    y0 = (uint32_t) regions[i].y0 < y0 ? (uint32_t) regions[i].y0 : y0;
+    y1 = (uint32_t) regions[i].y1 > y1 ? (uint32_t) regions[i].y1 : y1;
+  }
+  if (y1 <= y0)
+    return FLUTL_OK;            // nothing to draw: the frame is the result
+  (void) hipSetDevice (c->device);
+  // whole supertiles of 16 rows: the kernel writes video OVER'd (or copied) there
+  const uint32_t fy0 = y0 & ~15u, fy1 = ((y1 + 15u) & ~15u) < height ? ((y1 + 15u) & ~15u) : height;
+  const size_t tight = (size_t) width * 4, frame_bytes = tight * height;
+  if (2 * frame_bytes > c->frame_cap) {
+    (void) hipStreamSynchronize (c->stream);
+    if (c->frame)
+      (void) hipFree (c->frame);
+    c->frame = nullptr;
+    c->frame_cap = 0;
+    if (!hip_ok (hipMalloc (&c->frame, 2 * frame_bytes)))
+      return FLUTL_ENOMEM;
+    c->frame_cap = 2 * frame_bytes;
+  }
+  uint8_t *dst = static_cast<uint8_t *> (c->frame), *vid = dst + frame_bytes;
+  uint8_t *host = static_cast<uint8_t *> (video_host);
+  flutl_region *rd;
+  flutl_prim *pd;
+  if ((rc = upload_list (c, regions, n_regions, prims, n_prims, &rd, &pd)))
+    return rc;
+  const size_t rows = fy1 - fy0;
+  bool ok = hip_ok (hipMemcpy2DAsync (vid + (size_t) fy0 * tight, tight,
+      host + (size_t) fy0 * stride_bytes, stride_bytes, tight, rows, hipMemcpyHostToDevice,
+      c->stream));
+  if (ok)
+    ok = flutl_launch_frame_over_rows (c->stream, width, height, dst, vid, tight, rd, n_regions,
+        pd, c->atlas, fy0, fy1) == FLUTL_OK;
+  if (ok)
+    ok = hip_ok (hipMemcpy2DAsync (host + (size_t) fy0 * stride_bytes, stride_bytes,
+        dst + (size_t) fy0 * tight, tight, tight, rows, hipMemcpyDeviceToHost, c->stream));
+  if (!hip_ok (hipStreamSynchronize (c->stream)) || !ok)
+    return FLUTL_ENODEV;
+  return FLUTL_OK;
+}
+
 // ---- pooled output frames, completed asynchronously ---------------------------
 
 extern "C" int flutl_frame_create (flutl_ctx *c, uint32_t width, uint32_t height,

@@ -1295,6 +1295,19 @@ extern "C" int flutl_launch_frame_rows (void *stream, uint32_t width, uint32_t h
       dst_stride_bytes, nullptr, 1, 0, n_regions, regions, prims, atlas, row0, row1);
 }
 
+extern "C" int flutl_launch_frame_over_rows (void *stream, uint32_t width, uint32_t height,
+    void *dst, const void *video, size_t stride_bytes, const flutl_region *regions,
+    uint32_t n_regions, const flutl_prim *prims, const uint8_t *atlas, uint32_t row0,
+    uint32_t row1)
+{
+  if (!video || video == dst || row0 > row1 || row1 > height)
+    return FLUTL_EINVAL;
+  if (row0 == row1)
+    return FLUTL_OK;
+  return launch_tiles (static_cast<hipStream_t> (stream), width, height, dst, video,
+      stride_bytes, nullptr, 1, 0, n_regions, regions, prims, atlas, row0, row1);
+}
+
 extern "C" int flutl_launch_batch (void *stream, uint32_t width, uint32_t height,
     void *dst, size_t dst_stride_bytes, const flutl_frame_desc *frames,
     uint32_t n_frames, const flutl_region *regions, const flutl_prim *prims,

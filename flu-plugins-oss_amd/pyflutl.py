@@ -52,6 +52,7 @@ EXPORTS = [
     "flutl_render_frame_rows_to_host", "flutl_render_frame_window_to_host",
     "flutl_atlas_put_blurred",
     "flutl_launch_delta", "flutl_launch_delta_window", "flutl_launch_frame_rows",
+    "flutl_launch_frame_over_rows", "flutl_blend_over_host",
     "flutl_frame_create", "flutl_frame_destroy", "flutl_frame_host",
     "flutl_frame_device", "flutl_frame_submit", "flutl_frame_wait", "flutl_ctx_delta_bytes",
 ]
@@ -112,6 +113,9 @@ def lib():
         L.flutl_launch_delta.argtypes = [vp, vp, vp, vp, u32, u32, u32, u32, vp]
         L.flutl_launch_delta_window.argtypes = [vp, vp, vp, vp, u32, u32, u32, u32, u32, u32, vp]
         L.flutl_launch_frame_rows.argtypes = [vp, u32, u32, vp, sz, vp, u32, vp, vp, u32, u32]
+        L.flutl_launch_frame_over_rows.argtypes = [vp, u32, u32, vp, vp, sz, vp, u32, vp, vp,
+                                                   u32, u32]
+        L.flutl_blend_over_host.argtypes = [vp, u32, u32, vp, u32, vp, u32, vp, sz]
         L.flutl_frame_create.argtypes = [vp, u32, u32, ctypes.POINTER(vp)]
         L.flutl_frame_destroy.argtypes = [vp]
         L.flutl_frame_destroy.restype = None
@@ -348,6 +352,15 @@ class Context:
 
     def sync(self):
         _check(lib().flutl_ctx_sync(self._h), "flutl_ctx_sync")
+
+    def blend_over_host(self, width, height, regions, prims, video):
+        """overlay OVER `video` (a C-contiguous (height, width) uint32 array), in place"""
+        regions = np.ascontiguousarray(regions, REGION_DTYPE)
+        prims = np.ascontiguousarray(prims, PRIM_DTYPE)
+        _check(lib().flutl_blend_over_host(self._h, width, height, _np_ptr(regions),
+                                           len(regions), _np_ptr(prims), len(prims),
+                                           _np_ptr(video), video.strides[0]),
+               "flutl_blend_over_host")
 
     def delta_bytes(self):
         return int(lib().flutl_ctx_delta_bytes(self._h))

@@ -170,6 +170,13 @@ int flutl_launch_batch_over (void *stream, uint32_t width, uint32_t height,
     const flutl_region *regions, const flutl_prim *prims,
     const uint8_t *atlas);
 
+/* One frame OVER one video frame, rows [row0, row1) only (whole supertiles): the
+ * launch behind the element's video_sink pad. */
+int flutl_launch_frame_over_rows (void *stream, uint32_t width, uint32_t height,
+    void *dst, const void *video, size_t stride_bytes,
+    const flutl_region *regions, uint32_t n_regions,
+    const flutl_prim *prims, const uint8_t *atlas, uint32_t row0, uint32_t row1);
+
 /* Gaussian blur of a premultiplied ARGB32 image with pixman's convolution
  * semantics: replaces gst_ttml_blur_image_surface (gstttmlblur.c:71-110).
  * `kernel_fixed` = (2r+1)^2 pixman 16.16 weights (device), as produced by
@@ -316,6 +323,19 @@ int  flutl_render_frame_window_to_host (flutl_ctx *ctx, uint32_t width, uint32_t
     const flutl_prim *prims, uint32_t n_prims,
     void *dst_host, size_t dst_stride_bytes,
     const uint32_t *row_bands, uint32_t n_bands, uint32_t col0, uint32_t col1);
+
+/* Fused over-video for a video frame in HOST memory (what the element's optional
+ * video_sink pad receives; the mixing the reference leaves to a downstream
+ * compositor, plugins/ttml/README.md:47-50): the display list is composited OVER
+ * the frame (pixman OVER of premultiplied pixels) and the result written back IN
+ * PLACE.  Only the rows the list's regions span travel: up, through the fused
+ * kernel, and back; a list without regions leaves the frame untouched and costs
+ * nothing.  Synchronous.  video_host: width x height BGRA/BGRx pixels (opaque),
+ * rows stride_bytes apart. */
+int  flutl_blend_over_host (flutl_ctx *ctx, uint32_t width, uint32_t height,
+    const flutl_region *regions, uint32_t n_regions,
+    const flutl_prim *prims, uint32_t n_prims,
+    void *video_host, size_t stride_bytes);
 
 /* ---- pooled output frames, completed asynchronously ----------------------
  * A flutl_frame is one output frame of the element: a page-locked host block

@@ -491,3 +491,23 @@ def test_row_window_launch_writes_only_its_supertile_rows(gpu, size, rows):
     y0, y1 = r0 // 16 * 16, min(H, (r1 + 15) // 16 * 16)
     assert np.array_equal(got[y0:y1], exp[y0:y1])
     assert (got[:y0] == 0xABABABAB).all() and (got[y1:] == 0xABABABAB).all()
+
+
+@pytest.mark.parametrize("size", [(320, 180), (333, 77), (1280, 720)])
+def test_blend_over_host_frame_in_place(gpu, size):
+    """flutl_blend_over_host (the element's video_sink path): overlay OVER a video
+    frame in host memory, in place == (oracle overlay) OVER video, pixman rule; rows
+    outside the regions are not touched; an empty list leaves the frame alone."""
+    W, H = size
+    R, P, A = scenes.random_scene(41, W, H, n_regions=3)
+    rng = np.random.default_rng(W)
+    video = (rng.integers(0, 1 << 24, (H, W), dtype=np.uint64).astype(np.uint32)) | 0xFF000000
+    exp = O.over(O.render(W, H, R, P, A).reshape(-1), video.reshape(-1)).reshape(H, W)
+    with F.Context(0) as ctx:
+        ctx.atlas_put(A[F.ATLAS_SLACK:])
+        got = video.copy()
+        ctx.blend_over_host(W, H, R, P, got)
+        assert np.array_equal(got, exp), int((got != exp).sum())
+        again = video.copy()
+        ctx.blend_over_host(W, H, R[:0], P[:0], again)
+        assert np.array_equal(again, video)
