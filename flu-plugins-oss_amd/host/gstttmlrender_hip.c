@@ -452,6 +452,16 @@ typedef struct
   guint in_flight;
   gint64 t_submit, t_flush, t_resolve;   /* (finisher's clocks, read when it is idle) */
   gint64 t_build, t_layout;  /* parts of t_record: spans -> regions, paragraphs -> layouts */
+  /* fused over-video: with the optional request pad "video_sink"
+   * linked, gen_buffer records cues instead of rendering frames, and every video
+   * buffer gets the cue of its time composited into it on the device */
+  GstPad *video_pad;
+  GstPadEventFunction ttml_event;   /* the base class's handler of the TTML pad */
+  GMutex video_lock, ctx_lock;      /* ctx_lock: the device, between the two streaming threads */
+  GCond video_cond;
+  gboolean video_have_caps, ttml_eos, video_flushing;
+  gint video_width, video_height;
+  GQueue cues;               /* VideoCue *, in time order */
   guint n_deferred;          /* buffers that went through the finisher */
   guint64 delta_reported;
 } GstTTMLRenderPrivate;
@@ -1327,6 +1337,8 @@ walk_layout (GstTTMLRender *render, FlutlRecorder *rec, PangoLayout *layout,
 static gboolean flush_atlas (GstTTMLRender *render);
 static gboolean ensure_ctx (GstTTMLRender *render);
 static void pipeline_drain (GstTTMLRender *render);
+static void video_cue_push (GstTTMLRender *render, GstClockTime ts, GstClockTime duration,
+    const flutl_region *rg, guint32 n_rg, const flutl_prim *pr, guint32 n_pr);
 
 /* Glyph / outline / blurred-image masks, host copy and HBM: everything that is
  * re-made on demand. */
@@ -1540,7 +1552,10 @@ outline_layout (GstTTMLRender *render, HipRegion *r, PangoLayout *layout)
   double keep[4];
 
   if (r->outline.length[1].unit != GST_TTML_LENGTH_UNIT_NOT_PRESENT) {
+    GstTTMLRenderPrivate *priv = get_priv (render);
+    g_mutex_lock (&priv->ctx_lock);     /* (the video side may be on the device) */
     blurred_outline (render, r, layout, c);
+    g_mutex_unlock (&priv->ctx_lock);
     return;
   }
   flutl_recorder_get_color (rec, keep);
@@ -1818,6 +1833,23 @@ pipeline_push (GstTTMLRender *render, gint width, gint height, const flutl_regio
   g_async_queue_push (priv->jobs, job);
 }
 
+/* a timeline interval recorded for the video side (fused over-video, below) */
+typedef struct
+{
+  GstClockTime start, end;
+  flutl_region *regions;
+  flutl_prim *prims;
+  guint32 n_rg, n_pr;
+} VideoCue;
+
+static void
+video_cue_free (VideoCue *c)
+{
+  g_free (c->regions);
+  g_free (c->prims);
+  g_free (c);
+}
+
 static GstBuffer *
 gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime duration)
 {
@@ -1832,6 +1864,15 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
   GstBuffer *buffer = NULL;
   gint64 t_start = 0, t_recorded = 0;
 
+  if (priv->video_pad) {
+    /* fused over-video: the frame is the video frame, whose size the video caps bring */
+    g_mutex_lock (&priv->video_lock);
+    while (!priv->video_have_caps && !priv->video_flushing)
+      g_cond_wait (&priv->video_cond, &priv->video_lock);
+    width = base->state.frame_width = priv->video_width;
+    height = base->state.frame_height = priv->video_height;
+    g_mutex_unlock (&priv->video_lock);
+  }
   GST_DEBUG_OBJECT (render, "buffer %" GST_TIME_FORMAT " + %" GST_TIME_FORMAT
       ", frame %dx%d", GST_TIME_ARGS (ts), GST_TIME_ARGS (duration), width, height);
   if (width <= 0 || height <= 0 || width > 32767 || height > 32767)
@@ -1847,7 +1888,8 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
     flutl_recorder_lock (rec);
     (void) flutl_recorder_atlas (rec, &atlas_bytes);
     flutl_recorder_unlock (rec);
-    if (atlas_bytes > priv->atlas_limit && !priv->dump) {   /* (a dump keeps one atlas) */
+    /* (a dump keeps one atlas; so do the cues queued for the video side) */
+    if (atlas_bytes > priv->atlas_limit && !priv->dump && !priv->video_pad) {
       GST_INFO_OBJECT (render, "atlas at %" G_GSIZE_FORMAT " bytes: dropping the mask caches",
           atlas_bytes);
       caches_drop (render);
@@ -1855,7 +1897,7 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
   }
   /* outlines without a mask yet are rasterised on worker threads and waited for
    * by the finisher, unless the frame is needed complete right here */
-  flutl_recorder_set_defer (rec, !priv->sync_mode && !priv->full_d2h &&
+  flutl_recorder_set_defer (rec, !priv->sync_mode && !priv->full_d2h && !priv->video_pad &&
       (!priv->dump || priv->dump_defer));
   flutl_recorder_begin_frame (rec, width, height);
   if (base->state.saved_region_attr_stacks) {
@@ -1902,6 +1944,11 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
     atlas = flutl_recorder_atlas (rec, &atlas_size);
     flutl_pack_writer_add (priv->dump, width, height, rg, n_rg, pr, n_pr, atlas,
         atlas_size);
+  }
+  if (priv->video_pad) {
+    /* fused over-video: this interval is a cue for the video side; no buffer */
+    video_cue_push (render, ts, duration, rg, n_rg, pr, n_pr);
+    return NULL;
   }
   if (priv->dump_only) {
     /* record-only test facility (no GPU needed): the base class must see a
@@ -2167,7 +2214,13 @@ gst_ttmlrender_reset (GstTTMLBase *base)
     g_hash_table_unref (priv->layouts);
     priv->layouts = NULL;
   }
-  caches_drop (render);
+  /* (fused over-video: the document's cues are still waiting for their video
+   * frames, and they name masks of the atlas) */
+  g_mutex_lock (&priv->video_lock);
+  const gboolean cues_waiting = priv->video_pad && !g_queue_is_empty (&priv->cues);
+  g_mutex_unlock (&priv->video_lock);
+  if (!cues_waiting)
+    caches_drop (render);
   if (priv->dump)
     flutl_pack_writer_flush (priv->dump);
 }
@@ -2201,6 +2254,11 @@ gst_ttmlrender_dispose (GObject *object)
     frame_pool_unref (priv->pool);
     priv->pool = NULL;
   }
+  {
+    VideoCue *c;
+    while ((c = g_queue_pop_head (&priv->cues)))
+      video_cue_free (c);
+  }
   if (priv->jobs) {
     g_async_queue_unref (priv->jobs);
     priv->jobs = NULL;
@@ -2215,6 +2273,212 @@ gst_ttmlrender_dispose (GObject *object)
     render->downloader = NULL;
   }
   G_OBJECT_CLASS (gst_ttmlrender_parent_class)->dispose (object);
+}
+
+/* ---- fused over-video: the optional request pad "video_sink"  -------
+ * The reference renders overlay frames and leaves the mixing with the video to a
+ * downstream compositor (plugins/ttml/README.md:47-50).  With FLUTL_VIDEO_PAD=1 in
+ * the environment the element class has one more pad template, a request sink
+ * pad for BGRA/BGRx video (an environment knob and not a property or an always
+ * pad, so that gst-inspect of the default configuration stays identical to the
+ * reference's).  When that pad is linked:
+ *   - the TTML side still runs the untouched base class, but gen_buffer RECORDS
+ *     each timeline interval as a cue (display list + time span) and pushes
+ *     nothing;
+ *   - every video buffer gets the cue covering its PTS composited into it by the
+ *     fused kernel (flutl_blend_over_host: only the rows the regions span cross
+ *     PCIe) and leaves on the src pad with the video's caps and timestamps.
+ * Frame size = video size: the TTML side waits for the video caps. */
+/* gen_buffer in video mode: the interval becomes a cue; nothing is pushed. */
+static void
+video_cue_push (GstTTMLRender *render, GstClockTime ts, GstClockTime duration,
+    const flutl_region *rg, guint32 n_rg, const flutl_prim *pr, guint32 n_pr)
+{
+  GstTTMLRenderPrivate *priv = get_priv (render);
+  VideoCue *c = g_new0 (VideoCue, 1);
+  c->start = ts;
+  c->end = GST_CLOCK_TIME_IS_VALID (duration) ? ts + duration : GST_CLOCK_TIME_NONE;
+  c->n_rg = n_rg;
+  c->n_pr = n_pr;
+  c->regions = g_memdup (rg, n_rg * sizeof *rg);
+  c->prims = g_memdup (pr, n_pr * sizeof *pr);
+  g_mutex_lock (&priv->video_lock);
+  g_queue_push_tail (&priv->cues, c);
+  g_cond_broadcast (&priv->video_cond);
+  g_mutex_unlock (&priv->video_lock);
+}
+
+static GstFlowReturn
+video_chain (GstPad *pad, GstObject *parent, GstBuffer *buffer)
+{
+  GstTTMLRender *render = GST_TTMLRENDER (parent);
+  GstTTMLRenderPrivate *priv = get_priv (render);
+  GstTTMLBase *base = GST_TTMLBASE (render);
+  const GstClockTime t = GST_BUFFER_PTS (buffer);
+  VideoCue *cue = NULL;
+  GstFlowReturn ret;
+
+  /* the cue of this frame's time: wait until the TTML side has got that far */
+  g_mutex_lock (&priv->video_lock);
+  for (;;) {
+    VideoCue *c;
+    while ((c = g_queue_peek_head (&priv->cues)) && GST_CLOCK_TIME_IS_VALID (c->end) &&
+        GST_CLOCK_TIME_IS_VALID (t) && c->end <= t)
+      video_cue_free (g_queue_pop_head (&priv->cues));      /* video time only moves on */
+    c = g_queue_peek_head (&priv->cues);
+    if (c && (!GST_CLOCK_TIME_IS_VALID (t) || c->start <= t)) {
+      cue = c;
+      break;
+    }
+    if (c || priv->ttml_eos || priv->video_flushing)
+      break;                    /* a gap before the next cue, or no more subtitles */
+    g_cond_wait (&priv->video_cond, &priv->video_lock);
+  }
+  if (priv->video_flushing) {
+    g_mutex_unlock (&priv->video_lock);
+    gst_buffer_unref (buffer);
+    return GST_FLOW_FLUSHING;
+  }
+  if (cue && cue->n_rg && !priv->dump_only) {   /* (record-only test facility: no device) */
+    GstMapInfo map;
+    int rc;
+    const gint w = priv->video_width, h = priv->video_height;
+    g_mutex_unlock (&priv->video_lock);         /* (the head cue stays: only this thread pops) */
+    buffer = gst_buffer_make_writable (buffer);
+    if (!gst_buffer_map (buffer, &map, GST_MAP_READWRITE) || map.size < (gsize) w * h * 4) {
+      GST_ELEMENT_ERROR (render, STREAM, FAILED, ("ttmlrender: cannot map the video frame"),
+          (NULL));
+      gst_buffer_unref (buffer);
+      return GST_FLOW_ERROR;
+    }
+    /* (the TTML thread uses the device too, for blurred outlines: ctx_lock) */
+    g_mutex_lock (&priv->ctx_lock);
+    rc = ensure_ctx (render) && flush_atlas (render) ? FLUTL_OK : FLUTL_ENODEV;
+    if (rc == FLUTL_OK)
+      rc = flutl_blend_over_host (priv->ctx, w, h, cue->regions, cue->n_rg, cue->prims,
+          cue->n_pr, map.data, (size_t) w * 4);
+    g_mutex_unlock (&priv->ctx_lock);
+    gst_buffer_unmap (buffer, &map);
+    if (rc != FLUTL_OK) {
+      GST_ELEMENT_ERROR (render, LIBRARY, FAILED, ("ttmlrender: HIP render failed"),
+          ("flutl_blend_over_host: %s", flutl_strerror (rc)));
+      gst_buffer_unref (buffer);
+      return GST_FLOW_ERROR;
+    }
+  } else {
+    g_mutex_unlock (&priv->video_lock);
+  }
+  ret = gst_pad_push (base->srcpad, buffer);
+  return ret;
+}
+
+static gboolean
+video_event (GstPad *pad, GstObject *parent, GstEvent *event)
+{
+  GstTTMLRender *render = GST_TTMLRENDER (parent);
+  GstTTMLRenderPrivate *priv = get_priv (render);
+  GstTTMLBase *base = GST_TTMLBASE (render);
+  switch (GST_EVENT_TYPE (event)) {
+    case GST_EVENT_CAPS: {
+      GstCaps *caps;
+      GstStructure *st;
+      gint w = 0, h = 0;
+      gst_event_parse_caps (event, &caps);
+      st = gst_caps_get_structure (caps, 0);
+      gst_structure_get_int (st, "width", &w);
+      gst_structure_get_int (st, "height", &h);
+      if (w <= 0 || h <= 0 || w > 32767 || h > 32767) {
+        gst_event_unref (event);
+        return FALSE;
+      }
+      /* the video's caps are the output's; the TTML frame is the video frame */
+      g_mutex_lock (&priv->video_lock);
+      priv->video_width = w;
+      priv->video_height = h;
+      base->state.frame_width = w;
+      base->state.frame_height = h;
+      priv->video_have_caps = TRUE;
+      g_cond_broadcast (&priv->video_cond);
+      g_mutex_unlock (&priv->video_lock);
+      return gst_pad_push_event (base->srcpad, event);
+    }
+    case GST_EVENT_FLUSH_START:
+      g_mutex_lock (&priv->video_lock);
+      priv->video_flushing = TRUE;
+      g_cond_broadcast (&priv->video_cond);
+      g_mutex_unlock (&priv->video_lock);
+      break;
+    case GST_EVENT_FLUSH_STOP:
+      g_mutex_lock (&priv->video_lock);
+      priv->video_flushing = FALSE;
+      g_mutex_unlock (&priv->video_lock);
+      break;
+    default:
+      break;
+  }
+  /* stream-start, segment, tags, EOS ...: the output stream is the video stream */
+  return gst_pad_push_event (base->srcpad, event);
+}
+
+/* The TTML pad's events in video mode: what would announce or end a stream
+ * downstream is not forwarded (the video side does that); everything else goes
+ * to the base class's handler. */
+static gboolean
+ttml_event_in_video_mode (GstPad *pad, GstObject *parent, GstEvent *event)
+{
+  GstTTMLRender *render = GST_TTMLRENDER (parent);
+  GstTTMLRenderPrivate *priv = get_priv (render);
+  if (priv->video_pad) {
+    switch (GST_EVENT_TYPE (event)) {
+      case GST_EVENT_EOS:
+        g_mutex_lock (&priv->video_lock);
+        priv->ttml_eos = TRUE;
+        g_cond_broadcast (&priv->video_cond);
+        g_mutex_unlock (&priv->video_lock);
+        gst_event_unref (event);
+        return TRUE;
+      case GST_EVENT_STREAM_START:
+      case GST_EVENT_TAG:
+        gst_event_unref (event);
+        return TRUE;
+      default:
+        break;
+    }
+  }
+  return priv->ttml_event (pad, parent, event);
+}
+
+static GstPad *
+gst_ttmlrender_request_new_pad (GstElement *element, GstPadTemplate *templ,
+    const gchar *name, const GstCaps *caps)
+{
+  GstTTMLRender *render = GST_TTMLRENDER (element);
+  GstTTMLRenderPrivate *priv = get_priv (render);
+  GstPad *pad;
+  if (priv->video_pad || g_strcmp0 (GST_PAD_TEMPLATE_NAME_TEMPLATE (templ), "video_sink"))
+    return NULL;
+  pad = gst_pad_new_from_template (templ, "video_sink");
+  gst_pad_set_chain_function (pad, GST_DEBUG_FUNCPTR (video_chain));
+  gst_pad_set_event_function (pad, GST_DEBUG_FUNCPTR (video_event));
+  priv->video_pad = pad;
+  gst_pad_set_active (pad, TRUE);
+  gst_element_add_pad (element, pad);
+  return pad;
+}
+
+static void
+gst_ttmlrender_release_pad (GstElement *element, GstPad *pad)
+{
+  GstTTMLRenderPrivate *priv = get_priv (GST_TTMLRENDER (element));
+  if (pad != priv->video_pad)
+    return;
+  g_mutex_lock (&priv->video_lock);
+  priv->video_flushing = TRUE;
+  g_cond_broadcast (&priv->video_cond);
+  g_mutex_unlock (&priv->video_lock);
+  gst_pad_set_active (pad, FALSE);
+  gst_element_remove_pad (element, pad);
+  priv->video_pad = NULL;
 }
 
 static void
@@ -2260,6 +2524,17 @@ gst_ttmlrender_class_init (GstTTMLRenderClass *klass)
       "Codec/Decoder/Subtitle",
       "Render TTML subtitle streams into a video stream (MI355X / HIP compositor)",
       "fluttml-hip");
+
+  if (g_getenv ("FLUTL_VIDEO_PAD")) {
+    static GstStaticPadTemplate video_template =
+        GST_STATIC_PAD_TEMPLATE ("video_sink", GST_PAD_SINK, GST_PAD_REQUEST,
+            GST_STATIC_CAPS ("video/x-raw, format=(string){ BGRA, BGRx }, "
+                "width=(int)[1,32767], height=(int)[1,32767]"));
+    gst_element_class_add_pad_template (element_class,
+        gst_static_pad_template_get (&video_template));
+    element_class->request_new_pad = gst_ttmlrender_request_new_pad;
+    element_class->release_pad = gst_ttmlrender_release_pad;
+  }
 
   base_class->gen_buffer = gst_ttmlrender_gen_buffer;
   base_class->fixate_caps = gst_ttmlrender_fixate_caps;
@@ -2313,6 +2588,13 @@ gst_ttmlrender_init (GstTTMLRender *render)
   if (g_getenv ("FLUTL_ATLAS_LIMIT_BYTES"))     /* tests: force the start-over path */
     priv->atlas_limit = (gsize) g_ascii_strtoull (g_getenv ("FLUTL_ATLAS_LIMIT_BYTES"), NULL, 10);
   priv->overlay_meta = g_getenv ("FLUTL_OVERLAY_COMPOSITION") != NULL;
+  g_mutex_init (&priv->video_lock);
+  g_mutex_init (&priv->ctx_lock);
+  g_cond_init (&priv->video_cond);
+  g_queue_init (&priv->cues);
+  /* (the base class has installed its handler on the TTML pad by now) */
+  priv->ttml_event = GST_PAD_EVENTFUNC (render->base.sinkpad);
+  gst_pad_set_event_function (render->base.sinkpad, ttml_event_in_video_mode);
   priv->sync_mode = g_getenv ("FLUTL_SYNC") != NULL;
   priv->pool_prefill = g_getenv ("FLUTL_POOL_PREFILL")
       ? (guint) CLAMP (atoi (g_getenv ("FLUTL_POOL_PREFILL")), 0, POOL_MAX_FREE) : 8;

@@ -65,3 +65,29 @@ def test_plugin_registers_all_three_elements():
     out = inspect(gstenv.HIP_PLUGIN_DIR, "fluttml")
     for el in ("ttmlparse", "ttmlsegmentedparse", "ttmlrender"):
         assert el in out
+
+
+@need
+def test_video_pad_knob_adds_one_request_template_and_nothing_else():
+    """FLUTL_VIDEO_PAD=1 (fused over-video) adds the request sink pad
+    'video_sink'; properties, the always pads and everything else stay the
+    reference's.  Without the knob the pad templates are identical (test above)."""
+    r = subprocess.run([os.path.join(gstenv.CONDA, "bin", "gst-inspect-1.0"), "ttmlrender"],
+                       env=gstenv.env_for(gstenv.HIP_PLUGIN_DIR, {"FLUTL_VIDEO_PAD": "1"}),
+                       capture_output=True, text=True, cwd="/tmp")
+    assert r.returncode == 0, r.stderr
+    hip, ref = r.stdout, inspect(gstenv.REF_PLUGIN_DIR)
+    assert "SINK template: 'video_sink'" in hip and "On request" in hip
+    assert section(ref, "Element Properties:") == section(hip, "Element Properties:")
+    assert "SINK template: 'sink'" in hip and "SRC template: 'src'" in hip
+
+
+@pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
+                    reason="fluttml-hip plugin / GStreamer runtime not present")
+def test_video_pad_dataflow_without_a_device():
+    """The plumbing of the fused mode on CPU (record-only: cues are made, frames pass
+    through): every video frame comes out once, in order, and the pipeline ends."""
+    ttml = os.path.join(ROOT, "tests", "golden", "scenes", "k06_animation.ttml")
+    v, o = gstenv.render_over_video(ttml, 320, 180, 9, 3, extra_env={
+        "FLUTL_DUMP_ONLY": "1", "FLUTL_DUMP_PACK": os.devnull})
+    assert len(v) == 9 * 320 * 180 * 4 and v == o

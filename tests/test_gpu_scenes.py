@@ -114,3 +114,35 @@ def test_element_renders_embedded_images_and_exits_cleanly(gpu):
         ROOT, "tests", "golden", "variants", "k08_images_embedded.ttml"), W, H)
     got = np.frombuffer(raw, np.uint32).reshape(-1, H, W)
     assert np.array_equal(got, z["frames"])
+
+
+@pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
+                    reason="fluttml-hip plugin / GStreamer runtime not present")
+@pytest.mark.parametrize("name", ["k06_animation", "k02_opacity_zorder", "k08_images",
+                                  "g01_blur_outline"])
+def test_element_fused_over_video_through_its_request_pad(gpu, name):
+    """videotestsrc ! r.video_sink  filesrc ! ttmlrender name=r ! filesink
+    (FLUTL_VIDEO_PAD=1).  Every output frame must be the REFERENCE's overlay frame of
+    that time composited OVER the video frame with pixman's rule -- what the
+    reference's README pipeline gets from a compositor after ttmlrender
+    (plugins/ttml/README.md:47-50)."""
+    import oracle_lib as O
+    path = [s for s in SCENES if name in s][0]
+    z = np.load(path)
+    W, H = int(z["width"]), int(z["height"])
+    ttml = path[:-4] + ".ttml"
+    fps, n = 4, 15
+    vraw, oraw = gstenv.render_over_video(ttml, W, H, n, fps, pattern="smpte")
+    video = np.frombuffer(vraw, np.uint32).reshape(n, H, W)
+    out = np.frombuffer(oraw, np.uint32).reshape(n, H, W)
+    assert (video >> 24 == 255).all()
+    times = gstenv.buffer_times(gstenv.HIP_PLUGIN_DIR, ttml, W, H)
+    assert len(times) == int(z["n_states"])
+    for k in range(n):
+        t = k * 10**9 // fps
+        state = [i for i, (p, d) in enumerate(times) if p <= t and (d is None or t < p + d)]
+        if state:
+            exp = O.over(z["frames"][state[0]].reshape(-1), video[k].reshape(-1)).reshape(H, W)
+        else:
+            exp = video[k]
+        assert np.array_equal(out[k], exp), (k, state, int((out[k] != exp).sum()))

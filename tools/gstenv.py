@@ -21,8 +21,10 @@ def env_for(plugin_dir, extra=None):
     stamp = int(os.path.getmtime(so)) if os.path.exists(so) else 0
     # one registry per plugin build: a stale registry would keep a plugin that
     # once failed to load blacklisted
-    reg = os.path.join(tempfile.gettempdir(), "flutl-gst-registry-%s-%d-%d.bin" % (
-        os.path.basename(os.path.dirname(plugin_dir + "/")), os.getuid(), stamp))
+    # (FLUTL_VIDEO_PAD changes the element's pad templates, which the registry caches)
+    vp = "v" if (e.get("FLUTL_VIDEO_PAD") or (extra or {}).get("FLUTL_VIDEO_PAD")) else ""
+    reg = os.path.join(tempfile.gettempdir(), "flutl-gst-registry-%s-%d-%d%s.bin" % (
+        os.path.basename(os.path.dirname(plugin_dir + "/")), os.getuid(), stamp, vp))
     e.update({
         "GST_PLUGIN_SYSTEM_PATH_1_0": os.path.join(CONDA, "lib", "gstreamer-1.0"),
         "GST_PLUGIN_PATH_1_0": plugin_dir,
@@ -89,3 +91,52 @@ def dump_pack(ttml_path, width, height, pack_path, record_only=True, extra_env=N
     env.update(extra_env or {})
     render(HIP_PLUGIN_DIR, ttml_path, width, height, sink="fakesink", extra_env=env)
     return pack_path
+
+
+def render_over_video(ttml_path, width, height, n_frames, fps, pattern="smpte",
+                      extra_env=None):
+    """The element's fused over-video mode (FLUTL_VIDEO_PAD=1, request pad video_sink):
+        videotestsrc ! BGRA caps ! r.video_sink   filesrc ! ttmlrender name=r ! filesink
+    Returns (video frames as produced by videotestsrc alone, output frames), raw bytes."""
+    outs = []
+    vcaps = (f"video/x-raw,format=BGRA,width={width},height={height},framerate={fps}/1")
+    for with_subs in (False, True):
+        tmp = tempfile.NamedTemporaryFile(suffix=".raw", delete=False)
+        tmp.close()
+        src = ["videotestsrc", f"num-buffers={n_frames}", f"pattern={pattern}", "!", vcaps, "!"]
+        if with_subs:
+            cmd = src + ["r.video_sink", "filesrc", f"location={os.path.abspath(ttml_path)}", "!",
+                         "ttmlrender", "name=r", "!", "filesink", f"location={tmp.name}"]
+        else:
+            cmd = src + ["filesink", f"location={tmp.name}"]
+        env = dict(extra_env or {})
+        env["FLUTL_VIDEO_PAD"] = "1"
+        r = subprocess.run([os.path.join(CONDA, "bin", "gst-launch-1.0"), "-q", "--no-fault"] + cmd,
+                           env=env_for(HIP_PLUGIN_DIR, env), capture_output=True, text=True,
+                           cwd=tempfile.gettempdir(), timeout=300)
+        if r.returncode != 0:
+            raise RuntimeError(f"gst-launch failed (rc {r.returncode}): {r.stdout}\n{r.stderr}")
+        outs.append(open(tmp.name, "rb").read())
+        os.unlink(tmp.name)
+    return outs[0], outs[1]
+
+
+def buffer_times(plugin_dir, ttml_path, width, height):
+    """[(pts_ns, duration_ns)] of the buffers ttmlrender pushes for a document
+    (fakesink silent=false -v); an open-ended last buffer has duration None."""
+    import re
+    cmd = [os.path.join(CONDA, "bin", "gst-launch-1.0"), "-v", "filesrc",
+           f"location={os.path.abspath(ttml_path)}", "!", "ttmlrender", "!",
+           f"video/x-raw,width={width},height={height}", "!", "fakesink", "silent=false"]
+    r = subprocess.run(cmd, env=env_for(plugin_dir, {"FLUTL_DUMP_ONLY": "1",
+                                                     "FLUTL_DUMP_PACK": os.devnull}),
+                       capture_output=True, text=True, cwd=tempfile.gettempdir())
+
+    def ns(t):
+        h, m, sec = t.split(":")
+        return (int(h) * 3600 + int(m) * 60) * 10**9 + int(round(float(sec) * 1e9))
+    out = []
+    for m in re.finditer(r"chain .*?pts: ([0-9:.]+), duration: ([0-9:.]+)", r.stdout):
+        d = ns(m.group(2))
+        out.append((ns(m.group(1)), d if d < 10**15 else None))
+    return out
