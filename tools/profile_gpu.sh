@@ -10,11 +10,11 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- \
-  python3 "$ROOT/bench.py" --no-cpu-baseline "$@" > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
+  python3 "$ROOT/bench.py" --no-cpu-baseline --no-e2e "$@" > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- \
-  python3 "$ROOT/bench.py" --no-cpu-baseline --steps 40 --warmup 10 "$@" > /dev/null 2> "$OUT/pmc_write.err"
+  python3 "$ROOT/bench.py" --no-cpu-baseline --no-e2e --steps 40 --warmup 10 "$@" > /dev/null 2> "$OUT/pmc_write.err"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- \
-  python3 "$ROOT/bench.py" --no-cpu-baseline --steps 40 --warmup 10 "$@" > /dev/null 2> "$OUT/pmc_fetch.err"
+  python3 "$ROOT/bench.py" --no-cpu-baseline --no-e2e --steps 40 --warmup 10 "$@" > /dev/null 2> "$OUT/pmc_fetch.err"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --output-format csv -d "$OUT/pmc_sq" -- \
-  python3 "$ROOT/bench.py" --no-cpu-baseline --steps 40 --warmup 10 "$@" > /dev/null 2> "$OUT/pmc_sq.err"
+  python3 "$ROOT/bench.py" --no-cpu-baseline --no-e2e --steps 40 --warmup 10 "$@" > /dev/null 2> "$OUT/pmc_sq.err"
 echo "profile $TAG done"
