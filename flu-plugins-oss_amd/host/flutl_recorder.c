@@ -2429,6 +2429,65 @@ flutl_recorder_paint_image (FlutlRecorder *rec, cairo_surface_t *img, int x, int
   p->d = y;
 }
 
+/* ---- region replay (the element's region cache) --------------------------------
+ * A region whose inputs have not changed since an earlier buffer records the
+ * same primitives: the element keeps them and plays them back instead of walking
+ * the layouts again.  mark: where the next region's output will start; snapshot:
+ * what a region recorded since its mark (prims, its region record if it got one,
+ * whether a placeholder is among them -- then it is not final); replay: append a
+ * snapshot as this frame's next region. */
+void
+flutl_recorder_mark (FlutlRecorder *rec, uint32_t *prim_mark, uint32_t *region_mark)
+{
+  *prim_mark = rec->n_prims;
+  *region_mark = rec->n_regions;
+}
+
+int
+flutl_recorder_frame_is_clear (FlutlRecorder *rec)
+{
+  return rec->frame_clear;
+}
+
+const flutl_prim *
+flutl_recorder_snapshot (FlutlRecorder *rec, uint32_t prim_mark, uint32_t region_mark,
+    uint32_t *n_prims, const flutl_region **region, int *has_placeholder)
+{
+  *n_prims = rec->n_prims - prim_mark;
+  *region = rec->n_regions > region_mark ? &rec->regions[region_mark] : NULL;
+  *has_placeholder = 0;
+  for (uint32_t k = 0; k < rec->n_patches; k++)
+    if (rec->patches[k].prim >= prim_mark)
+      *has_placeholder = 1;
+  return rec->prims + prim_mark;
+}
+
+void
+flutl_recorder_replay (FlutlRecorder *rec, const flutl_prim *prims, uint32_t n_prims,
+    const flutl_region *region, int frame_clear_after, uint32_t unsupported)
+{
+  const uint32_t first = rec->n_prims;
+  if (rec->n_prims + n_prims > rec->cap_prims) {
+    while (rec->n_prims + n_prims > rec->cap_prims)
+      rec->cap_prims = rec->cap_prims ? rec->cap_prims * 2 : 256;
+    rec->prims = xrealloc (rec->prims, rec->cap_prims * sizeof (flutl_prim));
+  }
+  memcpy (rec->prims + first, prims, n_prims * sizeof (flutl_prim));
+  rec->n_prims += n_prims;
+  if (region) {
+    if (rec->n_regions == rec->cap_regions) {
+      rec->cap_regions = rec->cap_regions ? rec->cap_regions * 2 : 32;
+      rec->regions = xrealloc (rec->regions, rec->cap_regions * sizeof (flutl_region));
+    }
+    flutl_region *r = &rec->regions[rec->n_regions++];
+    *r = *region;
+    r->first = first;
+    r->count = n_prims;
+  }
+  rec->frame_clear = frame_clear_after;
+  rec->unsupported += unsupported;
+}
+
 /* ---- results ---------------------------------------------------------------- */
 
 const flutl_region *

@@ -117,6 +117,15 @@ uint32_t flutl_recorder_new_atlas_entries (FlutlRecorder *rec,
 /* number of primitives dropped because a feature is not implemented yet */
 uint32_t flutl_recorder_unsupported (FlutlRecorder *rec);
 
+/* ---- region replay (flutl_recorder.c, "region replay") ------------------------- */
+void flutl_recorder_mark (FlutlRecorder *rec, uint32_t *prim_mark, uint32_t *region_mark);
+int flutl_recorder_frame_is_clear (FlutlRecorder *rec);
+const flutl_prim *flutl_recorder_snapshot (FlutlRecorder *rec, uint32_t prim_mark,
+    uint32_t region_mark, uint32_t *n_prims, const flutl_region **region,
+    int *has_placeholder);
+void flutl_recorder_replay (FlutlRecorder *rec, const flutl_prim *prims, uint32_t n_prims,
+    const flutl_region *region, int frame_clear_after, uint32_t unsupported);
+
 /* ---- deferred strokes (flutl_recorder.c, "deferred strokes") -----------------
  * With set_defer (root recorders only) a stroke the cache has no mask for is
  * prepared on the calling thread and rasterised on a worker thread; the frame's

@@ -438,6 +438,9 @@ typedef struct
   GHashTable *images;        /* id -> cairo_surface_t (decoded PNGs) */
   GHashTable *layouts;       /* layout cache: key string -> PangoLayout, per document */
   gboolean no_layout_cache;  /* FLUTL_NO_LAYOUT_CACHE=1 */
+  GPtrArray *region_cache;   /* RegionEntry *: recorded regions by what determines them */
+  gboolean no_region_cache;  /* FLUTL_NO_REGION_CACHE=1 */
+  guint region_hits, region_misses;
   guint skipped;             /* outlines of this buffer that could not be drawn */
   /* the finisher: buffers are handed out when their list is recorded; this thread
    * waits for the outline masks still being rasterised (flutl_recorder_resolve),
@@ -1347,6 +1350,8 @@ caches_drop (GstTTMLRender *render)
 {
   GstTTMLRenderPrivate *priv = get_priv (render);
   pipeline_drain (render);      /* no frame may still want a mask or the device */
+  if (priv->region_cache)       /* (its primitives name atlas offsets) */
+    g_ptr_array_set_size (priv->region_cache, 0);
   if (priv->rec)
     flutl_recorder_reset (priv->rec);
   if (priv->sub)
@@ -1570,20 +1575,12 @@ outline_layout (GstTTMLRender *render, HipRegion *r, PangoLayout *layout)
 
 /* One region -> one binning group (reference :1235-1385). */
 static void
-record_region (HipRegion *r, GstTTMLRender *render)
+record_region_body (HipRegion *r, GstTTMLRender *render)
 {
   FlutlRecorder *rec = get_priv (render)->rec;
   cairo_t *cr = flutl_recorder_cairo (rec);
   gboolean grouped = r->opacity < 1.0;
   GList *l;
-
-  if (r->par) {
-    GstTTMLRenderPrivate *priv = get_priv (render);
-    gint64 t0 = priv->timing ? g_get_monotonic_time () : 0;
-    region_flush_paragraph (render, r);
-    if (priv->timing && priv->n_timed)
-      priv->t_layout += g_get_monotonic_time () - t0;
-  }
 
   flutl_recorder_region_begin (rec);
   cairo_save (cr);
@@ -1659,6 +1656,166 @@ record_region (HipRegion *r, GstTTMLRender *render)
   flutl_recorder_clip_reset (rec);
   cairo_restore (cr);
   flutl_recorder_region_end (rec);
+}
+
+
+/* ---- region cache (display lists across buffers) --------------------
+ * The reference re-draws every region for every buffer (gstttmlrender.c:1462-1472),
+ * although consecutive scene states mostly differ in one attribute of one region.
+ * What a region records is a function of: its geometry and styling, its layouts
+ * (shared objects of the layout cache: the same pointer is the same text, fonts,
+ * colours and wrapping), the frame size and whether the frame was still "clear"
+ * for Cairo when the region began.  Regions are kept under that key with the
+ * primitives they recorded, and played back.  Per document and atlas generation
+ * (primitives name atlas offsets). */
+typedef struct
+{
+  gint geo[8];
+  guint32 bg;
+  gdouble opacity;
+  gpointer image;
+  gint image_xy[2];
+  gint display_align, overflow_visible, writing_mode;
+  guint32 outline_color;
+  gint outline_current;
+  gfloat outline_len[2];
+  gint outline_unit[2];
+  gint frame_w, frame_h, clear_in;
+  guint n_layouts;
+} RegionKey;
+
+typedef struct
+{
+  RegionKey key;
+  PangoLayout **layouts;        /* referenced */
+  guint64 hash;
+  flutl_prim *prims;
+  guint32 n_prims;
+  gboolean has_region;
+  flutl_region region;
+  gint clear_out;
+  guint32 unsupported;
+} RegionEntry;
+
+static void
+region_entry_free (gpointer data)
+{
+  RegionEntry *e = data;
+  for (guint i = 0; i < e->key.n_layouts; i++)
+    g_object_unref (e->layouts[i]);
+  g_free (e->layouts);
+  g_free (e->prims);
+  g_free (e);
+}
+
+static void
+region_key_fill (RegionKey *k, const HipRegion *r, FlutlRecorder *rec, gint w, gint h)
+{
+  memset (k, 0, sizeof *k);      /* (padding too: keys are compared as bytes) */
+  k->geo[0] = r->ox; k->geo[1] = r->oy; k->geo[2] = r->ex; k->geo[3] = r->ey;
+  k->geo[4] = r->pox; k->geo[5] = r->poy; k->geo[6] = r->pex; k->geo[7] = r->pey;
+  k->bg = r->bg;
+  k->opacity = r->opacity;
+  k->image = r->image;
+  k->image_xy[0] = r->image_x;
+  k->image_xy[1] = r->image_y;
+  k->display_align = r->display_align;
+  k->overflow_visible = r->overflow_visible;
+  k->writing_mode = r->writing_mode;
+  k->outline_color = r->outline.color;
+  k->outline_current = r->outline.use_current_color;
+  for (int i = 0; i < 2; i++) {
+    k->outline_unit[i] = r->outline.length[i].unit;
+    k->outline_len[i] = r->outline.length[i].unit == GST_TTML_LENGTH_UNIT_NOT_PRESENT
+        ? 0.f : r->outline.length[i].f;
+  }
+  k->frame_w = w;
+  k->frame_h = h;
+  k->clear_in = flutl_recorder_frame_is_clear (rec);
+  k->n_layouts = g_list_length (r->layouts);
+}
+
+static void
+record_region (HipRegion *r, GstTTMLRender *render)
+{
+  GstTTMLRenderPrivate *priv = get_priv (render);
+  FlutlRecorder *rec = priv->rec;
+  RegionKey key;
+  RegionEntry *e;
+  guint64 hash = 0xcbf29ce484222325ull;
+  guint32 prim_mark, region_mark, n_prims, unsupported_before;
+  const flutl_region *region;
+  const flutl_prim *prims;
+  int has_placeholder;
+  guint skipped_before, i;
+  GList *l;
+
+  if (r->par) {
+    gint64 t0 = priv->timing ? g_get_monotonic_time () : 0;
+    region_flush_paragraph (render, r);
+    if (priv->timing && priv->n_timed)
+      priv->t_layout += g_get_monotonic_time () - t0;
+  }
+  if (priv->no_region_cache) {
+    record_region_body (r, render);
+    return;
+  }
+  region_key_fill (&key, r, rec, render->base.state.frame_width,
+      render->base.state.frame_height);
+  for (i = 0; i < sizeof key / sizeof (guint32); i++)
+    hash = (hash ^ ((const guint32 *) &key)[i]) * 0x100000001b3ull;
+  for (l = r->layouts; l; l = l->next)
+    hash = (hash ^ (guint64) (guintptr) l->data) * 0x100000001b3ull;
+  if (!priv->region_cache)
+    priv->region_cache = g_ptr_array_new_with_free_func (region_entry_free);
+  for (i = 0; i < priv->region_cache->len; i++) {
+    e = g_ptr_array_index (priv->region_cache, i);
+    if (e->hash != hash || memcmp (&e->key, &key, sizeof key) != 0)
+      continue;
+    guint k = 0;
+    for (l = r->layouts; l && e->layouts[k] == l->data; l = l->next)
+      k++;
+    if (l)
+      continue;
+    /* the same region as before: its primitives, and what recording it does to
+     * the shared Pango context (the reference switches it to east gravity for the
+     * vertical writing modes and never back, :1313-1340) */
+    if (r->writing_mode == GST_TTML_WRITING_MODE_TBRL ||
+        r->writing_mode == GST_TTML_WRITING_MODE_TBLR) {
+      pango_context_set_base_gravity (render->pango_context, PANGO_GRAVITY_EAST);
+      pango_context_set_gravity_hint (render->pango_context, PANGO_GRAVITY_HINT_STRONG);
+      pango_cairo_update_context (flutl_recorder_cairo (rec), render->pango_context);
+    }
+    flutl_recorder_replay (rec, e->prims, e->n_prims, e->has_region ? &e->region : NULL,
+        e->clear_out, e->unsupported);
+    priv->region_hits++;
+    return;
+  }
+  priv->region_misses++;
+  flutl_recorder_mark (rec, &prim_mark, &region_mark);
+  unsupported_before = flutl_recorder_unsupported (rec);
+  skipped_before = priv->skipped;
+  record_region_body (r, render);
+  prims = flutl_recorder_snapshot (rec, prim_mark, region_mark, &n_prims, &region,
+      &has_placeholder);
+  if (has_placeholder || priv->skipped != skipped_before)
+    return;                     /* not final yet (a mask is still being made), or failed */
+  if (priv->region_cache->len >= 256)           /* bound it: start over */
+    g_ptr_array_set_size (priv->region_cache, 0);
+  e = g_new0 (RegionEntry, 1);
+  e->key = key;
+  e->hash = hash;
+  e->layouts = g_new (PangoLayout *, key.n_layouts + 1);
+  for (l = r->layouts, i = 0; l; l = l->next)
+    e->layouts[i++] = g_object_ref (l->data);
+  e->prims = g_memdup (prims, n_prims * sizeof *prims);
+  e->n_prims = n_prims;
+  e->has_region = region != NULL;
+  if (region)
+    e->region = *region;
+  e->clear_out = flutl_recorder_frame_is_clear (rec);
+  e->unsupported = flutl_recorder_unsupported (rec) - unsupported_before;
+  g_ptr_array_add (priv->region_cache, e);
 }
 
 /* ---- device side -------------------------------------------------------------- */
@@ -1921,6 +2078,7 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
 
   rg = flutl_recorder_regions (rec, &n_rg);
   pr = flutl_recorder_prims (rec, &n_pr);
+  t_recorded = priv->timing ? g_get_monotonic_time () : 0;
   if (flutl_recorder_unsupported (rec) || priv->skipped) {
     /* never push a frame that differs from the reference's: no buffer at all
      * (the base class's error convention, gstttmlbase.c:161-163) */
@@ -1958,7 +2116,7 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
       if (priv->n_timed++ == 0)
         priv->t_first_return = t;
       else
-        priv->t_record += t - t_start;
+        priv->t_record += t_recorded - t_start;      /* (without writing the dump) */
       priv->t_last_return = t;
     }
     buffer = gst_buffer_new_and_alloc ((gsize) width * height * 4);
@@ -1969,7 +2127,6 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
   /* ---- device: display list -> frame ------------------------------------- */
   if (!ensure_ctx (render))
     return NULL;
-  t_recorded = priv->timing ? g_get_monotonic_time () : 0;
   {
     GstMapInfo map;
     const gsize size = (gsize) width * height * 4;
@@ -2183,7 +2340,7 @@ timing_report (GstTTMLRender *render)
   }
   g_printerr ("ttmlrender-hip timing: buffers=%u record_us=%.1f device_us=%.1f "
       "span_us=%" G_GINT64_FORMAT " drained_us=%" G_GINT64_FORMAT " delta_bytes=%.0f "
-      "deferred=%u resolve_wait_us=%.1f atlas_upload_us=%.1f build_us=%.1f layout_us=%.1f\n",
+      "deferred=%u resolve_wait_us=%.1f atlas_upload_us=%.1f build_us=%.1f layout_us=%.1f region_hits=%u region_misses=%u\n",
       priv->n_timed, (double) priv->t_record / MAX (priv->n_timed - 1, 1),
       (double) (priv->t_device + priv->t_submit) / MAX (priv->n_timed - 1, 1),
       priv->t_last_return - priv->t_first_return,
@@ -2192,7 +2349,9 @@ timing_report (GstTTMLRender *render)
       (double) priv->t_resolve / MAX (priv->n_deferred, 1),
       (double) priv->t_flush / MAX (priv->n_deferred, 1),
       (double) priv->t_build / MAX (priv->n_timed - 1, 1),
-      (double) priv->t_layout / MAX (priv->n_timed - 1, 1));
+      (double) priv->t_layout / MAX (priv->n_timed - 1, 1), priv->region_hits,
+      priv->region_misses);
+  priv->region_hits = priv->region_misses = 0;
   priv->n_timed = priv->n_deferred = 0;
   priv->t_record = priv->t_device = priv->t_submit = priv->t_flush = priv->t_resolve = 0;
   priv->t_build = priv->t_layout = 0;
@@ -2214,6 +2373,8 @@ gst_ttmlrender_reset (GstTTMLBase *base)
     g_hash_table_unref (priv->layouts);
     priv->layouts = NULL;
   }
+  if (priv->region_cache)       /* (keyed on layouts and decoded images of the document) */
+    g_ptr_array_set_size (priv->region_cache, 0);
   /* (fused over-video: the document's cues are still waiting for their video
    * frames, and they name masks of the atlas) */
   g_mutex_lock (&priv->video_lock);
@@ -2258,6 +2419,10 @@ gst_ttmlrender_dispose (GObject *object)
     VideoCue *c;
     while ((c = g_queue_pop_head (&priv->cues)))
       video_cue_free (c);
+  }
+  if (priv->region_cache) {
+    g_ptr_array_unref (priv->region_cache);
+    priv->region_cache = NULL;
   }
   if (priv->jobs) {
     g_async_queue_unref (priv->jobs);
@@ -2391,12 +2556,15 @@ video_event (GstPad *pad, GstObject *parent, GstEvent *event)
         gst_event_unref (event);
         return FALSE;
       }
-      /* the video's caps are the output's; the TTML frame is the video frame */
+      /* the video's caps are the output's; the TTML frame is the video frame.
+       * (base->state.frame_* is NOT set here but by the first gen_buffer, as in
+       * the stand-alone element: the base class normalises a length differently
+       * when the frame size is already known while it parses -- fontSize="1c"
+       * becomes a cell WIDTH then, gstttmlattribute.c:702-704 -- and the parser
+       * runs on the other thread) */
       g_mutex_lock (&priv->video_lock);
       priv->video_width = w;
       priv->video_height = h;
-      base->state.frame_width = w;
-      base->state.frame_height = h;
       priv->video_have_caps = TRUE;
       g_cond_broadcast (&priv->video_cond);
       g_mutex_unlock (&priv->video_lock);
@@ -2602,4 +2770,5 @@ gst_ttmlrender_init (GstTTMLRender *render)
   g_mutex_init (&priv->flight_lock);
   g_cond_init (&priv->flight_cond);
   priv->no_layout_cache = g_getenv ("FLUTL_NO_LAYOUT_CACHE") != NULL;
+  priv->no_region_cache = g_getenv ("FLUTL_NO_REGION_CACHE") != NULL;
 }
