@@ -82,8 +82,8 @@ enum
  * A HIP-aware consumer finds the device address of the twin as qdata
  * "flutl-hip-device-frame" on the memory (valid once the memory has been mapped).
  * FLUTL_FULL_D2H=1 restores synchronous whole-frame copies into writable memory. */
-#define MAX_IN_FLIGHT 8            /* buffers handed out but not yet queued on the device */
-#define POOL_MAX_FREE 16
+#define MAX_IN_FLIGHT 16           /* buffers handed out but not yet queued on the device */
+#define POOL_MAX_FREE 20
 
 typedef struct
 {
@@ -1982,8 +1982,13 @@ pipeline_push (GstTTMLRender *render, gint width, gint height, const flutl_regio
   job->ticket = ticket_ref (ticket);
   if (!priv->finisher)
     priv->finisher = g_thread_new ("ttmlrender-finish", finisher_main, render);
+  /* as many buffers ahead of the device as ~640 MB of page-locked frames allow
+   * (an outline takes milliseconds on its worker; the more strokes run side by
+   * side, the less the finisher waits): 16 at 4K, 4 at 8K */
+  const guint ahead = (guint) CLAMP (((gsize) 640 << 20) / MAX ((gsize) width * height * 4, 1), 3,
+      MAX_IN_FLIGHT);
   g_mutex_lock (&priv->flight_lock);
-  while (priv->in_flight >= MAX_IN_FLIGHT)
+  while (priv->in_flight >= ahead)
     g_cond_wait (&priv->flight_cond, &priv->flight_lock);
   priv->in_flight++;
   g_mutex_unlock (&priv->flight_lock);
