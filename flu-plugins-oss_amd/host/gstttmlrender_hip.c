@@ -82,7 +82,7 @@ enum
  * A HIP-aware consumer finds the device address of the twin as qdata
  * "flutl-hip-device-frame" on the memory (valid once the memory has been mapped).
  * FLUTL_FULL_D2H=1 restores synchronous whole-frame copies into writable memory. */
-#define MAX_IN_FLIGHT 16           /* buffers handed out but not yet queued on the device */
+#define MAX_IN_FLIGHT 8            /* buffers handed out but not yet queued on the device */
 #define POOL_MAX_FREE 20
 
 typedef struct
@@ -448,6 +448,7 @@ typedef struct
    * While it has work, it alone uses `ctx`. */
   gboolean sync_mode;        /* FLUTL_SYNC=1: everything on the streaming thread */
   guint pool_prefill;        /* FLUTL_POOL_PREFILL (default 8): frames made ahead */
+  guint max_ahead;           /* FLUTL_MAX_AHEAD: buffers ahead of the device (0: by size) */
   GThread *finisher;
   GAsyncQueue *jobs;
   GMutex flight_lock;
@@ -1982,11 +1983,13 @@ pipeline_push (GstTTMLRender *render, gint width, gint height, const flutl_regio
   job->ticket = ticket_ref (ticket);
   if (!priv->finisher)
     priv->finisher = g_thread_new ("ttmlrender-finish", finisher_main, render);
-  /* as many buffers ahead of the device as ~640 MB of page-locked frames allow
-   * (an outline takes milliseconds on its worker; the more strokes run side by
-   * side, the less the finisher waits): 16 at 4K, 4 at 8K */
-  const guint ahead = (guint) CLAMP (((gsize) 640 << 20) / MAX ((gsize) width * height * 4, 1), 3,
-      MAX_IN_FLIGHT);
+  /* buffers ahead of the device: 8 (measured at 4K on the GPU box's host: 4 ->
+   * 1.2 k frames/s on new outlined text per cue, 8 -> 1.65 k, 12 and 16 -> 1.4-1.5 k,
+   * the strokes then slow each other and the streaming thread down), fewer where
+   * 8 page-locked frames would exceed ~640 MB (4 at 8K) */
+  const guint ahead = priv->max_ahead ? priv->max_ahead
+      : (guint) CLAMP (((gsize) 640 << 20) / MAX ((gsize) width * height * 4, 1), 3,
+          MAX_IN_FLIGHT);
   g_mutex_lock (&priv->flight_lock);
   while (priv->in_flight >= ahead)
     g_cond_wait (&priv->flight_cond, &priv->flight_lock);
@@ -2769,6 +2772,8 @@ gst_ttmlrender_init (GstTTMLRender *render)
   priv->ttml_event = GST_PAD_EVENTFUNC (render->base.sinkpad);
   gst_pad_set_event_function (render->base.sinkpad, ttml_event_in_video_mode);
   priv->sync_mode = g_getenv ("FLUTL_SYNC") != NULL;
+  priv->max_ahead = g_getenv ("FLUTL_MAX_AHEAD")
+      ? (guint) CLAMP (atoi (g_getenv ("FLUTL_MAX_AHEAD")), 1, MAX_IN_FLIGHT) : 0;
   priv->pool_prefill = g_getenv ("FLUTL_POOL_PREFILL")
       ? (guint) CLAMP (atoi (g_getenv ("FLUTL_POOL_PREFILL")), 0, POOL_MAX_FREE) : 8;
   priv->jobs = g_async_queue_new ();
