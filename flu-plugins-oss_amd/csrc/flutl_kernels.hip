@@ -1237,7 +1237,13 @@ int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst
   fp.magic_stx = fp.st_x > 1u
       ? (uint32_t) ((0x100000000ull + fp.st_x - 1u) / fp.st_x) : 0u;
   fp.stride = stride;
+  // (every launch is checked on its own, so that a refused launch is reported for
+  // the part of the batch it belongs to; a fault inside a kernel is asynchronous
+  // and surfaces at the caller's next synchronisation)
+  hipError_t launch_error = hipSuccess;
 #define LAUNCH(grid) do { \
+    if (launch_error != hipSuccess) \
+      break; \
     if (video) \
       hipLaunchKernelGGL (flutl_composite_kernel<true>, grid, dim3 (kThreads), 0, stream, fp, \
           static_cast<uint8_t *> (dst), static_cast<const uint8_t *> (video), frames, \
@@ -1246,6 +1252,7 @@ int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst
       hipLaunchKernelGGL (flutl_composite_kernel<false>, grid, dim3 (kThreads), 0, stream, fp, \
           static_cast<uint8_t *> (dst), static_cast<const uint8_t *> (nullptr), frames, \
           regions, prims, atlas); \
+    launch_error = hipGetLastError (); \
   } while (0)
   // one workgroup (= one wave) per supertile; grid.x is a multiple of 8 so
   // that blockIdx.x & 7 is the XCD of the workgroup in every row of the grid
@@ -1269,7 +1276,7 @@ int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst
     LAUNCH (dim3 ((n_rows + 7u) / 8u * fp.st_x * 8u, rest));
   }
 #undef LAUNCH
-  return hipGetLastError () == hipSuccess ? FLUTL_OK : FLUTL_ENODEV;
+  return launch_error == hipSuccess ? FLUTL_OK : FLUTL_ENODEV;
 }
 
 }  // namespace
