@@ -146,3 +146,46 @@ def test_element_fused_over_video_through_its_request_pad(gpu, name):
         else:
             exp = video[k]
         assert np.array_equal(out[k], exp), (k, state, int((out[k] != exp).sum()))
+
+
+@pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
+                    reason="fluttml-hip plugin / GStreamer runtime not present")
+def test_two_elements_in_one_process_and_a_thread_boundary_downstream(gpu, tmp_path):
+    """Two ttmlrender instances in ONE pipeline process (each with its own context,
+    finisher thread and frame pool; the stroke workers are shared), each followed by
+    a queue: buffers pile up downstream and are mapped on another thread than the
+    one that made them.  Both outputs must be the reference's frames."""
+    import subprocess
+    names = ["k04_outline", "k12_moving_outline"]
+    outs = [str(tmp_path / (n + ".raw")) for n in names]
+    cmd = [os.path.join(gstenv.CONDA, "bin", "gst-launch-1.0"), "-q", "--no-fault"]
+    for n, o in zip(names, outs):
+        z = np.load(os.path.join(ROOT, "tests", "golden", "scenes", n + ".npz"))
+        cmd += ["filesrc", "location=" + os.path.join(ROOT, "tests", "golden", "scenes", n + ".ttml"),
+                "!", "ttmlrender", "!", f"video/x-raw,width={int(z['width'])},height={int(z['height'])}",
+                "!", "queue", "max-size-buffers=64", "!", "filesink", "location=" + o]
+    r = subprocess.run(cmd, env=gstenv.env_for(gstenv.HIP_PLUGIN_DIR), capture_output=True,
+                       text=True, cwd=str(tmp_path), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for n, o in zip(names, outs):
+        z = np.load(os.path.join(ROOT, "tests", "golden", "scenes", n + ".npz"))
+        got = np.fromfile(o, np.uint32).reshape(-1, int(z["height"]), int(z["width"]))
+        assert np.array_equal(got, z["frames"]), n
+
+
+@pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
+                    reason="fluttml-hip plugin / GStreamer runtime not present")
+@pytest.mark.parametrize("knobs", [{"FLUTL_SYNC": "1"}, {"FLUTL_NO_REGION_CACHE": "1"},
+                                   {"FLUTL_MAX_AHEAD": "1", "FLUTL_STROKE_THREADS": "1"},
+                                   {"FLUTL_FULL_D2H": "1"}, {"FLUTL_POOL_PREFILL": "0"}],
+                         ids=["sync", "no-region-cache", "ahead1", "full-d2h", "no-prefill"])
+def test_element_modes_all_reproduce_the_reference(gpu, knobs):
+    """The element's pipeline knobs change how a buffer is produced, never what it
+    holds: an outlined, animated scene and a moving outline under each of them."""
+    for name in ("k06_animation", "k12_moving_outline", "k13_vertical_group"):
+        path = [s for s in SCENES if name in s][0]
+        z = np.load(path)
+        W, H = int(z["width"]), int(z["height"])
+        raw = gstenv.render(gstenv.HIP_PLUGIN_DIR, path[:-4] + ".ttml", W, H, extra_env=knobs)
+        got = np.frombuffer(raw, np.uint32).reshape(-1, H, W)
+        assert np.array_equal(got, z["frames"]), (name, knobs)
