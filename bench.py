@@ -198,6 +198,8 @@ def main():
     ap.add_argument("--over-video", action="store_true",
                     help="fused mode: composite each overlay OVER a resident video frame "
                          "(flutl_launch_batch_over); adds 4*W*H read bytes per frame")
+    ap.add_argument("--no-row-order", action="store_true",
+                    help="--batch 1: supertile rows top to bottom instead of heaviest first")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the element end-to-end block (GStreamer pipeline runs)")
@@ -280,6 +282,16 @@ def main():
                 descs[s * B + j] = (r_first[st], r_count[st],
                                     ((s * B + j) % ring) * frame_bytes)
         D_dev = dev(descs)
+    # single-frame launches take their supertile rows heaviest first, as the element
+    # does (flutl_row_order: host side, once per scene state)
+    O_dev = None
+    if B == 1 and video is None and not args.no_row_order:
+        orders = [F.row_order(W, H, R, P) for (R, P) in states]
+        o_len = (H + 15) // 16
+        O_all = np.zeros((n_states, o_len), np.uint16)
+        for i, o in enumerate(orders):
+            O_all[i, :len(o)] = o
+        O_dev = dev(O_all)
     stream = torch.cuda.current_stream().cuda_stream
     # --gather: finished frames go to rank 0 in rank order, one collective per
     # step (the step's B frames are one contiguous block of the ring), issued
@@ -294,9 +306,15 @@ def main():
         if B == 1 and video is None:
             st = streams.state_schedule(n_states, rank, s, 1, world)[0]
             slot = s % ring
-            F.launch_frame(stream, W, H, out.data_ptr() + slot * frame_bytes,
-                           R_dev.data_ptr() + r_first[st] * 16, r_count[st],
-                           P_dev, A_dev)
+            if O_dev is not None:
+                F.launch_frame_ordered(stream, W, H, out.data_ptr() + slot * frame_bytes,
+                                       R_dev.data_ptr() + r_first[st] * 16, r_count[st],
+                                       P_dev, A_dev, 0, H,
+                                       O_dev.data_ptr() + st * ((H + 15) // 16) * 2)
+            else:
+                F.launch_frame(stream, W, H, out.data_ptr() + slot * frame_bytes,
+                               R_dev.data_ptr() + r_first[st] * 16, r_count[st],
+                               P_dev, A_dev)
             if gatherer and args.gather:
                 gatherer.submit(out[slot * frame_bytes:(slot + 1) * frame_bytes])
         else:
@@ -391,6 +409,7 @@ def main():
                        "scene_source": source, "output_ring_frames": ring,
                        "streams": world, "gather_to_rank0": bool(args.gather),
                        "fused_over_video": bool(args.over_video),
+                       "rows_heaviest_first": O_dev is not None,
                        "parallelism": f"{world} independent stream(s), one per GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -198,6 +199,38 @@ extern "C" int flutl_blur_kernel (int radius, double sigma, int32_t *out)
   for (i = 0; i < size * size; ++i)
     out[i] = (int32_t) ((acc[i] / sum) * 65536.0);  // pixman_double_to_fixed
   return FLUTL_OK;
+}
+
+extern "C" uint32_t flutl_row_order (uint32_t width, uint32_t height,
+    const flutl_region *regions, uint32_t n_regions, const flutl_prim *prims,
+    uint32_t n_prims, uint32_t row0, uint32_t row1, uint16_t *order_out)
+{
+  if (!order_out || row0 >= row1 || row1 > height || height > 32767)
+    return 0;
+  const uint32_t base = row0 / 16u, n = (row1 + 15u) / 16u - base;
+  std::vector<uint32_t> weight (n, 0u);
+  for (uint32_t r = 0; r < n_regions; r++) {
+    const flutl_region &rg = regions[r];
+    for (uint32_t i = rg.first; i < rg.first + rg.count && i < n_prims; i++) {
+      const flutl_prim &p = prims[i];
+      if (p.cx1 <= p.cx0 || p.cy1 <= p.cy0)
+        continue;
+      // tiles of 64 px the primitive crosses in a row, times what a tile of it costs
+      const uint32_t tiles = (uint32_t) (p.cx1 - 1) / 64u - (uint32_t) p.cx0 / 64u + 1u;
+      const uint32_t cost = p.op == FLUTL_OP_MASK ? 8u : p.op == FLUTL_OP_RECT ? 1u : 6u;
+      const uint32_t a = (uint32_t) p.cy0 / 16u, b = (uint32_t) (p.cy1 - 1) / 16u;
+      for (uint32_t row = a; row <= b; row++)
+        if (row >= base && row < base + n)
+          weight[row - base] += tiles * cost;
+    }
+  }
+  for (uint32_t k = 0; k < n; k++)
+    order_out[k] = (uint16_t) k;
+  // (stable: equal rows stay top to bottom)
+  std::stable_sort (order_out, order_out + n,
+      [&] (uint16_t x, uint16_t y) { return weight[x] > weight[y]; });
+  (void) width;
+  return n;
 }
 
 // ---- context -------------------------------------------------------------
@@ -880,8 +913,9 @@ extern "C" int flutl_frame_submit (flutl_ctx *c, flutl_frame *f,
     sl.busy = false;
   }
   const size_t rb = ((size_t) n_regions * sizeof (flutl_region) + 31) & ~(size_t) 31;
-  const size_t pb = (size_t) n_prims * sizeof (flutl_prim);
-  if (rb + pb + 32 > sl.cap) {
+  const size_t pb = ((size_t) n_prims * sizeof (flutl_prim) + 31) & ~(size_t) 31;
+  const size_t ob = (((size_t) height + 15) / 16 * sizeof (uint16_t) + 31) & ~(size_t) 31;   // row order
+  if (rb + pb + ob + 32 > sl.cap) {
     if (sl.host)
       (void) hipHostFree (sl.host);
     if (sl.dev)
@@ -889,7 +923,7 @@ extern "C" int flutl_frame_submit (flutl_ctx *c, flutl_frame *f,
     sl.host = sl.dev = nullptr;
     sl.cap = 0;
     size_t cap = (size_t) 1 << 16;
-    while (cap < rb + pb + 32)
+    while (cap < rb + pb + ob + 32)
       cap *= 2;
     if (!hip_ok (hipHostMalloc (&sl.host, cap, hipHostMallocDefault)) ||
         !hip_ok (hipMalloc (&sl.dev, cap)))
@@ -901,7 +935,10 @@ extern "C" int flutl_frame_submit (flutl_ctx *c, flutl_frame *f,
   if (n_regions)
     memcpy (sl.host, regions, (size_t) n_regions * sizeof (flutl_region));
   if (n_prims)
-    memcpy (static_cast<uint8_t *> (sl.host) + rb, prims, pb);
+    memcpy (static_cast<uint8_t *> (sl.host) + rb, prims, (size_t) n_prims * sizeof (flutl_prim));
+  // the supertile rows of the regions, heaviest first (flutl_launch_frame_ordered)
+  const uint32_t n_order = flutl_row_order (width, height, regions, n_regions, prims, n_prims,
+      now[1], now[3], reinterpret_cast<uint16_t *> (static_cast<uint8_t *> (sl.host) + rb + pb));
   // scratch frame of the context
   const size_t need = (size_t) width * 4 * height;
   if (need > c->frame_cap) {
@@ -916,7 +953,8 @@ extern "C" int flutl_frame_submit (flutl_ctx *c, flutl_frame *f,
   }
   bool ok = true;
   if (rb + pb)
-    ok = hip_ok (hipMemcpyAsync (sl.dev, sl.host, rb + pb, hipMemcpyHostToDevice, c->stream));
+    ok = hip_ok (hipMemcpyAsync (sl.dev, sl.host, rb + pb + (n_order ? ob : 0),
+        hipMemcpyHostToDevice, c->stream));
   if (!ok)
     return FLUTL_ENODEV;
   const flutl_region *rd = static_cast<const flutl_region *> (sl.dev);
@@ -924,8 +962,13 @@ extern "C" int flutl_frame_submit (flutl_ctx *c, flutl_frame *f,
   // only the rows the regions span are composited (whole supertiles of 16 rows);
   // the delta takes the new frame as transparent everywhere else
   const uint32_t fy0 = now[1] & ~15u, fy1 = now[3] > now[1] ? ((now[3] + 15u) & ~15u) : fy0;
-  rc = flutl_launch_frame_rows (c->stream, width, height, c->frame, (size_t) width * 4, rd,
-      n_regions, pd, c->atlas, now[1], now[3]);
+  if (n_order)
+    rc = flutl_launch_frame_ordered (c->stream, width, height, c->frame, (size_t) width * 4, rd,
+        n_regions, pd, c->atlas, now[1], now[3],
+        reinterpret_cast<const uint16_t *> (static_cast<uint8_t *> (sl.dev) + rb + pb));
+  else
+    rc = flutl_launch_frame_rows (c->stream, width, height, c->frame, (size_t) width * 4, rd,
+        n_regions, pd, c->atlas, now[1], now[3]);
   // rows of the delta: what the frame held before + what it holds now
   uint32_t y0 = now[1], y1 = now[3];
   if (f->ext[3] > f->ext[1]) {

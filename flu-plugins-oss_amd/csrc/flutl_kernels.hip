@@ -419,10 +419,15 @@ __device__ __forceinline__ uint32_t uniform_over (uint32_t d, uint32_t s)
 // replay loop, so that the compiler does not "structurise" its wave-uniform
 // dispatch into flag juggling.  It came out with MORE scalar branches, not
 // fewer, and 2 % slower; dropped.)
-template <bool VIDEO>
+// ORDERED (launches of fewer than 8 frames through the element's path): supertile
+// rows are taken in the order of a table made on the host, heaviest first.  A
+// single frame is one round of waves; its time is the time of the LAST wave, and
+// with rows dealt top to bottom the text of the bottom region starts last.
+template <bool VIDEO, bool ORDERED>
 __attribute__ ((amdgpu_waves_per_eu (FLUTL_WAVES)))
 __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
     FrameParams fp, uint8_t *__restrict__ dst, const uint8_t *__restrict__ video,
+    const uint16_t *__restrict__ row_order,
     const flutl_frame_desc *__restrict__ frames,
     const flutl_region *__restrict__ regions,
     const flutl_prim *__restrict__ prims, const uint8_t *__restrict__ atlas)
@@ -449,6 +454,9 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
 
   // One wavefront per workgroup: nothing is shared between waves.
   const int lane = threadIdx.x;
+#if FLUTL_EXP == 20   // diagnosis (tools/wave_timeline.py): when does each wave start and end
+  const unsigned long long t_wave_start = __builtin_readcyclecounter ();
+#endif
 
   // Workgroup -> (frame, supertile).  Workgroups are handed to the 8 XCDs
   // round robin (blockIdx.x & 7 is the XCD: grid.x is a multiple of 8), and
@@ -468,9 +476,12 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
   const uint32_t i = blockIdx.x >> 3;
   const uint32_t g = fp.magic_stx ? __umulhi (i, fp.magic_stx) : i;   // i / st_x
   const uint32_t stx = i - g * fp.st_x;
-  const uint32_t sty = fp.row_base + g * fp.row_mul + xcd * fp.row_add;
-  if (sty >= fp.row_end)
+  uint32_t sty = g * fp.row_mul + xcd * fp.row_add;      // within the row window
+  if (fp.row_base + sty >= fp.row_end)
     return;
+  if (ORDERED)
+    sty = row_order[sty];       // (wave uniform: a scalar load)
+  sty += fp.row_base;
   const uint32_t frame = fp.frame_first + xcd * fp.xcd_frames + blockIdx.y;
 
   uint32_t rfirst = fp.region_first, rcount = fp.region_count;
@@ -948,6 +959,17 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
       }
     }
   }
+#if FLUTL_EXP == 20
+  // the wave's first 16 bytes of its supertile become (start, end) clock values
+  if (lane == 0 && sx0 + 4 <= (int) fp.width && sy0 < (int) fp.height) {
+    __builtin_amdgcn_s_waitcnt (0);
+    const unsigned long long t_wave_end = __builtin_readcyclecounter ();
+    unsigned long long *q = reinterpret_cast<unsigned long long *> (
+        dst + dst_off + (size_t) sy0 * fp.stride + (size_t) sx0 * 4);
+    q[0] = t_wave_start;
+    q[1] = t_wave_end;
+  }
+#endif
 #undef STRIP_OUT
 #undef STRIP_LOAD
 #undef STRIP_STORE
@@ -1212,7 +1234,8 @@ __global__ __launch_bounds__ (256) void flutl_delta_kernel (
 int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst,
     const void *video, size_t stride, const flutl_frame_desc *frames, uint32_t n_frames,
     uint32_t region_first, uint32_t region_count, const flutl_region *regions,
-    const flutl_prim *prims, const uint8_t *atlas, uint32_t row0 = 0, uint32_t row1 = 0)
+    const flutl_prim *prims, const uint8_t *atlas, uint32_t row0 = 0, uint32_t row1 = 0,
+    const uint16_t *row_order = nullptr)
 {
   if (!dst || width == 0 || height == 0 || n_frames == 0 || width > 32767 ||
       height > 32767 || (stride & 3) || stride < (size_t) width * 4)
@@ -1228,6 +1251,8 @@ int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst
   if (fp.row_end <= fp.row_base)
     return FLUTL_OK;
   const uint32_t n_rows = fp.row_end - fp.row_base;
+  if (row_order && (n_frames != 1 || video))
+    return FLUTL_EINVAL;        // one table, one frame
   fp.n_frames = n_frames;
   fp.region_first = region_first;
   fp.region_count = region_count;
@@ -1241,17 +1266,24 @@ int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst
   // the part of the batch it belongs to; a fault inside a kernel is asynchronous
   // and surfaces at the caller's next synchronisation)
   hipError_t launch_error = hipSuccess;
+  // (tried for single frames, tools/b1_variants.sh: capping the resident waves
+  // with extra LDS per workgroup so that rounds overlap their store and compute
+  // phases -- 14.4 us -> 15.5 ... 24.8; wave priorities by dispatch order: no change)
 #define LAUNCH(grid) do { \
     if (launch_error != hipSuccess) \
       break; \
     if (video) \
-      hipLaunchKernelGGL (flutl_composite_kernel<true>, grid, dim3 (kThreads), 0, stream, fp, \
-          static_cast<uint8_t *> (dst), static_cast<const uint8_t *> (video), frames, \
-          regions, prims, atlas); \
+      hipLaunchKernelGGL ((flutl_composite_kernel<true, false>), grid, dim3 (kThreads), 0, stream, fp, \
+          static_cast<uint8_t *> (dst), static_cast<const uint8_t *> (video), \
+          static_cast<const uint16_t *> (nullptr), frames, regions, prims, atlas); \
+    else if (row_order) \
+      hipLaunchKernelGGL ((flutl_composite_kernel<false, true>), grid, dim3 (kThreads), 0, stream, fp, \
+          static_cast<uint8_t *> (dst), static_cast<const uint8_t *> (nullptr), row_order, \
+          frames, regions, prims, atlas); \
     else \
-      hipLaunchKernelGGL (flutl_composite_kernel<false>, grid, dim3 (kThreads), 0, stream, fp, \
-          static_cast<uint8_t *> (dst), static_cast<const uint8_t *> (nullptr), frames, \
-          regions, prims, atlas); \
+      hipLaunchKernelGGL ((flutl_composite_kernel<false, false>), grid, dim3 (kThreads), 0, stream, fp, \
+          static_cast<uint8_t *> (dst), static_cast<const uint8_t *> (nullptr), \
+          static_cast<const uint16_t *> (nullptr), frames, regions, prims, atlas); \
     launch_error = hipGetLastError (); \
   } while (0)
   // one workgroup (= one wave) per supertile; grid.x is a multiple of 8 so
@@ -1300,6 +1332,19 @@ extern "C" int flutl_launch_frame_rows (void *stream, uint32_t width, uint32_t h
     return FLUTL_OK;
   return launch_tiles (static_cast<hipStream_t> (stream), width, height, dst, nullptr,
       dst_stride_bytes, nullptr, 1, 0, n_regions, regions, prims, atlas, row0, row1);
+}
+
+extern "C" int flutl_launch_frame_ordered (void *stream, uint32_t width, uint32_t height,
+    void *dst, size_t dst_stride_bytes, const flutl_region *regions,
+    uint32_t n_regions, const flutl_prim *prims, const uint8_t *atlas, uint32_t row0,
+    uint32_t row1, const uint16_t *row_order)
+{
+  if (row0 > row1 || row1 > height || !row_order)
+    return FLUTL_EINVAL;
+  if (row0 == row1)
+    return FLUTL_OK;
+  return launch_tiles (static_cast<hipStream_t> (stream), width, height, dst, nullptr,
+      dst_stride_bytes, nullptr, 1, 0, n_regions, regions, prims, atlas, row0, row1, row_order);
 }
 
 extern "C" int flutl_launch_frame_over_rows (void *stream, uint32_t width, uint32_t height,

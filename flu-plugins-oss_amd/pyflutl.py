@@ -53,6 +53,7 @@ EXPORTS = [
     "flutl_atlas_put_blurred",
     "flutl_launch_delta", "flutl_launch_delta_window", "flutl_launch_frame_rows",
     "flutl_launch_frame_over_rows", "flutl_blend_over_host",
+    "flutl_launch_frame_ordered", "flutl_row_order",
     "flutl_frame_create", "flutl_frame_destroy", "flutl_frame_host",
     "flutl_frame_device", "flutl_frame_submit", "flutl_frame_wait", "flutl_ctx_delta_bytes",
 ]
@@ -116,6 +117,9 @@ def lib():
         L.flutl_launch_frame_over_rows.argtypes = [vp, u32, u32, vp, vp, sz, vp, u32, vp, vp,
                                                    u32, u32]
         L.flutl_blend_over_host.argtypes = [vp, u32, u32, vp, u32, vp, u32, vp, sz]
+        L.flutl_launch_frame_ordered.argtypes = [vp, u32, u32, vp, sz, vp, u32, vp, vp, u32, u32, vp]
+        L.flutl_row_order.argtypes = [u32, u32, vp, u32, vp, u32, u32, u32, vp]
+        L.flutl_row_order.restype = u32
         L.flutl_frame_create.argtypes = [vp, u32, u32, ctypes.POINTER(vp)]
         L.flutl_frame_destroy.argtypes = [vp]
         L.flutl_frame_destroy.restype = None
@@ -185,6 +189,26 @@ def launch_frame_rows(stream, width, height, dst, regions_dev, n_regions, prims_
                                          stride or width * 4, p(regions_dev), n_regions,
                                          p(prims_dev), p(atlas_dev), row0, row1),
            "flutl_launch_frame_rows")
+
+
+def row_order(width, height, regions, prims, row0=0, row1=None):
+    """supertile rows of [row0, row1), heaviest first (uint16 indices from row0 // 16)"""
+    regions = np.ascontiguousarray(regions, REGION_DTYPE)
+    prims = np.ascontiguousarray(prims, PRIM_DTYPE)
+    out = np.zeros((height + 15) // 16, np.uint16)
+    n = lib().flutl_row_order(width, height, _np_ptr(regions), len(regions), _np_ptr(prims),
+                              len(prims), row0, height if row1 is None else row1, _np_ptr(out))
+    return out[:n]
+
+
+def launch_frame_ordered(stream, width, height, dst, regions_dev, n_regions, prims_dev,
+                         atlas_dev, row0, row1, order_dev, stride=None):
+    p = _dev_ptr
+    _check(lib().flutl_launch_frame_ordered(ctypes.c_void_p(stream), width, height, p(dst),
+                                            stride or width * 4, p(regions_dev), n_regions,
+                                            p(prims_dev), p(atlas_dev), row0, row1,
+                                            p(order_dev)),
+           "flutl_launch_frame_ordered")
 
 
 def launch_batch(stream, width, height, dst, frames_dev, n_frames, regions_dev,

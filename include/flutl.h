@@ -141,6 +141,24 @@ int flutl_launch_frame_rows (void *stream, uint32_t width, uint32_t height,
     const flutl_region *regions, uint32_t n_regions,
     const flutl_prim *prims, const uint8_t *atlas, uint32_t row0, uint32_t row1);
 
+/* ... taking the window's supertile rows in the order of `row_order` (device:
+ * flutl_row_order's table), heaviest first.  A single frame is one round of
+ * waves, as long as its slowest; rows dealt top to bottom start the text of the
+ * lowest region last.  Speed only: any order gives the same pixels. */
+int flutl_launch_frame_ordered (void *stream, uint32_t width, uint32_t height,
+    void *dst, size_t dst_stride_bytes,
+    const flutl_region *regions, uint32_t n_regions,
+    const flutl_prim *prims, const uint8_t *atlas, uint32_t row0, uint32_t row1,
+    const uint16_t *row_order);
+/* Host helper: the supertile rows of the window [row0, row1), as indices relative
+ * to its first one, sorted by how much coverage work the (validated) list brings
+ * to each, descending.  order_out: room for (height + 15) / 16 entries; returns
+ * the number written. */
+uint32_t flutl_row_order (uint32_t width, uint32_t height,
+    const flutl_region *regions, uint32_t n_regions,
+    const flutl_prim *prims, uint32_t n_prims, uint32_t row0, uint32_t row1,
+    uint16_t *order_out);
+
 /* A batch of independent frames (different scene states / streams) in ONE
  * launch: frame i uses regions[region_first[i] .. +region_count[i]) and is
  * written to dst + i*dst_frame_bytes.  Prim indices inside regions are

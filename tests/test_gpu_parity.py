@@ -511,3 +511,33 @@ def test_blend_over_host_frame_in_place(gpu, size):
         again = video.copy()
         ctx.blend_over_host(W, H, R[:0], P[:0], again)
         assert np.array_equal(again, video)
+
+
+@pytest.mark.parametrize("size", [(320, 180), (333, 77), (1920, 1080)])
+def test_ordered_launch_gives_the_same_frame(gpu, size):
+    """flutl_launch_frame_ordered: supertile rows heaviest first (flutl_row_order, a
+    permutation of the window's rows) -- speed only, the frame is the oracle's."""
+    import torch
+    W, H = size
+    R, P, A = scenes.subtitle_like_scene(3, W, H, n_regions=5, lines=2)
+    order = F.row_order(W, H, R, P)
+    assert sorted(order.tolist()) == list(range((H + 15) // 16))
+    rd, pd, ad, od = gpu.to_dev(R), gpu.to_dev(P), gpu.to_dev(A), gpu.to_dev(order)
+    dst = torch.full((H * W * 4,), 0xAB, dtype=torch.uint8, device="cuda")
+    F.launch_frame_ordered(torch.cuda.current_stream().cuda_stream, W, H, dst, rd, len(R), pd,
+                           ad, 0, H, od)
+    torch.cuda.synchronize()
+    got = dst.cpu().numpy().view(np.uint32).reshape(H, W)
+    assert np.array_equal(got, O.render(W, H, R, P, A))
+    # ... and over a window of rows
+    r0, r1 = H // 3, H // 3 * 2
+    order = F.row_order(W, H, R, P, r0, r1)
+    y0, y1 = r0 // 16 * 16, min(H, (r1 + 15) // 16 * 16)
+    assert sorted(order.tolist()) == list(range((y1 - y0 + 15) // 16))
+    dst.fill_(0xAB)
+    F.launch_frame_ordered(torch.cuda.current_stream().cuda_stream, W, H, dst, rd, len(R), pd,
+                           ad, r0, r1, gpu.to_dev(order))
+    torch.cuda.synchronize()
+    got = dst.cpu().numpy().view(np.uint32).reshape(H, W)
+    assert np.array_equal(got[y0:y1], O.render(W, H, R, P, A)[y0:y1])
+    assert (got[:y0] == 0xABABABAB).all() and (got[y1:] == 0xABABABAB).all()
