@@ -67,6 +67,26 @@ typedef struct
 
 struct StrokeJob;
 
+/* one glyph of the pending run: its tight A8 bitmap in the atlas and where its
+ * pixel (0, 0) lands in the frame */
+typedef struct RunGlyph
+{
+  uint32_t offset;
+  int w, h, ox, oy;
+} RunGlyph;
+
+/* a run seen before: its glyphs (bitmaps + relative positions) and, from the
+ * second sighting on, ONE mask holding all of them */
+typedef struct RunEntry
+{
+  uint64_t hash;
+  uint8_t *key;
+  size_t key_len;
+  int state;                 /* 0 seen once; 1 merged; 2 cannot be merged */
+  uint32_t offset;           /* atlas offset of the merged mask */
+  int w, h;
+} RunEntry;
+
 typedef struct
 {
   uint64_t hash;
@@ -120,6 +140,16 @@ struct FlutlRecorder
   cairo_scaled_font_t **key_fonts;
   uint32_t n_key_fonts, cap_key_fonts;
 
+  /* glyph runs ("glyph runs" below): glyphs shown back to back in one colour under
+   * one clip, held back until something else is drawn */
+  struct RunGlyph *run;
+  uint32_t n_run, cap_run;
+  uint32_t run_pixel;
+  int run_clip[4];
+  int in_run_flush, no_run_merge;
+  struct RunEntry *runs;
+  uint32_t n_runs, cap_runs;
+
   /* deferred strokes (root recorder only): what the streaming thread and the
    * thread that resolves frames share -- atlas, mask table, stroke cache, the
    * log of new atlas entries -- is guarded by `lock` */
@@ -128,6 +158,8 @@ struct FlutlRecorder
   FlutlPatch *patches;
   uint32_t n_patches, cap_patches;
   int region_deferred;        /* the open region holds a placeholder */
+  int region_provisional;     /* ... or a run at its first sighting: recorded again, it
+                               * will be one primitive (the region cache waits for that) */
 
   int has_clip, clip[4];      /* x0,y0,x1,y1 */
   int in_group, group[4];
@@ -386,9 +418,13 @@ box_hits_target (const FlutlRecorder *rec, int x0, int y0, int x1, int y1)
   return x1 > x0 && y1 > y0;
 }
 
+static void run_flush (FlutlRecorder *rec);
+
 static flutl_prim *
 push_prim (FlutlRecorder *rec)
 {
+  if (rec->n_run && !rec->in_run_flush)
+    run_flush (rec);            /* paint order: the held-back glyphs come first */
   if (rec->n_prims == rec->cap_prims) {
     rec->cap_prims = rec->cap_prims ? rec->cap_prims * 2 : 256;
     rec->prims = xrealloc (rec->prims, rec->cap_prims * sizeof (flutl_prim));
@@ -423,6 +459,7 @@ flutl_recorder_new (void)
     abort ();
   rec->atlas_size = ATLAS_SLACK;
   rec->line_split = g_getenv ("FLUTL_LINE_SPLIT") != NULL;
+  rec->no_run_merge = g_getenv ("FLUTL_NO_RUN_MERGE") != NULL;
   g_rec_mutex_init (&rec->lock);
   return rec;
 }
@@ -496,6 +533,10 @@ drop_caches (FlutlRecorder *rec)
   for (uint32_t i = 0; i < rec->n_key_fonts; i++)
     cairo_scaled_font_destroy (rec->key_fonts[i]);
   rec->n_key_fonts = 0;
+  for (uint32_t i = 0; i < rec->n_runs; i++)
+    free (rec->runs[i].key);
+  rec->n_runs = 0;
+  rec->n_run = 0;
   rec->atlas_size = ATLAS_SLACK;
   if (rec->atlas)
     memset (rec->atlas, 0, rec->atlas_cap);
@@ -530,6 +571,8 @@ flutl_recorder_free (FlutlRecorder *rec)
   free (rec->strokes);
   free (rec->key_fonts);
   free (rec->patches);
+  free (rec->run);
+  free (rec->runs);
   g_rec_mutex_clear (&rec->lock);
   free (rec);
 }
@@ -561,6 +604,7 @@ flutl_recorder_begin_frame (FlutlRecorder *rec, int width, int height)
   rec->unsupported = 0;
   rec->n_patches = 0;
   rec->region_deferred = 0;
+  rec->n_run = 0;
   path_ops_clear (rec);
   flutl_recorder_set_color (rec, 0, 0, 0, 1);
 }
@@ -601,6 +645,7 @@ flutl_recorder_region_begin (FlutlRecorder *rec)
   rec->region_first = rec->n_prims;
   rec->in_region = 1;
   rec->region_deferred = 0;
+  rec->region_provisional = 0;
   rec->shift[0] = rec->shift[1] = 0;
 }
 
@@ -622,6 +667,7 @@ flutl_recorder_set_device_shift (FlutlRecorder *rec, int dx, int dy)
 void
 flutl_recorder_region_end (FlutlRecorder *rec)
 {
+  run_flush (rec);
   uint32_t n = rec->n_prims - rec->region_first;
   rec->in_region = 0;
   if (n == 0)
@@ -722,6 +768,7 @@ flutl_recorder_group_end (FlutlRecorder *rec, double opacity)
 void
 flutl_recorder_clip (FlutlRecorder *rec, int x, int y, int w, int h)
 {
+  run_flush (rec);
   int c[4] = { x, y, x + imax (w, 0), y + imax (h, 0) };
   if (rec->has_clip) {
     c[0] = imax (c[0], rec->clip[0]);
@@ -736,6 +783,7 @@ flutl_recorder_clip (FlutlRecorder *rec, int x, int y, int w, int h)
 void
 flutl_recorder_clip_reset (FlutlRecorder *rec)
 {
+  run_flush (rec);
   rec->has_clip = 0;
 }
 
@@ -988,22 +1036,181 @@ show_scaled_glyph (FlutlRecorder *rec, cairo_scaled_font_t *sf, uint32_t glyph, 
   if (e->w == 0)
     return;
   int ox = ix + e->bx, oy = iy + e->by;
-  int x0 = ox, y0 = oy, x1 = ox + e->w, y1 = oy + e->h;
-  if (!clip_box (rec, &x0, &y0, &x1, &y1))
+  int c[4];
+  if (!effective_clip (rec, c) || ox >= c[2] || oy >= c[3] || ox + e->w <= c[0] ||
+      oy + e->h <= c[1])
     return;
-  flutl_prim *p = push_prim (rec);
-  p->op = FLUTL_OP_MASK;
-  p->rule = FLUTL_RULE_PIXMAN;
-  p->cx0 = (int16_t) x0;
-  p->cy0 = (int16_t) y0;
-  p->cx1 = (int16_t) x1;
-  p->cy1 = (int16_t) y1;
-  p->color = rec->pixel;
-  p->param = (x0 > ox || x1 < ox + e->w) ? FLUTL_MASK_XCLIP : 0;
-  p->a = (int32_t) e->offset;
-  p->b = e->w + MASK_PAD;
-  p->c = ox;
-  p->d = oy;
+  /* held back: glyphs that follow in the same colour under the same clip form a
+   * run (run_flush) */
+  if (rec->n_run && (rec->run_pixel != rec->pixel || memcmp (rec->run_clip, c, sizeof c) != 0))
+    run_flush (rec);
+  if (rec->n_run == rec->cap_run) {
+    rec->cap_run = rec->cap_run ? rec->cap_run * 2 : 64;
+    rec->run = xrealloc (rec->run, rec->cap_run * sizeof (RunGlyph));
+  }
+  rec->run_pixel = rec->pixel;
+  memcpy (rec->run_clip, c, sizeof c);
+  RunGlyph *g = &rec->run[rec->n_run++];
+  g->offset = e->offset;
+  g->w = e->w;
+  g->h = e->h;
+  g->ox = ox;
+  g->oy = oy;
+}
+
+/* ---- glyph runs -----------------------------------------------------------------
+ * The reference shows one glyph at a time (gstttmlrender.c:1138-1161) and so did
+ * the display list: one MASK primitive per glyph.  On the device a primitive that
+ * hits a tile costs ~250 instructions of bookkeeping before any pixel is blended
+ * (the wave timeline), so a tile of text was dominated by it.  A
+ * run of glyphs in one colour under one clip whose coverages never meet on a
+ * pixel composites exactly like ONE mask holding all of them: a glyph leaves
+ * every pixel it covers with 0 untouched (pixman: s * 0 + d * 255 / 255 == d).
+ * Runs are recognised by their glyphs and relative positions; the first time a
+ * run is seen its glyphs are emitted one by one as before (a cue shown once pays
+ * nothing), the second time its bitmaps are pasted into one mask -- unless two of
+ * them do meet on a pixel, then it stays as it is -- and from then on the run is
+ * one primitive. */
+static void
+run_emit_glyphs (FlutlRecorder *rec)
+{
+  const int *c = rec->run_clip;
+  for (uint32_t i = 0; i < rec->n_run; i++) {
+    const RunGlyph *g = &rec->run[i];
+    int x0 = imax (g->ox, c[0]), y0 = imax (g->oy, c[1]);
+    int x1 = imin (g->ox + g->w, c[2]), y1 = imin (g->oy + g->h, c[3]);
+    flutl_prim *p = push_prim (rec);
+    p->op = FLUTL_OP_MASK;
+    p->rule = FLUTL_RULE_PIXMAN;
+    p->cx0 = (int16_t) x0;
+    p->cy0 = (int16_t) y0;
+    p->cx1 = (int16_t) x1;
+    p->cy1 = (int16_t) y1;
+    p->color = rec->run_pixel;
+    p->param = (x0 > g->ox || x1 < g->ox + g->w) ? FLUTL_MASK_XCLIP : 0;
+    p->a = (int32_t) g->offset;
+    p->b = g->w + MASK_PAD;
+    p->c = g->ox;
+    p->d = g->oy;
+  }
+}
+
+static void
+run_flush (FlutlRecorder *rec)
+{
+  if (rec->n_run == 0 || rec->in_run_flush)
+    return;
+  rec->in_run_flush = 1;
+  const uint32_t n = rec->n_run;
+  if (n < 2 || rec->no_run_merge || rec->parent) {
+    run_emit_glyphs (rec);
+    rec->n_run = 0;
+    rec->in_run_flush = 0;
+    return;
+  }
+  /* the run's identity: its bitmaps and where they sit relative to its corner */
+  int x0 = rec->run[0].ox, y0 = rec->run[0].oy, x1 = x0, y1 = y0;
+  for (uint32_t i = 0; i < n; i++) {
+    const RunGlyph *g = &rec->run[i];
+    x0 = imin (x0, g->ox);
+    y0 = imin (y0, g->oy);
+    x1 = imax (x1, g->ox + g->w);
+    y1 = imax (y1, g->oy + g->h);
+  }
+  const size_t key_len = (size_t) n * 5 * sizeof (int32_t);
+  int32_t *key = malloc (key_len);
+  if (!key)
+    abort ();
+  for (uint32_t i = 0; i < n; i++) {
+    const RunGlyph *g = &rec->run[i];
+    key[5 * i] = (int32_t) g->offset;
+    key[5 * i + 1] = g->w;
+    key[5 * i + 2] = g->h;
+    key[5 * i + 3] = g->ox - x0;
+    key[5 * i + 4] = g->oy - y0;
+  }
+  const uint64_t h = hash_bytes ((const uint8_t *) key, key_len);
+  g_rec_mutex_lock (&rec->lock);      /* (the atlas is shared with the resolving thread) */
+  RunEntry *e = NULL;
+  for (uint32_t i = 0; i < rec->n_runs; i++)
+    if (rec->runs[i].hash == h && rec->runs[i].key_len == key_len &&
+        memcmp (rec->runs[i].key, key, key_len) == 0) {
+      e = &rec->runs[i];
+      break;
+    }
+  if (!e) {                     /* first sighting: remember it, emit as before */
+    if (rec->n_runs == rec->cap_runs) {
+      rec->cap_runs = rec->cap_runs ? rec->cap_runs * 2 : 32;
+      rec->runs = xrealloc (rec->runs, rec->cap_runs * sizeof (RunEntry));
+    }
+    e = &rec->runs[rec->n_runs++];
+    memset (e, 0, sizeof *e);
+    e->hash = h;
+    e->key = (uint8_t *) key;
+    e->key_len = key_len;
+    key = NULL;
+    rec->region_provisional = 1;
+  } else if (e->state == 0) {   /* second sighting: one mask, if coverages never meet */
+    const int W = x1 - x0, H = y1 - y0;
+    uint8_t *m = calloc ((size_t) W, (size_t) H);
+    if (!m)
+      abort ();
+    int clash = 0;
+    for (uint32_t i = 0; i < n && !clash; i++) {
+      const RunGlyph *g = &rec->run[i];
+      const uint8_t *src = rec->atlas + g->offset;     /* rows g->w + MASK_PAD apart */
+      for (int y = 0; y < g->h && !clash; y++) {
+        uint8_t *d = m + (size_t) (g->oy - y0 + y) * W + (g->ox - x0);
+        const uint8_t *sr = src + (size_t) y * (g->w + MASK_PAD);
+        for (int x = 0; x < g->w; x++) {
+          if (sr[x]) {
+            if (d[x]) {
+              clash = 1;
+              break;
+            }
+            d[x] = sr[x];
+          }
+        }
+      }
+    }
+    if (clash) {
+      e->state = 2;
+    } else {
+      e->offset = atlas_put_mask (rec, m, W, H, 0);
+      e->w = W;
+      e->h = H;
+      e->state = 1;
+    }
+    free (m);
+  }
+  const int state = e->state;
+  const uint32_t offset = e->offset;
+  const int W = e->w;
+  g_rec_mutex_unlock (&rec->lock);
+  free (key);
+  if (state == 1) {
+    const int *c = rec->run_clip;
+    int bx0 = imax (x0, c[0]), by0 = imax (y0, c[1]), bx1 = imin (x1, c[2]), by1 = imin (y1, c[3]);
+    if (bx1 > bx0 && by1 > by0) {
+      flutl_prim *p = push_prim (rec);
+      p->op = FLUTL_OP_MASK;
+      p->rule = FLUTL_RULE_PIXMAN;
+      p->cx0 = (int16_t) bx0;
+      p->cy0 = (int16_t) by0;
+      p->cx1 = (int16_t) bx1;
+      p->cy1 = (int16_t) by1;
+      p->color = rec->run_pixel;
+      p->param = (bx0 > x0 || bx1 < x1) ? FLUTL_MASK_XCLIP : 0;
+      p->a = (int32_t) offset;
+      p->b = W + MASK_PAD;
+      p->c = x0;
+      p->d = y0;
+    }
+  } else {
+    run_emit_glyphs (rec);
+  }
+  rec->n_run = 0;
+  rec->in_run_flush = 0;
 }
 
 /* ---- unknown glyphs: Pango's hex box -------------------------------------------
@@ -2455,7 +2662,7 @@ flutl_recorder_snapshot (FlutlRecorder *rec, uint32_t prim_mark, uint32_t region
 {
   *n_prims = rec->n_prims - prim_mark;
   *region = rec->n_regions > region_mark ? &rec->regions[region_mark] : NULL;
-  *has_placeholder = 0;
+  *has_placeholder = rec->region_provisional;
   for (uint32_t k = 0; k < rec->n_patches; k++)
     if (rec->patches[k].prim >= prim_mark)
       *has_placeholder = 1;
@@ -2500,6 +2707,7 @@ flutl_recorder_regions (FlutlRecorder *rec, uint32_t *n)
 const flutl_prim *
 flutl_recorder_prims (FlutlRecorder *rec, uint32_t *n)
 {
+  run_flush (rec);
   *n = rec->n_prims;
   return rec->prims;
 }

@@ -148,6 +148,44 @@ def config(cfg, seed=None, keep_states=None, keep_ttml=True):
         shutil.rmtree(tmpd)
 
 
+def repack(cfg, seed=None):
+    """Re-record bench_data/<cfg>[_seed<N>].flpk.z with the element as it is now,
+    WITHOUT running the reference again: the kept states must hash (through the
+    oracle, spot checks) to the SHA-256 the reference's frames gave.  Also stores
+    the algorithmic bytes per state of the UNMERGED list (one mask per glyph
+    instance, SURVEY 8d's definition) in the json: bench.py prices the roofline
+    with those, not with the larger masks of merged glyph runs."""
+    kind = cfg
+    W, H = gen_config_ttml.SIZES[kind]
+    d = os.path.join(ROOT, "bench_data")
+    name = cfg if seed is None else f"{kind}_seed{seed}"
+    if seed is None:
+        seed = {"cfg0": 0, "cfg1": 1, "cfg2": 2, "cfg4": 4}[kind]
+    meta_path = os.path.join(d, name + ".sha256.json")
+    meta = json.load(open(meta_path))
+    keep = meta["states"]
+    import scenes as S
+    with tempfile.TemporaryDirectory() as td:
+        ttml = os.path.join(td, name + ".ttml")
+        open(ttml, "w").write(gen_config_ttml.gen(kind, seed))
+        pk = scene_pack.load(gstenv.dump_pack(ttml, W, H, os.path.join(td, "a.flpk")))
+        pk0 = scene_pack.load(gstenv.dump_pack(ttml, W, H, os.path.join(td, "b.flpk"),
+                                               extra_env={"FLUTL_NO_RUN_MERGE": "1"}))
+    st, st0 = pk.states()[:keep], pk0.states()[:keep]
+    assert len(st) == keep == len(st0)
+    for i in sorted({0, 1, 2, keep // 2, keep - 1}):
+        got = O.render(W, H, st[i][0], st[i][1], pk.atlas)
+        assert hashlib.sha256(got.tobytes()).hexdigest() == meta["sha256"][i], (name, i)
+    meta["algorithmic_bytes"] = [int(S.algorithmic_bytes(W, H, R, P)) for (R, P) in st0]
+    meta["prims_per_state"] = [int(len(P)) for (_, P) in st]
+    json.dump(meta, open(meta_path, "w"), indent=0)
+    blob = zlib.compress(scene_pack.dumps(W, H, st, pk.atlas), 9)
+    open(os.path.join(d, name + ".flpk.z"), "wb").write(blob)
+    print(f"{name}: repacked {keep} states, {sum(len(P) for _, P in st)} prims "
+          f"(unmerged {sum(len(P) for _, P in st0)}), pack {len(blob)/1e6:.2f} MB, "
+          f"atlas {pk.atlas.size/1e6:.2f} MB")
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["scenes", "cfg0", "cfg1", "cfg2"]
     for w in what:
@@ -155,5 +193,8 @@ if __name__ == "__main__":
             scenes(only=w.partition(":")[2] or None)
         elif w.startswith("gpu_scenes"):
             scenes(gpu=True, only=w.partition(":")[2] or None)
+        elif w.startswith("repack:"):         # repack:cfg2 or repack:cfg2:23
+            parts = w.split(":")
+            repack(parts[1], int(parts[2]) if len(parts) > 2 else None)
         else:
             config(w)
