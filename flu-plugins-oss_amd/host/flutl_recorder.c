@@ -2679,7 +2679,8 @@ flutl_recorder_replay (FlutlRecorder *rec, const flutl_prim *prims, uint32_t n_p
       rec->cap_prims = rec->cap_prims ? rec->cap_prims * 2 : 256;
     rec->prims = xrealloc (rec->prims, rec->cap_prims * sizeof (flutl_prim));
   }
-  memcpy (rec->prims + first, prims, n_prims * sizeof (flutl_prim));
+  if (n_prims)                  /* (a region that recorded nothing replays nothing) */
+    memcpy (rec->prims + first, prims, n_prims * sizeof (flutl_prim));
   rec->n_prims += n_prims;
   if (region) {
     if (rec->n_regions == rec->cap_regions) {
