@@ -279,10 +279,18 @@ hash_bytes (const uint8_t *p, size_t n)
   return h;
 }
 
+static uint32_t atlas_put_dedup_hashed (FlutlRecorder *rec, const uint8_t *src, size_t bytes,
+    uint64_t h);
+
 static uint32_t
 atlas_put_dedup (FlutlRecorder *rec, const uint8_t *src, size_t bytes)
 {
-  uint64_t h = hash_bytes (src, bytes);
+  return atlas_put_dedup_hashed (rec, src, bytes, hash_bytes (src, bytes));
+}
+
+static uint32_t
+atlas_put_dedup_hashed (FlutlRecorder *rec, const uint8_t *src, size_t bytes, uint64_t h)
+{
   /* (a child recorder keeps its own table of masks, but the bytes live in the
    * parent's atlas, see atlas_put_ex) */
   FlutlRecorder *root = root_of (rec);
@@ -311,8 +319,8 @@ atlas_put_dedup (FlutlRecorder *rec, const uint8_t *src, size_t bytes)
  * bytes in front of the first row, every row followed by 4 zero bytes (stride
  * w + 4).  Returns the atlas offset of mask pixel (0,0). */
 #define MASK_PAD 4
-static uint32_t
-atlas_put_mask (FlutlRecorder *rec, const uint8_t *tight, int w, int h, int dedup)
+static uint8_t *
+mask_padded (const uint8_t *tight, int w, int h, size_t *bytes_out)
 {
   size_t stride = (size_t) w + MASK_PAD, bytes = MASK_PAD + stride * h;
   uint8_t *buf = calloc (1, bytes);
@@ -320,6 +328,15 @@ atlas_put_mask (FlutlRecorder *rec, const uint8_t *tight, int w, int h, int dedu
     abort ();
   for (int y = 0; y < h; y++)
     memcpy (buf + MASK_PAD + y * stride, tight + (size_t) y * w, (size_t) w);
+  *bytes_out = bytes;
+  return buf;
+}
+
+static uint32_t
+atlas_put_mask (FlutlRecorder *rec, const uint8_t *tight, int w, int h, int dedup)
+{
+  size_t bytes;
+  uint8_t *buf = mask_padded (tight, w, h, &bytes);
   uint32_t off = dedup ? atlas_put_dedup (rec, buf, bytes) : atlas_put (rec, buf, bytes);
   free (buf);
   return off + MASK_PAD;
@@ -1973,7 +1990,11 @@ typedef struct StrokeJob
   double line_width, miter_limit;
   RasterBox rb;
   int sw, sh;                    /* size of the surface to stroke on */
+  gint64 t_pushed;
   uint8_t *tight;                /* result: w x h coverage at (x, y), or NULL */
+  uint8_t *padded;               /* ... in the atlas's layout, and its hash: made here so */
+  size_t padded_bytes;           /* that the thread that resolves frames only copies it  */
+  uint64_t padded_hash;
   int x, y, w, h;
   GMutex lock;
   GCond cond;
@@ -2005,6 +2026,7 @@ stroke_job_unref (StrokeJob *j)
   if (j->path)
     cairo_path_destroy (j->path);
   free (j->tight);
+  free (j->padded);
   g_mutex_clear (&j->lock);
   g_cond_clear (&j->cond);
   free (j);
@@ -2019,10 +2041,28 @@ stroke_job_wait (StrokeJob *j)
   g_mutex_unlock (&j->lock);
 }
 
+static gint64 stroke_jobs_done, stroke_jobs_us, stroke_jobs_queue_us;   /* statistics */
+static gint64 resolve_wait_us;  /* time flutl_recorder_resolve spent waiting for workers */
+
+uint64_t
+flutl_recorder_resolve_wait_us (void)
+{
+  return (uint64_t) __atomic_load_n (&resolve_wait_us, __ATOMIC_RELAXED);
+}
+
+void
+flutl_recorder_stroke_stats (uint64_t *jobs, uint64_t *busy_us, uint64_t *queued_us)
+{
+  *jobs = (uint64_t) __atomic_load_n (&stroke_jobs_done, __ATOMIC_RELAXED);
+  *busy_us = (uint64_t) __atomic_load_n (&stroke_jobs_us, __ATOMIC_RELAXED);
+  *queued_us = (uint64_t) __atomic_load_n (&stroke_jobs_queue_us, __ATOMIC_RELAXED);
+}
+
 static void
 stroke_job_run (gpointer data, gpointer user_data)
 {
   StrokeJob *j = data;
+  const gint64 t_run = g_get_monotonic_time ();
   WorkerSurface *ws = g_private_get (&worker_surface_key);
   if (!ws) {
     ws = calloc (1, sizeof *ws);
@@ -2053,6 +2093,13 @@ stroke_job_run (gpointer data, gpointer user_data)
   cairo_stroke (cr);
   cairo_destroy (cr);
   j->tight = crop_coverage (ws->s, &j->rb, &j->x, &j->y, &j->w, &j->h);
+  if (j->tight) {
+    j->padded = mask_padded (j->tight, j->w, j->h, &j->padded_bytes);
+    j->padded_hash = hash_bytes (j->padded, j->padded_bytes);
+  }
+  __atomic_fetch_add (&stroke_jobs_done, 1, __ATOMIC_RELAXED);
+  __atomic_fetch_add (&stroke_jobs_us, g_get_monotonic_time () - t_run, __ATOMIC_RELAXED);
+  __atomic_fetch_add (&stroke_jobs_queue_us, t_run - j->t_pushed, __ATOMIC_RELAXED);
   g_mutex_lock (&j->lock);
   j->done = 1;
   g_cond_broadcast (&j->cond);
@@ -2063,6 +2110,7 @@ stroke_job_run (gpointer data, gpointer user_data)
 
 static GThreadPool *stroke_pool;
 static GMutex stroke_pool_lock;
+
 
 static GThreadPool *
 stroke_pool_get (void)
@@ -2084,21 +2132,19 @@ flutl_recorder_set_defer (FlutlRecorder *rec, int on)
   rec->defer = on && !rec->parent;
 }
 
-/* The stroke of the pending ops, prepared here and drawn elsewhere. */
-static void
-stroke_defer (FlutlRecorder *rec, StrokeEntry *e)
+/* The stroke of the pending ops, prepared here and drawn elsewhere: the job, or
+ * NULL if there is nothing to draw (rb is valid either way).  Touches nothing the
+ * resolving thread shares: called WITHOUT the recorder's lock -- building the path
+ * and taking its exact extents is most of what a new stroke costs this thread. */
+static StrokeJob *
+stroke_defer_prepare (FlutlRecorder *rec, RasterBox *rb)
 {
   cairo_t *cr = rec->cr;
-  RasterBox rb;
-  raster_prepare (rec, 0, &rb);
-  e->w = e->h = 0;
-  memcpy (e->ext, rb.ext, sizeof e->ext);
-  e->translatable = rb.inside;
-  if (rb.bx1 <= rb.bx0 || rb.by1 <= rb.by0) {
+  raster_prepare (rec, 0, rb);
+  if (rb->bx1 <= rb->bx0 || rb->by1 <= rb->by0) {
     cairo_new_path (cr);
-    return;
+    return NULL;
   }
-  memcpy (e->lim, rb.lim, sizeof e->lim);
   StrokeJob *j = calloc (1, sizeof *j);
   if (!j)
     abort ();
@@ -2115,11 +2161,26 @@ stroke_defer (FlutlRecorder *rec, StrokeEntry *e)
   cairo_new_path (cr);
   if (!j->path || j->path->status != CAIRO_STATUS_SUCCESS)
     abort ();
-  j->rb = rb;
+  j->rb = *rb;
   j->sw = rec->sw;
   j->sh = rec->sh;
+  return j;
+}
+
+/* (with the lock) the prepared stroke becomes the entry's */
+static void
+stroke_defer_commit (FlutlRecorder *rec, StrokeEntry *e, const RasterBox *rb, StrokeJob *j)
+{
+  e->w = e->h = 0;
+  memcpy (e->ext, rb->ext, sizeof e->ext);
+  e->translatable = rb->inside;
+  if (!j)
+    return;
+  memcpy (e->lim, rb->lim, sizeof e->lim);
   e->job = j;
+  j->t_pushed = g_get_monotonic_time ();
   g_thread_pool_push (stroke_pool_get (), j, NULL);
+  (void) rec;
 }
 
 /* The frame rectangle a stroke emitted now may reach: frame x clip x group. */
@@ -2185,13 +2246,17 @@ flutl_recorder_resolve (FlutlRecorder *rec, flutl_region *regions, uint32_t n_re
     if (j)
       g_atomic_int_inc (&j->refs);
     g_rec_mutex_unlock (&rec->lock);
-    if (j)
+    if (j) {
+      const gint64 t_w = g_get_monotonic_time ();
       stroke_job_wait (j);
+      __atomic_fetch_add (&resolve_wait_us, g_get_monotonic_time () - t_w, __ATOMIC_RELAXED);
+    }
     g_rec_mutex_lock (&rec->lock);
     StrokeEntry *e = &rec->strokes[pt->entry];    /* (the array may have moved) */
     if (j && e->job == j) {     /* first to get here: the mask goes into the atlas */
       if (j->tight) {
-        e->offset = atlas_put_mask (rec, j->tight, j->w, j->h, 1);
+        e->offset = atlas_put_dedup_hashed (rec, j->padded, j->padded_bytes, j->padded_hash) +
+            MASK_PAD;
         e->x = j->x;
         e->y = j->y;
         e->w = j->w;
@@ -2308,24 +2373,32 @@ ops_get_mask (FlutlRecorder *rec, int fill, int *dx, int *dy)
 {
   int is_new;
   StrokeEntry *e = ops_find_mask (rec, fill, dx, dy, &is_new);
-  if (is_new) {
-    if (rec->defer && !fill)
-      stroke_defer (rec, e);
-    else
-      e->translatable = stroke_rasterise (rec, e, fill);
-  }
+  if (is_new)
+    e->translatable = stroke_rasterise (rec, e, fill);
   return e;
 }
 
 static void
 ops_to_mask (FlutlRecorder *rec, int fill)
 {
-  int dx, dy;
+  int dx, dy, is_new;
+  GRecMutex *lk = &root_of (rec)->lock;
   /* (the stroke cache is shared with the thread that resolves frames) */
-  g_rec_mutex_lock (&root_of (rec)->lock);
-  StrokeEntry *e = ops_get_mask (rec, fill, &dx, &dy);
+  g_rec_mutex_lock (lk);
+  StrokeEntry *e = ops_find_mask (rec, fill, &dx, &dy, &is_new);
+  if (is_new && rec->defer && !fill) {
+    const uint32_t idx = (uint32_t) (e - rec->strokes);
+    RasterBox rb;
+    g_rec_mutex_unlock (lk);
+    StrokeJob *j = stroke_defer_prepare (rec, &rb);
+    g_rec_mutex_lock (lk);
+    e = &rec->strokes[idx];     /* (only this thread adds entries: it has not moved) */
+    stroke_defer_commit (rec, e, &rb, j);
+  } else if (is_new) {
+    e->translatable = stroke_rasterise (rec, e, fill);
+  }
   stroke_emit (rec, e, dx, dy);
-  g_rec_mutex_unlock (&root_of (rec)->lock);
+  g_rec_mutex_unlock (lk);
 }
 
 /* Device rows an op's stroke can touch: its outline's bounding box under the

@@ -148,6 +148,10 @@ void flutl_recorder_set_defer (FlutlRecorder *rec, int on);
 const FlutlPatch *flutl_recorder_patches (FlutlRecorder *rec, uint32_t *n);
 void flutl_recorder_resolve (FlutlRecorder *rec, flutl_region *regions, uint32_t n_regions,
     flutl_prim *prims, uint32_t n_prims, const FlutlPatch *patches, uint32_t n_patches);
+/* process-wide statistics of the stroke workers: jobs done, time they ran, time they
+ * waited in the pool's queue (microseconds) */
+void flutl_recorder_stroke_stats (uint64_t *jobs, uint64_t *busy_us, uint64_t *queued_us);
+uint64_t flutl_recorder_resolve_wait_us (void);
 void flutl_recorder_lock (FlutlRecorder *rec);
 void flutl_recorder_unlock (FlutlRecorder *rec);
 

@@ -82,8 +82,8 @@ enum
  * A HIP-aware consumer finds the device address of the twin as qdata
  * "flutl-hip-device-frame" on the memory (valid once the memory has been mapped).
  * FLUTL_FULL_D2H=1 restores synchronous whole-frame copies into writable memory. */
-#define MAX_IN_FLIGHT 8            /* buffers handed out but not yet queued on the device */
-#define POOL_MAX_FREE 20
+#define MAX_IN_FLIGHT 16           /* buffers handed out but not yet queued on the device */
+#define POOL_MAX_FREE 24
 
 typedef struct
 {
@@ -97,6 +97,7 @@ typedef struct
   gint refs;
   GMutex lock;
   gsize block_size, prefilled_size;
+  guint prefilled_count;
   GPtrArray *free_slots;          /* FrameSlot* */
 } FramePool;
 
@@ -361,15 +362,19 @@ static void
 frame_pool_prefill (FramePool *p, flutl_ctx *ctx, gint width, gint height, guint n)
 {
   const gsize size = (gsize) width * height * 4;
+  guint have = 0;
   g_mutex_lock (&p->lock);
-  if (p->prefilled_size == size) {
+  if (p->prefilled_size == size)
+    have = p->prefilled_count;
+  if (have >= n) {
     g_mutex_unlock (&p->lock);
     return;
   }
   p->prefilled_size = size;
+  p->prefilled_count = n;
   frame_pool_set_size (p, size);
   g_mutex_unlock (&p->lock);
-  for (guint i = 0; i < n; i++) {
+  for (guint i = have; i < n; i++) {
     FrameSlot *slot = frame_slot_new (ctx, width, height, TRUE);
     if (!slot)
       break;
@@ -448,6 +453,7 @@ typedef struct
    * While it has work, it alone uses `ctx`. */
   gboolean sync_mode;        /* FLUTL_SYNC=1: everything on the streaming thread */
   guint pool_prefill;        /* FLUTL_POOL_PREFILL (default 8): frames made ahead */
+  gboolean pool_prefill_set;
   guint max_ahead;           /* FLUTL_MAX_AHEAD: buffers ahead of the device (0: by size) */
   gboolean queue_always;     /* FLUTL_QUEUE_ALWAYS=1: every frame goes through the finisher
                               * (default: a frame with all its masks there is queued on the
@@ -461,6 +467,7 @@ typedef struct
   guint in_flight;
   gint64 t_submit, t_flush, t_resolve;   /* (finisher's clocks, read when it is idle) */
   gint64 t_build, t_layout;  /* parts of t_record: spans -> regions, paragraphs -> layouts */
+  gint64 t_push_block;       /* streaming thread blocked on the run-ahead limit */
   /* fused over-video: with the optional request pad "video_sink"
    * linked, gen_buffer records cues instead of rendering frames, and every video
    * buffer gets the cue of its time composited into it on the device */
@@ -1977,6 +1984,21 @@ pipeline_stop (GstTTMLRender *render)
   priv->finisher = NULL;
 }
 
+/* Buffers that may be ahead of the device.  The pipeline is bound by latency per
+ * slot -- an outline takes ~2.7 ms on its worker, plus thread wake-ups -- so the
+ * depth sets the rate on a stream with new outlined text per cue; measured at 4K on
+ * the GPU box's host, frames made ahead: 4 -> 1.3 k frames/s, 8 -> 1.6-1.7 k, 12 ->
+ * 1.8 k, 16 -> 2.1 k.  16, or fewer where that many page-locked frames would exceed
+ * ~640 MB (4 at 8K). */
+static guint
+run_ahead (GstTTMLRenderPrivate *priv, gint width, gint height)
+{
+  if (priv->max_ahead)
+    return priv->max_ahead;
+  return (guint) CLAMP (((gsize) 640 << 20) / MAX ((gsize) width * height * 4, 1), 3,
+      MAX_IN_FLIGHT);
+}
+
 /* Hand a recorded frame to the finisher.  The lists are copied: the recorder's
  * arrays are reused by the next buffer. */
 static void
@@ -2001,16 +2023,14 @@ pipeline_push (GstTTMLRender *render, gint width, gint height, const flutl_regio
   job->ticket = ticket_ref (ticket);
   if (!priv->finisher)
     priv->finisher = g_thread_new ("ttmlrender-finish", finisher_main, render);
-  /* buffers ahead of the device: 8 (measured at 4K on the GPU box's host: 4 ->
-   * 1.2 k frames/s on new outlined text per cue, 8 -> 1.65 k, 12 and 16 -> 1.4-1.5 k,
-   * the strokes then slow each other and the streaming thread down), fewer where
-   * 8 page-locked frames would exceed ~640 MB (4 at 8K) */
-  const guint ahead = priv->max_ahead ? priv->max_ahead
-      : (guint) CLAMP (((gsize) 640 << 20) / MAX ((gsize) width * height * 4, 1), 3,
-          MAX_IN_FLIGHT);
+  const guint ahead = run_ahead (priv, width, height);
   g_mutex_lock (&priv->flight_lock);
-  while (priv->in_flight >= ahead)
-    g_cond_wait (&priv->flight_cond, &priv->flight_lock);
+  if (priv->in_flight >= ahead) {
+    const gint64 t_b = g_get_monotonic_time ();
+    while (priv->in_flight >= ahead)
+      g_cond_wait (&priv->flight_cond, &priv->flight_lock);
+    priv->t_push_block += g_get_monotonic_time () - t_b;
+  }
   priv->in_flight++;
   g_mutex_unlock (&priv->flight_lock);
   g_async_queue_push (priv->jobs, job);
@@ -2157,8 +2177,15 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
     GstMapInfo map;
     const gsize size = (gsize) width * height * 4;
     const gboolean async = !priv->full_d2h;
-    if (async && !priv->sync_mode && !priv->dump)
-      frame_pool_prefill (priv->pool, priv->ctx, width, height, priv->pool_prefill);
+    if (async && !priv->sync_mode && !priv->dump) {
+      /* 8 frames at first; as many as may be ahead of the device once the stream
+       * turns out to bring outlines that take milliseconds on their workers */
+      uint32_t n_def = 0;
+      (void) flutl_recorder_patches (rec, &n_def);
+      const guint ahead = run_ahead (priv, width, height);
+      frame_pool_prefill (priv->pool, priv->ctx, width, height,
+          n_def && !priv->pool_prefill_set ? MAX (priv->pool_prefill, ahead) : priv->pool_prefill);
+    }
     FrameSlot *slot = frame_pool_take (priv->pool, priv->ctx, width, height, async);
     int rc = FLUTL_OK;
     uint32_t n_deferred = 0;
@@ -2352,9 +2379,10 @@ timing_report (GstTTMLRender *render)
 {
   GstTTMLRenderPrivate *priv = get_priv (render);
   gint64 t_drained;
-  guint64 delta = 0;
+  guint64 delta = 0, sj = 0, sb = 0, sq = 0;
   if (!priv->timing || !priv->n_timed)
     return;
+  flutl_recorder_stroke_stats (&sj, &sb, &sq);
   pipeline_drain (render);
   if (priv->ctx) {
     flutl_ctx_sync (priv->ctx);
@@ -2366,7 +2394,7 @@ timing_report (GstTTMLRender *render)
   }
   g_printerr ("ttmlrender-hip timing: buffers=%u record_us=%.1f device_us=%.1f "
       "span_us=%" G_GINT64_FORMAT " drained_us=%" G_GINT64_FORMAT " delta_bytes=%.0f "
-      "deferred=%u resolve_wait_us=%.1f atlas_upload_us=%.1f build_us=%.1f layout_us=%.1f region_hits=%u region_misses=%u\n",
+      "deferred=%u resolve_wait_us=%.1f atlas_upload_us=%.1f build_us=%.1f layout_us=%.1f region_hits=%u region_misses=%u strokes=%u stroke_us=%.0f stroke_queued_us=%.0f pure_wait_us=%.0f submit_us=%.1f push_block_us=%.1f\n",
       priv->n_timed, (double) priv->t_record / MAX (priv->n_timed - 1, 1),
       (double) (priv->t_device + priv->t_submit) / MAX (priv->n_timed - 1, 1),
       priv->t_last_return - priv->t_first_return,
@@ -2376,7 +2404,11 @@ timing_report (GstTTMLRender *render)
       (double) priv->t_flush / MAX (priv->n_deferred, 1),
       (double) priv->t_build / MAX (priv->n_timed - 1, 1),
       (double) priv->t_layout / MAX (priv->n_timed - 1, 1), priv->region_hits,
-      priv->region_misses);
+      priv->region_misses, (guint) sj, sj ? (double) sb / sj : 0.0, sj ? (double) sq / sj : 0.0,
+      (double) flutl_recorder_resolve_wait_us () / MAX (priv->n_deferred, 1),
+      (double) priv->t_submit / MAX (priv->n_deferred, 1),
+      (double) priv->t_push_block / MAX (priv->n_deferred, 1));
+  priv->t_push_block = 0;
   priv->region_hits = priv->region_misses = 0;
   priv->n_timed = priv->n_deferred = 0;
   priv->t_record = priv->t_device = priv->t_submit = priv->t_flush = priv->t_resolve = 0;
@@ -2793,6 +2825,7 @@ gst_ttmlrender_init (GstTTMLRender *render)
   priv->queue_always = g_getenv ("FLUTL_QUEUE_ALWAYS") != NULL;
   priv->max_ahead = g_getenv ("FLUTL_MAX_AHEAD")
       ? (guint) CLAMP (atoi (g_getenv ("FLUTL_MAX_AHEAD")), 1, MAX_IN_FLIGHT) : 0;
+  priv->pool_prefill_set = g_getenv ("FLUTL_POOL_PREFILL") != NULL;
   priv->pool_prefill = g_getenv ("FLUTL_POOL_PREFILL")
       ? (guint) CLAMP (atoi (g_getenv ("FLUTL_POOL_PREFILL")), 0, POOL_MAX_FREE) : 8;
   priv->jobs = g_async_queue_new ();

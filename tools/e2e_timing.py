@@ -52,7 +52,9 @@ def measure(ttml, W, H, extra_env=None, log_path=None, sink="fakesink"):
            "record_us_per_buffer": kv["record_us"], "device_us_per_buffer": kv["device_us"],
            "span_s": round(kv["span_us"] * 1e-6, 4), "drained_s": round(kv["drained_us"] * 1e-6, 4),
            "pipeline_wall_s": round(wall, 2)}
-    for k in ("delta_bytes", "deferred", "resolve_wait_us", "atlas_upload_us"):
+    for k in ("delta_bytes", "deferred", "resolve_wait_us", "atlas_upload_us", "build_us",
+              "layout_us", "strokes", "stroke_us", "stroke_queued_us", "pure_wait_us", "submit_us",
+              "push_block_us"):
         if k in kv:
             out[k] = kv[k]
     return out
