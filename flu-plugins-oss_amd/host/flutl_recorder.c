@@ -149,6 +149,7 @@ struct FlutlRecorder
   int in_run_flush, no_run_merge;
   struct RunEntry *runs;
   uint32_t n_runs, cap_runs;
+  uint32_t runs_merged, runs_clashed;     /* statistics */
 
   /* deferred strokes (root recorder only): what the streaming thread and the
    * thread that resolves frames share -- atlas, mask table, stroke cache, the
@@ -1192,7 +1193,9 @@ run_flush (FlutlRecorder *rec)
     }
     if (clash) {
       e->state = 2;
+      rec->runs_clashed++;
     } else {
+      rec->runs_merged++;
       e->offset = atlas_put_mask (rec, m, W, H, 0);
       e->w = W;
       e->h = H;
@@ -2124,6 +2127,13 @@ stroke_pool_get (void)
   }
   g_mutex_unlock (&stroke_pool_lock);
   return stroke_pool;
+}
+
+void
+flutl_recorder_run_stats (FlutlRecorder *rec, uint32_t *merged, uint32_t *clashed)
+{
+  *merged = rec->runs_merged;
+  *clashed = rec->runs_clashed;
 }
 
 void

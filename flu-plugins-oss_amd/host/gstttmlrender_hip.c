@@ -2383,6 +2383,8 @@ timing_report (GstTTMLRender *render)
   if (!priv->timing || !priv->n_timed)
     return;
   flutl_recorder_stroke_stats (&sj, &sb, &sq);
+  uint32_t rm = 0, rc_ = 0;
+  flutl_recorder_run_stats (priv->rec, &rm, &rc_);
   pipeline_drain (render);
   if (priv->ctx) {
     flutl_ctx_sync (priv->ctx);
@@ -2394,7 +2396,7 @@ timing_report (GstTTMLRender *render)
   }
   g_printerr ("ttmlrender-hip timing: buffers=%u record_us=%.1f device_us=%.1f "
       "span_us=%" G_GINT64_FORMAT " drained_us=%" G_GINT64_FORMAT " delta_bytes=%.0f "
-      "deferred=%u resolve_wait_us=%.1f atlas_upload_us=%.1f build_us=%.1f layout_us=%.1f region_hits=%u region_misses=%u strokes=%u stroke_us=%.0f stroke_queued_us=%.0f pure_wait_us=%.0f submit_us=%.1f push_block_us=%.1f\n",
+      "deferred=%u resolve_wait_us=%.1f atlas_upload_us=%.1f build_us=%.1f layout_us=%.1f region_hits=%u region_misses=%u strokes=%u stroke_us=%.0f stroke_queued_us=%.0f pure_wait_us=%.0f submit_us=%.1f push_block_us=%.1f runs_merged=%u runs_clashed=%u\n",
       priv->n_timed, (double) priv->t_record / MAX (priv->n_timed - 1, 1),
       (double) (priv->t_device + priv->t_submit) / MAX (priv->n_timed - 1, 1),
       priv->t_last_return - priv->t_first_return,
@@ -2407,7 +2409,7 @@ timing_report (GstTTMLRender *render)
       priv->region_misses, (guint) sj, sj ? (double) sb / sj : 0.0, sj ? (double) sq / sj : 0.0,
       (double) flutl_recorder_resolve_wait_us () / MAX (priv->n_deferred, 1),
       (double) priv->t_submit / MAX (priv->n_deferred, 1),
-      (double) priv->t_push_block / MAX (priv->n_deferred, 1));
+      (double) priv->t_push_block / MAX (priv->n_deferred, 1), rm, rc_);
   priv->t_push_block = 0;
   priv->region_hits = priv->region_misses = 0;
   priv->n_timed = priv->n_deferred = 0;
