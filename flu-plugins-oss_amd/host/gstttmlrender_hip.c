@@ -443,6 +443,9 @@ typedef struct
   GHashTable *images;        /* id -> cairo_surface_t (decoded PNGs) */
   GHashTable *layouts;       /* layout cache: key string -> PangoLayout, per document */
   gboolean no_layout_cache;  /* FLUTL_NO_LAYOUT_CACHE=1 */
+  GHashTable *plans;         /* SpanPlan * (a set): what span_to_region does, by its inputs */
+  GByteArray *plan_key;
+  gboolean no_span_plans;    /* FLUTL_NO_SPAN_PLANS=1 */
   GPtrArray *region_cache;   /* RegionEntry *: recorded regions by what determines them */
   gboolean no_region_cache;  /* FLUTL_NO_REGION_CACHE=1 */
   guint region_hits, region_misses;
@@ -566,8 +569,12 @@ typedef struct
                                * first span that reaches the region (:62-64) */
   GList *layouts;            /* PangoLayout */
   GString *par;              /* markup of the paragraph being assembled */
-  GstTTMLStyle par_style;
+  GstTTMLStyle par_style;    /* (slow path) style of the paragraph's first span ... */
+  gboolean par_vals;         /* ... or (span plans) what region_flush_paragraph wants of it */
+  gint par_wrap, par_align, par_spacing;
   PangoAttrList *par_attrs;
+  GString *par_key;          /* the par_add_attr calls so far, as bytes (layout cache key) */
+  gboolean par_unkeyable;    /* ... or attributes that are not plain data (shapes) */
   gint par_plain_len;
 } HipRegion;
 
@@ -593,6 +600,8 @@ region_free (gpointer data)
     g_string_free (r->par, TRUE);
   if (r->par_attrs)
     pango_attr_list_unref (r->par_attrs);
+  if (r->par_key)
+    g_string_free (r->par_key, TRUE);
   gst_ttml_style_reset (&r->par_style);
   g_list_free_full (r->layouts, g_object_unref);
   g_free (r->id);
@@ -760,10 +769,31 @@ region_configure (GstTTMLRender *render, HipRegion *r, GstTTMLStyle *style)
   r->writing_mode = a ? a->value.writing_mode : GST_TTML_WRITING_MODE_LRTB;
 }
 
+static void par_values_from_style (GstTTMLRender *render, GstTTMLStyle *style, gint *wrap,
+    gint *align, gint *spacing);
+
 /* ---- active spans -> region paragraphs (reference :591-939) ------------------ */
 static void
 par_add_attr (HipRegion *r, PangoAttribute *attr)
 {
+  /* what the layout cache keys on: the calls, not Pango's merged list (walking
+   * that copies every attribute) */
+  gint32 rec[6] = { 0, (gint32) attr->start_index, (gint32) attr->end_index, 0, 0, 0 };
+  if (!r->par_key)
+    r->par_key = g_string_new (NULL);
+  if (attr->klass->type == PANGO_ATTR_FOREGROUND || attr->klass->type == PANGO_ATTR_BACKGROUND) {
+    const PangoColor *c = &((PangoAttrColor *) attr)->color;
+    rec[0] = attr->klass->type == PANGO_ATTR_FOREGROUND ? 1 : 2;
+    rec[3] = c->red;
+    rec[4] = c->green;
+    rec[5] = c->blue;
+  } else if (attr->klass >= &hip_attr_klass[0] && attr->klass < &hip_attr_klass[HIP_ATTR_LAST]) {
+    rec[0] = 16 + (gint32) (attr->klass - hip_attr_klass);
+    rec[3] = ((PangoAttrInt *) attr)->value;
+  } else {
+    r->par_unkeyable = TRUE;
+  }
+  g_string_append_len (r->par_key, (const gchar *) rec, sizeof rec);
   if (!r->par_attrs)
     r->par_attrs = pango_attr_list_new ();
   pango_attr_list_change (r->par_attrs, attr);
@@ -865,6 +895,7 @@ anamorphic_shapes (GstTTMLRender *render, HipRegion *r, GstTTMLSpan *span,
       sa->end_index = r->par_plain_len + (next - span->chars);
       if (!r->par_attrs)
         r->par_attrs = pango_attr_list_new ();
+      r->par_unkeyable = TRUE;    /* (shape attributes carry objects: no cached layout) */
       pango_attr_list_insert (r->par_attrs, sa);
       p = next;
     }
@@ -875,7 +906,7 @@ anamorphic_shapes (GstTTMLRender *render, HipRegion *r, GstTTMLSpan *span,
 }
 
 static void
-span_to_region (GstTTMLRender *render, GList **regions, GstTTMLSpan *span)
+span_to_region_slow (GstTTMLRender *render, GList **regions, GstTTMLSpan *span)
 {
   GstTTMLBase *base = GST_TTMLBASE (render);
   GstTTMLStyle merged;
@@ -990,6 +1021,324 @@ span_to_region (GstTTMLRender *render, GList **regions, GstTTMLSpan *span)
   gst_ttml_style_reset (&merged);
 }
 
+/* ---- span plans ---------------------------------------------------
+ * span_to_region_slow above merges the region's attribute stack with the span's,
+ * configures the region, generates Pango markup and picks the styling Pango markup
+ * cannot express -- ~6 us of copying, freeing and printf per active span and
+ * buffer, most of what the streaming thread did on animated documents (cfg2: 8
+ * spans, of which one or two change per buffer).  All of it is a function of the
+ * span's attributes, its region's attribute stack, the parser's residual style
+ * (relative paddings look there, like the reference's) and a few numbers; the
+ * result -- a "plan" -- is kept under exactly those bytes and applied.  The text
+ * itself is not part of it.  Spans with an anamorphic font size (two lengths) take
+ * the slow path: their shapes depend on the paragraph so far. */
+typedef struct
+{
+  guint16 r, g, b;
+  gint kind;                    /* 0 overline 1 invisible 2 background 3 foreground
+                                 * 4 reverse 5 reverse oblique */
+} PlanAttr;
+
+typedef struct
+{
+  guint8 *key;
+  gsize key_len;
+  gboolean drop;                /* display none, or an unknown region */
+  gchar *rid;
+  HipRegion proto;              /* what region_configure makes of the merged style */
+  gchar *head, *tail;
+  gint par_wrap, par_align, par_spacing;
+  guint n_attrs;
+  PlanAttr attrs[6];
+} SpanPlan;
+
+static void
+span_plan_free (gpointer data)
+{
+  SpanPlan *p = data;
+  g_free (p->key);
+  g_free (p->rid);
+  g_free (p->head);
+  g_free (p->tail);
+  g_free (p);
+}
+
+static guint
+span_plan_hash (gconstpointer v)
+{
+  const SpanPlan *p = v;
+  guint64 h = 0xcbf29ce484222325ull;
+  gsize i = 0;
+  for (; i + 8 <= p->key_len; i += 8) {
+    guint64 w;
+    memcpy (&w, p->key + i, 8);
+    h = (h ^ w) * 0x100000001b3ull;
+    h ^= h >> 29;
+  }
+  for (; i < p->key_len; i++)
+    h = (h ^ p->key[i]) * 0x100000001b3ull;
+  return (guint) (h ^ (h >> 32));
+}
+
+static gboolean
+span_plan_equal (gconstpointer a, gconstpointer b)
+{
+  const SpanPlan *x = a, *y = b;
+  return x->key_len == y->key_len && memcmp (x->key, y->key, x->key_len) == 0;
+}
+
+static void
+key_put (GByteArray *k, gconstpointer p, guint n)
+{
+  g_byte_array_append (k, p, n);
+}
+
+static void
+key_put_string (GByteArray *k, const gchar *str)
+{
+  guint32 n = str ? (guint32) strlen (str) + 1 : 0;
+  key_put (k, &n, 4);
+  if (n)
+    key_put (k, str, n);
+}
+
+/* the bytes of an attribute list that determine what it means */
+static void
+key_put_attrs (GByteArray *k, GList *attrs)
+{
+  guint32 n = 0;
+  GList *l;
+  for (l = attrs; l; l = l->next)
+    n++;
+  key_put (k, &n, 4);
+  for (l = attrs; l; l = l->next) {
+    const GstTTMLAttribute *a = l->data;
+    guint32 type = (guint32) a->type;
+    key_put (k, &type, 4);
+    key_put_string (k, a->value.string);
+    /* (the anonymous union after `string`: attributes are made zero-filled and
+     * copied whole, so equal values are equal bytes) */
+    key_put (k, (const guint8 *) &a->value + sizeof (gchar *),
+        sizeof a->value - sizeof (gchar *));
+  }
+}
+
+static SpanPlan *
+span_plan_build (GstTTMLRender *render, GstTTMLSpan *span, GList *region_attrs,
+    gboolean region_known)
+{
+  GstTTMLBase *base = GST_TTMLBASE (render);
+  SpanPlan *p = g_new0 (SpanPlan, 1);
+  GstTTMLStyle merged;
+  GstTTMLAttribute *a;
+  GList *link;
+  gchar *font_size;
+
+  a = gst_ttml_style_get_attr (&span->style, GST_TTML_ATTR_DISPLAY);
+  if (a && !a->value.b) {
+    p->drop = TRUE;
+    return p;
+  }
+  a = gst_ttml_style_get_attr (&span->style, GST_TTML_ATTR_REGION);
+  p->rid = g_strdup (a ? a->value.string : "anonymous");
+  if (a) {
+    GstTTMLStyle region_style;
+    if (!region_known) {
+      p->drop = TRUE;
+      return p;
+    }
+    region_style.attributes = region_attrs;
+    gst_ttml_style_copy (&merged, &region_style, FALSE);
+    for (link = span->style.attributes; link; link = link->next)
+      gst_ttml_attribute_free (
+          gst_ttml_style_set_attr (&merged, (GstTTMLAttribute *) link->data));
+  } else {
+    gst_ttml_style_copy (&merged, &span->style, FALSE);
+  }
+  region_configure (render, &p->proto, &merged);
+  font_size = render->default_font_size
+      ? g_strdup (render->default_font_size)
+      : g_strdup_printf (" %dpx ",
+            base->state.frame_height / base->state.cell_resolution_y);
+  gst_ttml_style_gen_pango_markup (&base->state, &merged, &p->head, &p->tail,
+      render->default_font_family, font_size);
+  g_free (font_size);
+  par_values_from_style (render, &merged, &p->par_wrap, &p->par_align, &p->par_spacing);
+
+#define PLAN_ATTR(k_, r_, g_, b_) do { PlanAttr *pa_ = &p->attrs[p->n_attrs++]; \
+    pa_->kind = (k_); pa_->r = (r_); pa_->g = (g_); pa_->b = (b_); } while (0)
+  a = gst_ttml_style_get_attr (&span->style, GST_TTML_ATTR_TEXT_DECORATION);
+  if (a && (a->value.text_decoration & GST_TTML_TEXT_DECORATION_OVERLINE))
+    PLAN_ATTR (0, 0, 0, 0);
+  a = gst_ttml_style_get_attr (&span->style, GST_TTML_ATTR_VISIBILITY);
+  if (a && !a->value.b)
+    PLAN_ATTR (1, 0, 0, 0);
+  a = gst_ttml_style_get_attr (&span->style, GST_TTML_ATTR_BACKGROUND_COLOR);
+  if (a && (a->value.color & 0xFF)) {
+    guint16 cr, cg, cb;
+    smuggled_color (a->value.color, &cr, &cg, &cb);
+    PLAN_ATTR (2, cr, cg, cb);
+  }
+  a = gst_ttml_style_get_attr (&span->style, GST_TTML_ATTR_COLOR);
+  if (a && (a->value.color & 0xFF)) {
+    guint16 cr, cg, cb;
+    smuggled_color (a->value.color, &cr, &cg, &cb);
+    PLAN_ATTR (3, cr, cg, cb);
+  }
+  a = gst_ttml_style_get_attr (&span->style, GST_TTML_ATTR_UNICODE_BIDI);
+  if (a && a->value.unicode_bidi == GST_TTML_UNICODE_BIDI_OVERRIDE) {
+    a = gst_ttml_style_get_attr (&span->style, GST_TTML_ATTR_DIRECTION);
+    if (a && a->value.direction == GST_TTML_DIRECTION_RTL)
+      PLAN_ATTR (4, 0, 0, 0);
+  }
+  a = gst_ttml_style_get_attr (&span->style, GST_TTML_ATTR_FONT_STYLE);
+  if (a && a->value.font_style == GST_TTML_FONT_STYLE_REVERSE_OBLIQUE)
+    PLAN_ATTR (5, 0, 0, 0);
+#undef PLAN_ATTR
+  gst_ttml_style_reset (&merged);
+  return p;
+}
+
+/* What span_to_region_slow does to the regions, from the plan (same order). */
+static void
+span_plan_apply (const SpanPlan *p, GList **regions, GstTTMLSpan *span)
+{
+  HipRegion *r;
+  GList *link;
+  guint start, end, i;
+  gboolean configure = TRUE;
+
+  if (p->drop)
+    return;
+  link = g_list_find_custom (*regions, p->rid, region_cmp_id);
+  if (link) {
+    r = link->data;
+    configure = !r->layouts && !r->par;   /* only the first contributor configures */
+  } else {
+    r = g_new0 (HipRegion, 1);
+    r->id = g_strdup (p->rid);
+  }
+  if (configure) {
+    const HipRegion *q = &p->proto;
+    r->zindex = q->zindex;
+    r->opacity = q->opacity;
+    r->ox = q->ox; r->oy = q->oy; r->ex = q->ex; r->ey = q->ey;
+    r->pox = q->pox; r->poy = q->poy; r->pex = q->pex; r->pey = q->pey;
+    r->bg = q->bg;
+    r->image = q->image;
+    r->image_x = q->image_x;
+    r->image_y = q->image_y;
+    r->display_align = q->display_align;
+    r->outline = q->outline;
+    r->overflow_visible = q->overflow_visible;
+    r->writing_mode = q->writing_mode;
+  }
+  if (!link)
+    *regions = g_list_insert_sorted (*regions, r, region_cmp_z);
+
+  if (span->length) {
+    if (!r->par)
+      r->par = g_string_new (NULL);
+    g_string_append (r->par, p->head);
+    g_string_append_len (r->par, span->chars, span->length);
+    g_string_append (r->par, p->tail);
+  }
+  if (!r->par_vals && !r->par_style.attributes) {
+    r->par_vals = TRUE;
+    r->par_wrap = p->par_wrap;
+    r->par_align = p->par_align;
+    r->par_spacing = p->par_spacing;
+  }
+  start = r->par_plain_len;
+  end = start + span->length;
+  for (i = 0; i < p->n_attrs; i++) {
+    const PlanAttr *pa = &p->attrs[i];
+    PangoAttribute *at;
+    switch (pa->kind) {
+      case 0:
+        at = hip_attr_new (&hip_attr_klass[HIP_ATTR_OVERLINE], 1, start, end);
+        break;
+      case 1:
+        at = hip_attr_new (&hip_attr_klass[HIP_ATTR_INVISIBLE], 0, start, end);
+        break;
+      case 2:
+        at = pango_attr_background_new (pa->r, pa->g, pa->b);
+        at->start_index = start;
+        at->end_index = end;
+        break;
+      case 3:
+        at = pango_attr_foreground_new (pa->r, pa->g, pa->b);
+        at->start_index = start;
+        at->end_index = end;
+        break;
+      case 4:
+        at = hip_attr_new (&hip_attr_klass[HIP_ATTR_REVERSE], 1, start, end);
+        break;
+      default:
+        at = hip_attr_new (&hip_attr_klass[HIP_ATTR_REVERSE_OBLIQUE], 1, start, end);
+        break;
+    }
+    par_add_attr (r, at);
+  }
+  r->par_plain_len += span->length;
+}
+
+static void
+span_to_region (GstTTMLRender *render, GList **regions, GstTTMLSpan *span)
+{
+  GstTTMLRenderPrivate *priv = get_priv (render);
+  GstTTMLBase *base = GST_TTMLBASE (render);
+  GstTTMLAttribute *a;
+  GList *region_attrs = NULL;
+  gboolean region_known = FALSE;
+  GByteArray *k;
+  SpanPlan probe, *p;
+  gint32 ctx[6];
+
+  a = gst_ttml_style_get_attr (&span->style, GST_TTML_ATTR_FONT_SIZE);
+  if (priv->no_span_plans || (a && gst_ttml_attribute_is_length_present (a, 1))) {
+    span_to_region_slow (render, regions, span);
+    return;
+  }
+  a = gst_ttml_style_get_attr (&span->style, GST_TTML_ATTR_REGION);
+  if (a && a->value.string)
+    region_known = g_hash_table_lookup_extended (base->state.saved_region_attr_stacks,
+        a->value.string, NULL, (gpointer *) &region_attrs);
+  /* the plan's key: everything the slow path reads */
+  if (!priv->plan_key)
+    priv->plan_key = g_byte_array_new ();
+  k = priv->plan_key;
+  g_byte_array_set_size (k, 0);
+  ctx[0] = base->state.frame_width;
+  ctx[1] = base->state.frame_height;
+  ctx[2] = base->state.cell_resolution_x;
+  ctx[3] = base->state.cell_resolution_y;
+  ctx[4] = (gint32) render->default_display_align;
+  ctx[5] = region_known;
+  key_put (k, ctx, sizeof ctx);
+  key_put_string (k, render->default_font_family);
+  key_put_string (k, render->default_font_size);
+  ctx[0] = (gint32) render->default_text_align;
+  key_put (k, ctx, 4);
+  key_put_attrs (k, span->style.attributes);
+  key_put_attrs (k, region_attrs);
+  key_put_attrs (k, base->state.style.attributes);
+  probe.key = k->data;
+  probe.key_len = k->len;
+  if (!priv->plans)
+    priv->plans = g_hash_table_new_full (span_plan_hash, span_plan_equal, NULL, span_plan_free);
+  p = g_hash_table_lookup (priv->plans, &probe);
+  if (!p) {
+    if (g_hash_table_size (priv->plans) >= 1024)   /* bound it: start over */
+      g_hash_table_remove_all (priv->plans);
+    p = span_plan_build (render, span, region_attrs, region_known);
+    p->key = g_memdup (k->data, k->len);
+    p->key_len = k->len;
+    g_hash_table_add (priv->plans, p);
+  }
+  span_plan_apply (p, regions, span);
+}
+
 /* Regions whose background shows even without text (reference :1400-1425). */
 static void
 background_region (gpointer key, gpointer value, gpointer user_data)
@@ -1025,41 +1374,62 @@ layout_cache_key (GString *key, PangoContext *ctx, HipRegion *r, gint w, gint h,
 {
   /* (the context's gravity is part of the key: the reference sets it for the
    * vertical writing modes and never sets it back, and so do we) */
-  g_string_append_printf (key, "%d,%d,%d,%d,%d,%d,%d,%d|", w, h, wrap, (int) align, spacing,
-      (int) r->writing_mode, (int) pango_context_get_base_gravity (ctx),
-      (int) pango_context_get_gravity_hint (ctx));
-  if (r->par_attrs) {
-    PangoAttrIterator *it = pango_attr_list_get_iterator (r->par_attrs);
-    gboolean plain = TRUE;
-    do {
-      GSList *l, *attrs = pango_attr_iterator_get_attrs (it);
-      for (l = attrs; l; l = l->next) {
-        PangoAttribute *at = l->data;
-        if (plain) {
-          if (at->klass->type == PANGO_ATTR_FOREGROUND ||
-              at->klass->type == PANGO_ATTR_BACKGROUND) {
-            const PangoColor *c = &((PangoAttrColor *) at)->color;
-            g_string_append_printf (key, "c%d:%u-%u:%u,%u,%u;", (int) at->klass->type,
-                at->start_index, at->end_index, c->red, c->green, c->blue);
-          } else if (at->klass >= &hip_attr_klass[0] &&
-              at->klass < &hip_attr_klass[HIP_ATTR_LAST]) {
-            g_string_append_printf (key, "h%d:%u-%u:%d;", (int) (at->klass - hip_attr_klass),
-                at->start_index, at->end_index, ((PangoAttrInt *) at)->value);
-          } else {
-            plain = FALSE;
-          }
-        }
-        pango_attribute_destroy (at);
-      }
-      g_slist_free (attrs);
-    } while (pango_attr_iterator_next (it));
-    pango_attr_iterator_destroy (it);
-    if (!plain)
-      return FALSE;
-  }
-  g_string_append_c (key, '|');
+  const gint32 head[9] = { w, h, wrap, (gint32) align, spacing, (gint32) r->writing_mode,
+    (gint32) pango_context_get_base_gravity (ctx), (gint32) pango_context_get_gravity_hint (ctx),
+    r->par_key ? (gint32) r->par_key->len : 0 };
+  if (r->par_unkeyable)
+    return FALSE;
+  g_string_append_len (key, (const gchar *) head, sizeof head);
+  if (r->par_key)
+    g_string_append_len (key, r->par_key->str, r->par_key->len);
   g_string_append_len (key, r->par->str, r->par->len);
   return TRUE;
+}
+
+static guint
+layout_key_hash (gconstpointer v)
+{
+  const GString *k = v;
+  guint64 h = 0xcbf29ce484222325ull;
+  gsize i = 0;
+  for (; i + 8 <= k->len; i += 8) {
+    guint64 w;
+    memcpy (&w, k->str + i, 8);
+    h = (h ^ w) * 0x100000001b3ull;
+    h ^= h >> 29;
+  }
+  for (; i < k->len; i++)
+    h = (h ^ (guint8) k->str[i]) * 0x100000001b3ull;
+  return (guint) (h ^ (h >> 32));
+}
+
+static gboolean
+layout_key_equal (gconstpointer a, gconstpointer b)
+{
+  const GString *x = a, *y = b;
+  return x->len == y->len && memcmp (x->str, y->str, x->len) == 0;
+}
+
+static void
+layout_key_free (gpointer v)
+{
+  g_string_free (v, TRUE);
+}
+
+/* What a paragraph takes from the style of its first span: wrap option, text
+ * alignment (a GstTTMLTextAlign) and line height (reference: smuggled to the draw
+ * loop as the layout spacing; -1 means "use the line's own extents"). */
+static void
+par_values_from_style (GstTTMLRender *render, GstTTMLStyle *style, gint *wrap, gint *align,
+    gint *spacing)
+{
+  GstTTMLAttribute *a = gst_ttml_style_get_attr (style, GST_TTML_ATTR_WRAP_OPTION);
+  *wrap = a ? (gint) a->value.wrap_option : (gint) GST_TTML_WRAP_OPTION_YES;
+  a = gst_ttml_style_get_attr (style, GST_TTML_ATTR_TEXT_ALIGN);
+  *align = a ? (gint) a->value.text_align : (gint) render->default_text_align;
+  a = gst_ttml_style_get_attr (style, GST_TTML_ATTR_LINE_HEIGHT);
+  *spacing = (a && gst_ttml_attribute_is_length_present (a, 0)) ? (gint) norm_len (render, a, 0, 1)
+                                                                : -1;
 }
 
 /* Paragraph -> PangoLayout (reference :199-289). */
@@ -1078,11 +1448,11 @@ region_flush_paragraph (GstTTMLRender *render, HipRegion *r)
     w = r->pey;
     h = r->pex;
   }
-  a = gst_ttml_style_get_attr (&r->par_style, GST_TTML_ATTR_WRAP_OPTION);
-  if (a)
-    wrap = a->value.wrap_option;
-  a = gst_ttml_style_get_attr (&r->par_style, GST_TTML_ATTR_TEXT_ALIGN);
-  switch (a ? a->value.text_align : render->default_text_align) {
+  if (!r->par_vals)
+    par_values_from_style (render, &r->par_style, &r->par_wrap, &r->par_align, &r->par_spacing);
+  wrap = r->par_wrap;
+  spacing = r->par_spacing;
+  switch (r->par_align) {
     case GST_TTML_TEXT_ALIGN_RIGHT:
     case GST_TTML_TEXT_ALIGN_END:
       align = PANGO_ALIGN_RIGHT;
@@ -1093,12 +1463,6 @@ region_flush_paragraph (GstTTMLRender *render, HipRegion *r)
     default:
       break;
   }
-  /* reference: lineHeight is smuggled to the draw loop as the layout spacing;
-   * -1 means "use the line's own extents" */
-  a = gst_ttml_style_get_attr (&r->par_style, GST_TTML_ATTR_LINE_HEIGHT);
-  if (a && gst_ttml_attribute_is_length_present (a, 0))
-    spacing = norm_len (render, a, 0, 1);
-
   if (!priv->no_layout_cache) {
     key = g_string_new (NULL);
     if (!layout_cache_key (key, render->pango_context, r, w, h,
@@ -1107,7 +1471,7 @@ region_flush_paragraph (GstTTMLRender *render, HipRegion *r)
       key = NULL;
     }
   }
-  layout = key && priv->layouts ? g_hash_table_lookup (priv->layouts, key->str) : NULL;
+  layout = key && priv->layouts ? g_hash_table_lookup (priv->layouts, key) : NULL;
   if (layout) {
     g_object_ref (layout);
     g_string_free (key, TRUE);
@@ -1144,11 +1508,11 @@ region_flush_paragraph (GstTTMLRender *render, HipRegion *r)
 
   if (key) {
     if (!priv->layouts)
-      priv->layouts = g_hash_table_new_full (g_str_hash, g_str_equal, g_free,
+      priv->layouts = g_hash_table_new_full (layout_key_hash, layout_key_equal, layout_key_free,
           g_object_unref);
     if (g_hash_table_size (priv->layouts) >= 512)   /* bound it: start over */
       g_hash_table_remove_all (priv->layouts);
-    g_hash_table_insert (priv->layouts, g_string_free (key, FALSE), g_object_ref (layout));
+    g_hash_table_insert (priv->layouts, key, g_object_ref (layout));
   }
 
 done:
@@ -1156,6 +1520,10 @@ done:
   g_string_free (r->par, TRUE);
   r->par = NULL;
   r->par_plain_len = 0;
+  if (r->par_key)
+    g_string_truncate (r->par_key, 0);
+  r->par_unkeyable = FALSE;
+  r->par_vals = FALSE;
   gst_ttml_style_reset (&r->par_style);
 }
 
@@ -2435,6 +2803,8 @@ gst_ttmlrender_reset (GstTTMLBase *base)
   }
   if (priv->region_cache)       /* (keyed on layouts and decoded images of the document) */
     g_ptr_array_set_size (priv->region_cache, 0);
+  if (priv->plans)              /* (they hold decoded images of the document) */
+    g_hash_table_remove_all (priv->plans);
   /* (fused over-video: the document's cues are still waiting for their video
    * frames, and they name masks of the atlas) */
   g_mutex_lock (&priv->video_lock);
@@ -2483,6 +2853,14 @@ gst_ttmlrender_dispose (GObject *object)
   if (priv->region_cache) {
     g_ptr_array_unref (priv->region_cache);
     priv->region_cache = NULL;
+  }
+  if (priv->plans) {
+    g_hash_table_unref (priv->plans);
+    priv->plans = NULL;
+  }
+  if (priv->plan_key) {
+    g_byte_array_unref (priv->plan_key);
+    priv->plan_key = NULL;
   }
   if (priv->jobs) {
     g_async_queue_unref (priv->jobs);
@@ -2835,4 +3213,5 @@ gst_ttmlrender_init (GstTTMLRender *render)
   g_cond_init (&priv->flight_cond);
   priv->no_layout_cache = g_getenv ("FLUTL_NO_LAYOUT_CACHE") != NULL;
   priv->no_region_cache = g_getenv ("FLUTL_NO_REGION_CACHE") != NULL;
+  priv->no_span_plans = g_getenv ("FLUTL_NO_SPAN_PLANS") != NULL;
 }
