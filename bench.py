@@ -177,6 +177,20 @@ def e2e_block(W, H, cpu_baseline):
             out[doc] = d
         except Exception as e:      # noqa: BLE001
             out[doc] = {"error": repr(e)[:300]}
+    # several streams on the one GPU: 4 element pipelines at once (one process each, as 4
+    # gst-launch instances would be), frames/s summed -- the counterpart of the
+    # reference's "all host cores" figure; the element is bound by its streaming thread
+    try:
+        import concurrent.futures
+        ttml = os.path.join(ROOT, "bench_data", "cfg2.ttml")
+        n = 4
+        with concurrent.futures.ThreadPoolExecutor(n) as ex:
+            runs = list(ex.map(lambda _: e2e_timing.measure(ttml, W, H), range(n)))
+        out["cfg2_x4_streams"] = {
+            "value": round(sum(r["frames_per_s"] for r in runs), 1), "unit": "frames/s",
+            "streams": n, "per_stream": [r["frames_per_s"] for r in runs]}
+    except Exception as e:      # noqa: BLE001
+        out["cfg2_x4_streams"] = {"error": repr(e)[:300]}
     return out
 
 
