@@ -1671,6 +1671,15 @@ typedef struct
  * NOT in y (+-1 at a few pixels, irregularly: measured with one line of 17 px
  * text at 40 vertical positions, 2 variants of its outline mask), so a moved
  * group keeps its mask, and a mask is otherwise only reused at the same y. */
+static gint64 prepare_path_us, prepare_extents_us;   /* statistics: building paths, their extents */
+
+void
+flutl_recorder_prepare_stats (uint64_t *path_us, uint64_t *extents_us)
+{
+  *path_us = (uint64_t) __atomic_load_n (&prepare_path_us, __ATOMIC_RELAXED);
+  *extents_us = (uint64_t) __atomic_load_n (&prepare_extents_us, __ATOMIC_RELAXED);
+}
+
 static void
 raster_origin (const FlutlRecorder *rec, int *ox, int *oy)
 {
@@ -1712,11 +1721,16 @@ current_limits (FlutlRecorder *rec, int lim[4])
   lim[3] -= oy;
 }
 
+static void raster_box_from_extents (RasterBox *rb, double ex1, double ey1, double ex2, double ey2,
+    int sw, int sh);
+
+/* the pending ops become a real Cairo path on rec->cr, under the reference's bounds */
 static void
-raster_prepare (FlutlRecorder *rec, int fill, RasterBox *rb)
+raster_build_path (FlutlRecorder *rec, RasterBox *rb)
 {
   cairo_t *cr = rec->cr;
   int ox, oy;
+  const gint64 t_prepare = g_get_monotonic_time ();
   raster_origin (rec, &ox, &oy);
   cairo_new_path (cr);
   /* The reference builds its path on a context that carries the region's clip,
@@ -1761,7 +1775,16 @@ raster_prepare (FlutlRecorder *rec, int fill, RasterBox *rb)
     cairo_restore (cr);
   }
   cairo_restore (cr);           /* the clip goes, the path stays */
+  __atomic_fetch_add (&prepare_path_us, g_get_monotonic_time () - t_prepare, __ATOMIC_RELAXED);
+}
+
+static void
+raster_prepare (FlutlRecorder *rec, int fill, RasterBox *rb)
+{
+  cairo_t *cr = rec->cr;
+  raster_build_path (rec, rb);
   double ex1, ey1, ex2, ey2;
+  const gint64 t_path_done = g_get_monotonic_time ();
   cairo_save (cr);
   cairo_identity_matrix (cr);            /* extents in device space */
   if (fill)
@@ -1769,6 +1792,15 @@ raster_prepare (FlutlRecorder *rec, int fill, RasterBox *rb)
   else
     cairo_stroke_extents (cr, &ex1, &ey1, &ex2, &ey2);
   cairo_restore (cr);
+  __atomic_fetch_add (&prepare_extents_us, g_get_monotonic_time () - t_path_done, __ATOMIC_RELAXED);
+  raster_box_from_extents (rb, ex1, ey1, ex2, ey2, rec->sw, rec->sh);
+}
+
+/* rb->lim is set; the rest of the box from the (exact) extents of the stroke / fill */
+static void
+raster_box_from_extents (RasterBox *rb, double ex1, double ey1, double ex2, double ey2, int sw,
+    int sh)
+{
   rb->inside = ex1 >= rb->lim[0] + 3 && ey1 >= rb->lim[1] + 3 && ex2 <= rb->lim[2] - 3 &&
       ey2 <= rb->lim[3] - 3;
   rb->ext[0] = (int) floor (ex1);
@@ -1777,8 +1809,8 @@ raster_prepare (FlutlRecorder *rec, int fill, RasterBox *rb)
   rb->ext[3] = (int) ceil (ey2);
   rb->bx0 = imax (imax ((int) floor (ex1) - 2, rb->lim[0]), 0);
   rb->by0 = imax (imax ((int) floor (ey1) - 2, rb->lim[1]), 0);
-  rb->bx1 = imin (imin ((int) ceil (ex2) + 2, rb->lim[2]), rec->sw);
-  rb->by1 = imin (imin ((int) ceil (ey2) + 2, rb->lim[3]), rec->sh);
+  rb->bx1 = imin (imin ((int) ceil (ex2) + 2, rb->lim[2]), sw);
+  rb->by1 = imin (imin ((int) ceil (ey2) + 2, rb->lim[3]), sh);
 }
 
 /* The covered part of the box, cut out of an A8 surface (which is left clear
@@ -1993,6 +2025,8 @@ typedef struct StrokeJob
   double line_width, miter_limit;
   RasterBox rb;
   int sw, sh;                    /* size of the surface to stroke on */
+  int exact_pending;             /* rb was made from bounds of the extents: the worker takes
+                                  * the exact ones (rb becomes exact before the stroke) */
   gint64 t_pushed;
   uint8_t *tight;                /* result: w x h coverage at (x, y), or NULL */
   uint8_t *padded;               /* ... in the atlas's layout, and its hash: made here so */
@@ -2083,17 +2117,29 @@ stroke_job_run (gpointer data, gpointer user_data)
     ws->h = j->sh;
   }
   cairo_t *cr = cairo_create (ws->s);
+  cairo_append_path (cr, j->path);      /* (identity CTM: device coordinates) */
+  cairo_set_line_width (cr, j->line_width);
+  cairo_set_miter_limit (cr, j->miter_limit);
+  if (j->exact_pending) {
+    /* what raster_prepare does on the streaming thread in the synchronous path:
+     * the stroke's extents in device space (identity CTM), exactly */
+    double ex1, ey1, ex2, ey2;
+    cairo_stroke_extents (cr, &ex1, &ey1, &ex2, &ey2);
+    raster_box_from_extents (&j->rb, ex1, ey1, ex2, ey2, j->sw, j->sh);
+  }
   if (!j->rb.inside) {          /* under the reference's limits, see current_limits */
+    cairo_path_t *pth = cairo_copy_path (cr);
+    cairo_new_path (cr);
     cairo_rectangle (cr, j->rb.lim[0], j->rb.lim[1], j->rb.lim[2] - j->rb.lim[0],
         j->rb.lim[3] - j->rb.lim[1]);
     cairo_clip (cr);
+    cairo_append_path (cr, pth);
+    cairo_path_destroy (pth);
   }
-  cairo_append_path (cr, j->path);      /* (identity CTM: device coordinates) */
   cairo_set_matrix (cr, &j->ctm);
-  cairo_set_line_width (cr, j->line_width);
-  cairo_set_miter_limit (cr, j->miter_limit);
   cairo_set_source_rgba (cr, 1, 1, 1, 1);
-  cairo_stroke (cr);
+  if (j->rb.bx1 > j->rb.bx0 && j->rb.by1 > j->rb.by0)
+    cairo_stroke (cr);
   cairo_destroy (cr);
   j->tight = crop_coverage (ws->s, &j->rb, &j->x, &j->y, &j->w, &j->h);
   if (j->tight) {
@@ -2147,10 +2193,59 @@ flutl_recorder_set_defer (FlutlRecorder *rec, int on)
  * resolving thread shares: called WITHOUT the recorder's lock -- building the path
  * and taking its exact extents is most of what a new stroke costs this thread. */
 static StrokeJob *
-stroke_defer_prepare (FlutlRecorder *rec, RasterBox *rb)
+stroke_defer_prepare (FlutlRecorder *rec, RasterBox *rb, int *exact)
 {
   cairo_t *cr = rec->cr;
-  raster_prepare (rec, 0, rb);
+  double px1, py1, px2, py2;
+  raster_build_path (rec, rb);
+  /* cairo_stroke_extents runs the stroker over the whole path: 4x what building
+   * the path costs, and the worker can do it.  What this thread must decide
+   * now -- does the stroke meet its target at all (Cairo's "clear" bookkeeping,
+   * stroke_emit), may it be reused under a translation -- follows from bounds of
+   * the extents in all but contrived cases: the stroke covers its path and reaches
+   * at most half a line width times the miter limit beyond it. */
+  cairo_save (cr);
+  cairo_identity_matrix (cr);
+  cairo_path_extents (cr, &px1, &py1, &px2, &py2);
+  cairo_restore (cr);
+  const double reach = 0.5 * cairo_get_line_width (cr) * fmax (cairo_get_miter_limit (cr), 1.0) + 2.0;
+  int gx, gy;
+  raster_origin (rec, &gx, &gy);
+  const int in0 = (int) floor (px1), in1 = (int) floor (py1), in2 = (int) ceil (px2),
+      in3 = (int) ceil (py2);                 /* inside the extents */
+  const int out0 = (int) floor (px1 - reach), out1 = (int) floor (py1 - reach),
+      out2 = (int) ceil (px2 + reach), out3 = (int) ceil (py2 + reach);   /* around them */
+  const int hit_in = px2 > px1 && py2 > py1 &&
+      box_hits_target (rec, in0 + gx, in1 + gy, in2 + gx, in3 + gy);
+  const int hit_out = box_hits_target (rec, out0 + gx, out1 + gy, out2 + gx, out3 + gy);
+  *exact = 0;
+  if (px2 <= px1 || py2 <= py1 || (hit_out && !hit_in) || !(cairo_get_line_width (cr) > 0.0)) {
+    /* an empty path or pen, or the bounds disagree: the exact extents, here */
+    double ex1, ey1, ex2, ey2;
+    cairo_save (cr);
+    cairo_identity_matrix (cr);
+    cairo_stroke_extents (cr, &ex1, &ey1, &ex2, &ey2);
+    cairo_restore (cr);
+    raster_box_from_extents (rb, ex1, ey1, ex2, ey2, rec->sw, rec->sh);
+    *exact = 1;
+  } else {
+    /* hit_in: the extents meet the target because the path's box does; !hit_out:
+     * they miss it because even the outer box does.  Either box gives stroke_emit
+     * the right answer for this placement; the exact extents replace it when the
+     * job is collected.  Reuse under translation waits for them (inside = 0 unless
+     * even the outer box is clear of the limits). */
+    const int *b = hit_in ? (const int[4]) { in0, in1, in2, in3 } : (const int[4]) { out0, out1, out2, out3 };
+    rb->ext[0] = b[0];
+    rb->ext[1] = b[1];
+    rb->ext[2] = b[2];
+    rb->ext[3] = b[3];
+    rb->inside = out0 >= rb->lim[0] + 3 && out1 >= rb->lim[1] + 3 && out2 <= rb->lim[2] - 3 &&
+        out3 <= rb->lim[3] - 3;
+    rb->bx0 = imax (imax (out0 - 2, rb->lim[0]), 0);
+    rb->by0 = imax (imax (out1 - 2, rb->lim[1]), 0);
+    rb->bx1 = imin (imin (out2 + 2, rb->lim[2]), rec->sw);
+    rb->by1 = imin (imin (out3 + 2, rb->lim[3]), rec->sh);
+  }
   if (rb->bx1 <= rb->bx0 || rb->by1 <= rb->by0) {
     cairo_new_path (cr);
     return NULL;
@@ -2172,6 +2267,7 @@ stroke_defer_prepare (FlutlRecorder *rec, RasterBox *rb)
   if (!j->path || j->path->status != CAIRO_STATUS_SUCCESS)
     abort ();
   j->rb = *rb;
+  j->exact_pending = !*exact;
   j->sw = rec->sw;
   j->sh = rec->sh;
   return j;
@@ -2264,6 +2360,9 @@ flutl_recorder_resolve (FlutlRecorder *rec, flutl_region *regions, uint32_t n_re
     g_rec_mutex_lock (&rec->lock);
     StrokeEntry *e = &rec->strokes[pt->entry];    /* (the array may have moved) */
     if (j && e->job == j) {     /* first to get here: the mask goes into the atlas */
+      /* (the worker's extents are the exact ones) */
+      memcpy (e->ext, j->rb.ext, sizeof e->ext);
+      e->translatable = j->rb.inside;
       if (j->tight) {
         e->offset = atlas_put_dedup_hashed (rec, j->padded, j->padded_bytes, j->padded_hash) +
             MASK_PAD;
@@ -2400,7 +2499,8 @@ ops_to_mask (FlutlRecorder *rec, int fill)
     const uint32_t idx = (uint32_t) (e - rec->strokes);
     RasterBox rb;
     g_rec_mutex_unlock (lk);
-    StrokeJob *j = stroke_defer_prepare (rec, &rb);
+    int exact;
+    StrokeJob *j = stroke_defer_prepare (rec, &rb, &exact);
     g_rec_mutex_lock (lk);
     e = &rec->strokes[idx];     /* (only this thread adds entries: it has not moved) */
     stroke_defer_commit (rec, e, &rb, j);

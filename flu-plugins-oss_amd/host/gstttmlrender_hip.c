@@ -2752,7 +2752,9 @@ timing_report (GstTTMLRender *render)
     return;
   flutl_recorder_stroke_stats (&sj, &sb, &sq);
   uint32_t rm = 0, rc_ = 0;
+  uint64_t pp = 0, pe = 0;
   flutl_recorder_run_stats (priv->rec, &rm, &rc_);
+  flutl_recorder_prepare_stats (&pp, &pe);
   pipeline_drain (render);
   if (priv->ctx) {
     flutl_ctx_sync (priv->ctx);
@@ -2764,7 +2766,7 @@ timing_report (GstTTMLRender *render)
   }
   g_printerr ("ttmlrender-hip timing: buffers=%u record_us=%.1f device_us=%.1f "
       "span_us=%" G_GINT64_FORMAT " drained_us=%" G_GINT64_FORMAT " delta_bytes=%.0f "
-      "deferred=%u resolve_wait_us=%.1f atlas_upload_us=%.1f build_us=%.1f layout_us=%.1f region_hits=%u region_misses=%u strokes=%u stroke_us=%.0f stroke_queued_us=%.0f pure_wait_us=%.0f submit_us=%.1f push_block_us=%.1f runs_merged=%u runs_clashed=%u\n",
+      "deferred=%u resolve_wait_us=%.1f atlas_upload_us=%.1f build_us=%.1f layout_us=%.1f region_hits=%u region_misses=%u strokes=%u stroke_us=%.0f stroke_queued_us=%.0f pure_wait_us=%.0f submit_us=%.1f push_block_us=%.1f runs_merged=%u runs_clashed=%u path_us=%.0f extents_us=%.0f\n",
       priv->n_timed, (double) priv->t_record / MAX (priv->n_timed - 1, 1),
       (double) (priv->t_device + priv->t_submit) / MAX (priv->n_timed - 1, 1),
       priv->t_last_return - priv->t_first_return,
@@ -2777,7 +2779,8 @@ timing_report (GstTTMLRender *render)
       priv->region_misses, (guint) sj, sj ? (double) sb / sj : 0.0, sj ? (double) sq / sj : 0.0,
       (double) flutl_recorder_resolve_wait_us () / MAX (priv->n_deferred, 1),
       (double) priv->t_submit / MAX (priv->n_deferred, 1),
-      (double) priv->t_push_block / MAX (priv->n_deferred, 1), rm, rc_);
+      (double) priv->t_push_block / MAX (priv->n_deferred, 1), rm, rc_,
+      sj ? (double) pp / sj : 0.0, sj ? (double) pe / sj : 0.0);
   priv->t_push_block = 0;
   priv->region_hits = priv->region_misses = 0;
   priv->n_timed = priv->n_deferred = 0;
