@@ -192,3 +192,27 @@ def test_element_modes_all_reproduce_the_reference(gpu, knobs):
         raw = gstenv.render(gstenv.HIP_PLUGIN_DIR, path[:-4] + ".ttml", W, H, extra_env=knobs)
         got = np.frombuffer(raw, np.uint32).reshape(-1, H, W)
         assert np.array_equal(got, z["frames"]), (name, knobs)
+
+
+@pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
+                    reason="fluttml-hip plugin / GStreamer runtime not present")
+def test_promise_buffers_through_a_converting_element(gpu, tmp_path):
+    """The element's buffers are promises in its own GstMemory (map waits).  A stock
+    transform element downstream must get the right pixels without knowing:
+    ttmlrender ! videoconvert ! RGBA ! filesink == the reference's frames with B and R
+    swapped."""
+    import subprocess
+    name = "k06_animation"
+    z = np.load(os.path.join(ROOT, "tests", "golden", "scenes", name + ".npz"))
+    W, H = int(z["width"]), int(z["height"])
+    out = str(tmp_path / "rgba.raw")
+    cmd = [os.path.join(gstenv.CONDA, "bin", "gst-launch-1.0"), "-q", "--no-fault", "filesrc",
+           "location=" + os.path.join(ROOT, "tests", "golden", "scenes", name + ".ttml"), "!",
+           "ttmlrender", "!", f"video/x-raw,width={W},height={H}", "!", "videoconvert", "!",
+           "video/x-raw,format=RGBA", "!", "filesink", "location=" + out]
+    r = subprocess.run(cmd, env=gstenv.env_for(gstenv.HIP_PLUGIN_DIR), capture_output=True,
+                       text=True, cwd=str(tmp_path), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.fromfile(out, np.uint8).reshape(-1, H, W, 4)
+    exp = z["frames"].view(np.uint8).reshape(-1, H, W, 4)[..., [2, 1, 0, 3]]
+    assert np.array_equal(got, exp)
