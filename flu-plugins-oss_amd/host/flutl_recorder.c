@@ -1080,7 +1080,7 @@ show_scaled_glyph (FlutlRecorder *rec, cairo_scaled_font_t *sf, uint32_t glyph, 
  * The reference shows one glyph at a time (gstttmlrender.c:1138-1161) and so did
  * the display list: one MASK primitive per glyph.  On the device a primitive that
  * hits a tile costs ~250 instructions of bookkeeping before any pixel is blended
- * (DESIGN.md 5.5: the wave timeline), so a tile of text was dominated by it.  A
+ * (DESIGN.md 5.6: the wave timeline), so a tile of text was dominated by it.  A
  * run of glyphs in one colour under one clip whose coverages never meet on a
  * pixel composites exactly like ONE mask holding all of them: a glyph leaves
  * every pixel it covers with 0 untouched (pixman: s * 0 + d * 255 / 255 == d).
