@@ -429,6 +429,8 @@ typedef struct
   gboolean ctx_failed;
   FlutlPackWriter *dump;     /* FLUTL_DUMP_PACK=<file>: scene-pack dump */
   gboolean dump_only;        /* FLUTL_DUMP_ONLY=1: record, do not render */
+  guint8 *blank;             /* ... and hand out this blank frame */
+  gsize blank_size;
   gboolean dump_defer;       /* FLUTL_DUMP_DEFER=1: dump with strokes made on worker threads */
   gsize atlas_limit;         /* FLUTL_ATLAS_LIMIT_MB (default 256): see gen_buffer */
   gboolean overlay_meta;     /* FLUTL_OVERLAY_COMPOSITION=1: also attach the frame as a
@@ -470,6 +472,7 @@ typedef struct
   guint in_flight;
   gint64 t_submit, t_flush, t_resolve;   /* (finisher's clocks, read when it is idle) */
   gint64 t_build, t_layout;  /* parts of t_record: spans -> regions, paragraphs -> layouts */
+  gint64 t_miss;             /* ... and recording the regions the region cache did not have */
   gint64 t_push_block;       /* streaming thread blocked on the run-ahead limit */
   /* fused over-video: with the optional request pad "video_sink"
    * linked, gen_buffer records cues instead of rendering frames, and every video
@@ -1564,6 +1567,18 @@ walk_layout (GstTTMLRender *render, FlutlRecorder *rec, PangoLayout *layout,
   int spacing = pango_layout_get_spacing (layout);
   int baseline = pango_layout_get_baseline (layout) / PANGO_SCALE;
   int xoffset = 0, li;
+  /* The reference moves its Cairo context about with a save / translate /
+   * restore / translate per glyph.  Only the CTM matters to what is recorded, and
+   * saving a context copies a whole graphics state (references on the target, the
+   * source, the clip, the font...): a third of the time a new region took.  The
+   * matrix is tracked here with Cairo's own arithmetic -- cairo_translate IS
+   * cairo_matrix_translate on the CTM (_cairo_gstate_translate), a restore is a
+   * copy -- and handed to the context only where something reads it. */
+  cairo_matrix_t m, stack[3];
+  gboolean m_dirty = FALSE;
+  cairo_get_matrix (cr, &m);
+#define CTM_SYNC() G_STMT_START { if (m_dirty) { cairo_set_matrix (cr, &m); m_dirty = FALSE; } } G_STMT_END
+#define CTM_TRANSLATE(tx, ty) G_STMT_START { cairo_matrix_translate (&m, (tx), (ty)); m_dirty = TRUE; } G_STMT_END
 
   if (pango_layout_get_width (layout) == -1) {
     /* no wrapping: alignment is applied by hand against the region width */
@@ -1594,9 +1609,8 @@ walk_layout (GstTTMLRender *render, FlutlRecorder *rec, PangoLayout *layout,
     line_dx = xoffset + ranges[0] / PANGO_SCALE;     /* integer division */
     g_free (ranges);
 
-    cairo_translate (cr, line_dx,
-        writing_mode != GST_TTML_WRITING_MODE_TBLR ? pre : -post);
-    cairo_save (cr);
+    CTM_TRANSLATE (line_dx, writing_mode != GST_TTML_WRITING_MODE_TBLR ? pre : -post);
+    stack[0] = m;
     for (rl = line->runs; rl; rl = rl->next) {
       PangoGlyphItem *run = rl->data;
       PangoGlyphString *gs = run->glyphs;
@@ -1609,7 +1623,7 @@ walk_layout (GstTTMLRender *render, FlutlRecorder *rec, PangoLayout *layout,
       for (i = 0; i < gs->num_glyphs; i++)
         width += gs->glyphs[i].geometry.width;
       width /= PANGO_SCALE;
-      cairo_save (cr);
+      stack[1] = m;
       double saved_color[4];
       flutl_recorder_get_color (rec, saved_color);
 
@@ -1622,6 +1636,7 @@ walk_layout (GstTTMLRender *render, FlutlRecorder *rec, PangoLayout *layout,
           double keep[4];
           if (!show_background)
             continue;
+          CTM_SYNC ();
           if (!fill)
             flutl_recorder_stroke (rec);   /* flush the outline path so far */
           flutl_recorder_get_color (rec, keep);
@@ -1638,6 +1653,7 @@ walk_layout (GstTTMLRender *render, FlutlRecorder *rec, PangoLayout *layout,
         PangoAttribute *attr = al->data;
         PangoFontMetrics *fm;
         double thick, pos;
+        CTM_SYNC ();
         switch (attr->klass->type) {
           case PANGO_ATTR_UNDERLINE:
             fm = pango_font_get_metrics (run->item->analysis.font, NULL);
@@ -1687,35 +1703,41 @@ walk_layout (GstTTMLRender *render, FlutlRecorder *rec, PangoLayout *layout,
         int n = gs->num_glyphs;
         for (i = 0; i < n; i++) {
           PangoGlyphInfo *gi = &gs->glyphs[reverse ? n - 1 - i : i];
-          cairo_save (cr);
+          stack[2] = m;
           if (oblique) {
-            /* reference :1125, :1141-1143: reverseOblique = x += y / 4 */
+            /* reference :1125, :1141-1143: reverseOblique = x += y / 4
+             * (cairo_transform: ctm = shear x ctm, _cairo_gstate_transform) */
             cairo_matrix_t shear;
             cairo_matrix_init (&shear, 1, 0, 0.25, 1, 0, 0);
-            cairo_transform (cr, &shear);
+            cairo_matrix_multiply (&m, &shear, &m);
+            m_dirty = TRUE;
           }
           /* reference: the glyph offsets are applied here AND again by Pango */
-          cairo_translate (cr, gi->geometry.x_offset / (double) PANGO_SCALE,
+          CTM_TRANSLATE (gi->geometry.x_offset / (double) PANGO_SCALE,
               gi->geometry.y_offset / (double) PANGO_SCALE);
+          CTM_SYNC ();
           if (fill) {
             flutl_recorder_show_glyph (rec, run->item->analysis.font, gi);
           } else {
             flutl_recorder_path_glyph (rec, run->item->analysis.font, gi);
           }
-          cairo_restore (cr);
-          cairo_translate (cr, gi->geometry.width / (double) PANGO_SCALE, 0);
+          m = stack[2];
+          CTM_TRANSLATE (gi->geometry.width / (double) PANGO_SCALE, 0);
         }
       }
-      cairo_restore (cr);
-      /* cairo_restore also restores the source colour */
+      m = stack[1];
+      m_dirty = TRUE;
+      /* (restoring the context also restores the source colour) */
       flutl_recorder_set_color (rec, saved_color[0], saved_color[1], saved_color[2],
           saved_color[3]);
-      cairo_translate (cr, width, 0);
+      CTM_TRANSLATE (width, 0);
     }
-    cairo_restore (cr);
-    cairo_translate (cr, -line_dx,
-        writing_mode != GST_TTML_WRITING_MODE_TBLR ? post : -pre);
+    m = stack[0];
+    CTM_TRANSLATE (-line_dx, writing_mode != GST_TTML_WRITING_MODE_TBLR ? post : -pre);
   }
+  CTM_SYNC ();
+#undef CTM_SYNC
+#undef CTM_TRANSLATE
 }
 
 static gboolean flush_atlas (GstTTMLRender *render);
@@ -2176,7 +2198,12 @@ record_region (HipRegion *r, GstTTMLRender *render)
   flutl_recorder_mark (rec, &prim_mark, &region_mark);
   unsupported_before = flutl_recorder_unsupported (rec);
   skipped_before = priv->skipped;
-  record_region_body (r, render);
+  {
+    gint64 t0 = priv->timing ? g_get_monotonic_time () : 0;
+    record_region_body (r, render);
+    if (priv->timing && priv->n_timed)
+      priv->t_miss += g_get_monotonic_time () - t0;
+  }
   prims = flutl_recorder_snapshot (rec, prim_mark, region_mark, &n_prims, &region,
       &has_placeholder);
   if (has_placeholder || priv->skipped != skipped_before)
@@ -2533,9 +2560,18 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
         priv->t_record += t_recorded - t_start;      /* (without writing the dump) */
       priv->t_last_return = t;
     }
-    buffer = gst_buffer_new_and_alloc ((gsize) width * height * 4);
-    gst_buffer_memset (buffer, 0, 0, (gsize) width * height * 4);
-    return buffer;
+    /* (one shared blank frame, read-only: no 33 MB memset per buffer in the
+     * host-side profile; freed with the element) */
+    {
+      const gsize size = (gsize) width * height * 4;
+      if (priv->blank_size != size) {
+        g_free (priv->blank);     /* (buffers of the old size were pushed and are gone in these tests) */
+        priv->blank = g_malloc0 (size);
+        priv->blank_size = size;
+      }
+      return gst_buffer_new_wrapped_full (GST_MEMORY_FLAG_READONLY, priv->blank, size, 0, size,
+          NULL, NULL);
+    }
   }
 
   /* ---- device: display list -> frame ------------------------------------- */
@@ -2766,7 +2802,7 @@ timing_report (GstTTMLRender *render)
   }
   g_printerr ("ttmlrender-hip timing: buffers=%u record_us=%.1f device_us=%.1f "
       "span_us=%" G_GINT64_FORMAT " drained_us=%" G_GINT64_FORMAT " delta_bytes=%.0f "
-      "deferred=%u resolve_wait_us=%.1f atlas_upload_us=%.1f build_us=%.1f layout_us=%.1f region_hits=%u region_misses=%u strokes=%u stroke_us=%.0f stroke_queued_us=%.0f pure_wait_us=%.0f submit_us=%.1f push_block_us=%.1f runs_merged=%u runs_clashed=%u path_us=%.0f extents_us=%.0f\n",
+      "deferred=%u resolve_wait_us=%.1f atlas_upload_us=%.1f build_us=%.1f layout_us=%.1f region_hits=%u region_misses=%u strokes=%u stroke_us=%.0f stroke_queued_us=%.0f pure_wait_us=%.0f submit_us=%.1f push_block_us=%.1f runs_merged=%u runs_clashed=%u path_us=%.0f extents_us=%.0f miss_us=%.1f\n",
       priv->n_timed, (double) priv->t_record / MAX (priv->n_timed - 1, 1),
       (double) (priv->t_device + priv->t_submit) / MAX (priv->n_timed - 1, 1),
       priv->t_last_return - priv->t_first_return,
@@ -2780,12 +2816,13 @@ timing_report (GstTTMLRender *render)
       (double) flutl_recorder_resolve_wait_us () / MAX (priv->n_deferred, 1),
       (double) priv->t_submit / MAX (priv->n_deferred, 1),
       (double) priv->t_push_block / MAX (priv->n_deferred, 1), rm, rc_,
-      sj ? (double) pp / sj : 0.0, sj ? (double) pe / sj : 0.0);
+      sj ? (double) pp / sj : 0.0, sj ? (double) pe / sj : 0.0,
+      (double) priv->t_miss / MAX (priv->n_timed - 1, 1));
   priv->t_push_block = 0;
   priv->region_hits = priv->region_misses = 0;
   priv->n_timed = priv->n_deferred = 0;
   priv->t_record = priv->t_device = priv->t_submit = priv->t_flush = priv->t_resolve = 0;
-  priv->t_build = priv->t_layout = 0;
+  priv->t_build = priv->t_layout = priv->t_miss = 0;
 }
 
 /* ---- reset / dispose / init (reference :1610-1750) ------------------------------- */
@@ -2857,6 +2894,9 @@ gst_ttmlrender_dispose (GObject *object)
     g_ptr_array_unref (priv->region_cache);
     priv->region_cache = NULL;
   }
+  g_free (priv->blank);
+  priv->blank = NULL;
+  priv->blank_size = 0;
   if (priv->plans) {
     g_hash_table_unref (priv->plans);
     priv->plans = NULL;
