@@ -235,6 +235,9 @@ extern "C" uint32_t flutl_row_order (uint32_t width, uint32_t height,
 
 // ---- context -------------------------------------------------------------
 
+static int atlas_reserve (flutl_ctx *c, size_t need);
+static void stage_reserve (flutl_ctx *c);
+
 extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
 {
   if (!out)
@@ -266,6 +269,19 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
   c->stage = nullptr;
   c->stage_cap = c->stage_used = 0;
   c->delta_segments = nullptr;
+  // The first masks of a stream come with its first frame, and the caller's
+  // recording thread may be waiting on whoever uploads them: the atlas and the
+  // upload staging are made now (10 ms of allocation calls), not then.  (Failure
+  // is not an error here: both are made on demand as well.)
+  (void) atlas_reserve (c, (size_t) 1 << 20);
+  (void) stage_reserve (c);
+  // (... and the runtime sets up its path for copies of 256 KB and more on the
+  // first such copy, 8 ms measured: zeros over the zeros of the fresh atlas)
+  if (c->atlas && c->stage) {
+    memset (c->stage, 0, (size_t) 1 << 20);
+    (void) hipMemcpyAsync (c->atlas, c->stage, (size_t) 1 << 20, hipMemcpyHostToDevice, c->stream);
+    (void) hipStreamSynchronize (c->stream);
+  }
   *out = c;
   return FLUTL_OK;
 }
@@ -308,11 +324,22 @@ extern "C" int flutl_ctx_sync (flutl_ctx *c)
   return FLUTL_OK;
 }
 
+static void stage_reserve (flutl_ctx *c)
+{
+  constexpr size_t kStageBytes = (size_t) 8 << 20;
+  if (!c->stage && hip_ok (hipHostMalloc (reinterpret_cast<void **> (&c->stage), kStageBytes,
+          hipHostMallocDefault)))
+    c->stage_cap = kStageBytes;
+}
+
 static int atlas_reserve (flutl_ctx *c, size_t need)
 {
   if (need <= c->atlas_cap)
     return FLUTL_OK;
-  size_t cap = c->atlas_cap ? c->atlas_cap : (size_t) 1 << 20;
+  // (growing costs a device allocation, a copy and a drained stream, on the frame
+  // that brings a cue's first masks: start where 4K text with outlines ends up;
+  // HBM is not what is short on this device)
+  size_t cap = c->atlas_cap ? c->atlas_cap : (size_t) 64 << 20;
   while (cap < need)
     cap *= 2;
   uint8_t *n = nullptr;
@@ -354,10 +381,7 @@ extern "C" int flutl_atlas_put (flutl_ctx *c, const void *src, size_t bytes,
   // masks, outline masks) go through page-locked staging and are not waited
   // for -- the stream orders them before whatever reads them; the staging
   // memory is reclaimed when the stream is next drained
-  constexpr size_t kStageBytes = (size_t) 8 << 20;
-  if (!c->stage && hip_ok (hipHostMalloc (reinterpret_cast<void **> (&c->stage), kStageBytes,
-          hipHostMallocDefault)))
-    c->stage_cap = kStageBytes;
+  stage_reserve (c);
   if (c->stage && bytes <= c->stage_cap / 2) {
     if (c->stage_used + bytes > c->stage_cap) {
       if (!hip_ok (hipStreamSynchronize (c->stream)))

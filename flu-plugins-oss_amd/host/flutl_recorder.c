@@ -145,6 +145,7 @@ struct FlutlRecorder
   struct RunGlyph *run;
   uint32_t n_run, cap_run;
   uint32_t run_pixel;
+  uint16_t run_tag;             /* colour source of the run (0xFFFF: glyphs of several) */
   int run_clip[4];
   int in_run_flush, no_run_merge;
   struct RunEntry *runs;
@@ -170,6 +171,8 @@ struct FlutlRecorder
   double rgba[4];
   uint32_t pixel;             /* quantised premultiplied a8r8g8b8 */
   int color_opaque, color_clear;
+  uint16_t color_tag;           /* who set the colour (element's numbering; 0: not said) */
+  uint16_t *prim_tags;          /* per primitive, parallel to prims */
 
   uint32_t unsupported;
 };
@@ -446,7 +449,9 @@ push_prim (FlutlRecorder *rec)
   if (rec->n_prims == rec->cap_prims) {
     rec->cap_prims = rec->cap_prims ? rec->cap_prims * 2 : 256;
     rec->prims = xrealloc (rec->prims, rec->cap_prims * sizeof (flutl_prim));
+    rec->prim_tags = xrealloc (rec->prim_tags, rec->cap_prims * sizeof (uint16_t));
   }
+  rec->prim_tags[rec->n_prims] = rec->in_run_flush ? rec->run_tag : rec->color_tag;
   flutl_prim *p = &rec->prims[rec->n_prims++];
   memset (p, 0, sizeof *p);
   return p;
@@ -578,6 +583,7 @@ flutl_recorder_free (FlutlRecorder *rec)
   if (rec->scratch)
     cairo_surface_destroy (rec->scratch);
   free (rec->prims);
+  free (rec->prim_tags);
   free (rec->regions);
   free (rec->atlas);
   free (rec->new_off);
@@ -824,6 +830,47 @@ flutl_recorder_set_color (FlutlRecorder *rec, double r, double g, double b, doub
       ((uint32_t) (gs >> 8) << 8) | (uint32_t) (bs >> 8);
   rec->color_opaque = as >= 0xff00;   /* CAIRO_COLOR_IS_OPAQUE */
   rec->color_clear = as <= 0x00ff;    /* CAIRO_COLOR_IS_CLEAR  */
+  rec->color_tag = 0;
+}
+
+/* The pixel a colour becomes (what set_color leaves in the primitives). */
+uint32_t
+flutl_recorder_pixel_of (double r, double g, double b, double a)
+{
+  r = clamp01 (r);
+  g = clamp01 (g);
+  b = clamp01 (b);
+  a = clamp01 (a);
+  uint16_t as = color_double_to_short (a);
+  uint16_t rs = color_double_to_short (r * a);
+  uint16_t gs = color_double_to_short (g * a);
+  uint16_t bs = color_double_to_short (b * a);
+  return ((uint32_t) (as >> 8) << 24) | ((uint32_t) (rs >> 8) << 16) |
+      ((uint32_t) (gs >> 8) << 8) | (uint32_t) (bs >> 8);
+}
+
+/* Colour tags: the element names the source of the colour it has just set (a
+ * colour attribute of a layout); every primitive remembers the tag it was drawn
+ * under.  A region whose layouts change in nothing but such colours is then the
+ * same primitives with other colour words (the element's region cache).
+ * set_color clears the tag. */
+void
+flutl_recorder_set_color_tag (FlutlRecorder *rec, uint16_t tag)
+{
+  rec->color_tag = tag;
+}
+
+uint16_t
+flutl_recorder_get_color_tag (FlutlRecorder *rec)
+{
+  return rec->color_tag;
+}
+
+const uint16_t *
+flutl_recorder_prim_tags (FlutlRecorder *rec)
+{
+  run_flush (rec);
+  return rec->prim_tags;
 }
 
 void
@@ -1066,6 +1113,10 @@ show_scaled_glyph (FlutlRecorder *rec, cairo_scaled_font_t *sf, uint32_t glyph, 
     rec->cap_run = rec->cap_run ? rec->cap_run * 2 : 64;
     rec->run = xrealloc (rec->run, rec->cap_run * sizeof (RunGlyph));
   }
+  if (rec->n_run == 0)
+    rec->run_tag = rec->color_tag;
+  else if (rec->run_tag != rec->color_tag)
+    rec->run_tag = 0xFFFF;      /* one colour from two sources */
   rec->run_pixel = rec->pixel;
   memcpy (rec->run_clip, c, sizeof c);
   RunGlyph *g = &rec->run[rec->n_run++];
@@ -2861,9 +2912,12 @@ flutl_recorder_replay (FlutlRecorder *rec, const flutl_prim *prims, uint32_t n_p
     while (rec->n_prims + n_prims > rec->cap_prims)
       rec->cap_prims = rec->cap_prims ? rec->cap_prims * 2 : 256;
     rec->prims = xrealloc (rec->prims, rec->cap_prims * sizeof (flutl_prim));
+    rec->prim_tags = xrealloc (rec->prim_tags, rec->cap_prims * sizeof (uint16_t));
   }
-  if (n_prims)                  /* (a region that recorded nothing replays nothing) */
+  if (n_prims) {                /* (a region that recorded nothing replays nothing) */
     memcpy (rec->prims + first, prims, n_prims * sizeof (flutl_prim));
+    memset (rec->prim_tags + first, 0, n_prims * sizeof (uint16_t));
+  }
   rec->n_prims += n_prims;
   if (region) {
     if (rec->n_regions == rec->cap_regions) {

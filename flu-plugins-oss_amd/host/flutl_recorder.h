@@ -59,6 +59,11 @@ void flutl_recorder_clip_reset (FlutlRecorder *rec);
 void flutl_recorder_set_color (FlutlRecorder *rec, double r, double g, double b,
     double a);
 void flutl_recorder_get_color (FlutlRecorder *rec, double rgba[4]);
+/* colour tags (see flutl_recorder.c): the source of the colour just set, kept per primitive */
+uint32_t flutl_recorder_pixel_of (double r, double g, double b, double a);
+void flutl_recorder_set_color_tag (FlutlRecorder *rec, uint16_t tag);
+uint16_t flutl_recorder_get_color_tag (FlutlRecorder *rec);
+const uint16_t *flutl_recorder_prim_tags (FlutlRecorder *rec);
 
 /* cairo_rectangle (x, y, w, h) + cairo_fill under the tracking context's CTM. */
 void flutl_recorder_fill_rect (FlutlRecorder *rec, double x, double y, double w,

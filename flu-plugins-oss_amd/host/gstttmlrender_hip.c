@@ -439,6 +439,7 @@ typedef struct
                               * that the element's property surface stays identical) */
   gboolean full_d2h;         /* FLUTL_FULL_D2H=1: whole-frame copies, writable memory */
   gboolean timing;           /* FLUTL_TIMING=1: host / device split on stderr at dispose */
+  gboolean timing_trace;     /* FLUTL_TIMING=2: ... and a line per buffer */
   gint64 t_record, t_device;
   gint64 t_first_return, t_last_return;   /* monotonic us: end of the first / last gen_buffer */
   guint n_timed;
@@ -450,6 +451,9 @@ typedef struct
   gboolean no_span_plans;    /* FLUTL_NO_SPAN_PLANS=1 */
   GPtrArray *region_cache;   /* RegionEntry *: recorded regions by what determines them */
   gboolean no_region_cache;  /* FLUTL_NO_REGION_CACHE=1 */
+  gboolean no_recolour;      /* FLUTL_NO_RECOLOUR=1: regions that differ in colours are recorded anew */
+  GArray *color_sources;     /* ColorSource: the colour attributes the region being recorded has drawn with */
+  guint region_recoloured;   /* statistics (FLUTL_TIMING) */
   guint region_hits, region_misses;
   guint skipped;             /* outlines of this buffer that could not be drawn */
   /* the finisher: buffers are handed out when their list is recorded; this thread
@@ -1371,6 +1375,110 @@ background_region (gpointer key, gpointer value, gpointer user_data)
  * its extra attributes and a few numbers; layouts are kept per document under
  * that key and shared (they are never modified after creation).  Returns FALSE
  * for paragraphs whose attributes are not plain data (anamorphic shapes). */
+/* A colour attribute of a paragraph as the draw loop meets it: foreground (1) or
+ * background (2) and the Pango colour the alpha travels in (smuggled_color). */
+typedef struct
+{
+  guint16 type, r, g, b;
+} ColorSource;
+
+/* What a layout is apart from its colours: its cache key with the colour values
+ * of the attribute records (par_add_attr) blanked, and those values in order.
+ * Two layouts of equal shape differ in nothing but colour attributes over the
+ * same ranges -- same text, fonts, breaks, glyph positions. */
+typedef struct
+{
+  guint8 *key;
+  gsize len;
+  guint64 hash;
+  ColorSource *colors;
+  guint n_colors;
+} LayoutShape;
+
+static void
+layout_shape_free (gpointer data)
+{
+  LayoutShape *sh = data;
+  g_free (sh->key);
+  g_free (sh->colors);
+  g_free (sh);
+}
+
+static GQuark
+layout_shape_quark (void)
+{
+  static GQuark q;
+  if (G_UNLIKELY (!q))
+    q = g_quark_from_static_string ("flutl-hip-layout-shape");
+  return q;
+}
+
+/* key: what layout_cache_key made (9 x gint32, the records, the markup) */
+static void
+layout_attach_shape (PangoLayout *layout, const GString *key)
+{
+  LayoutShape *sh = g_new0 (LayoutShape, 1);
+  gint32 rec_len;
+  guint64 h = 0xcbf29ce484222325ull;
+  sh->len = key->len;
+  sh->key = g_memdup (key->str, key->len);
+  memcpy (&rec_len, key->str + 8 * sizeof (gint32), sizeof rec_len);
+  sh->colors = g_new (ColorSource, rec_len / (6 * sizeof (gint32)) + 1);
+  for (gsize off = 9 * sizeof (gint32); off + 6 * sizeof (gint32) <= 9 * sizeof (gint32) + (gsize) rec_len;
+      off += 6 * sizeof (gint32)) {
+    gint32 rec[6];
+    memcpy (rec, sh->key + off, sizeof rec);
+    if (rec[0] == 1 || rec[0] == 2) {
+      ColorSource *c = &sh->colors[sh->n_colors++];
+      c->type = (guint16) rec[0];
+      c->r = (guint16) rec[3];
+      c->g = (guint16) rec[4];
+      c->b = (guint16) rec[5];
+      rec[3] = rec[4] = rec[5] = 0;
+      memcpy (sh->key + off, rec, sizeof rec);
+    }
+  }
+  /* ... and the colours of the markup (gst_ttml_style_gen_pango_markup,
+   * gstttmlstyle.c:160-170: fgcolor="#RRGGBB" unless white, bgcolor unless black;
+   * text is escaped, so a raw quote only ever belongs to the markup).  Pango makes
+   * 16-bit components of them by repeating the byte; the colour attributes above
+   * override them wherever the alpha is not 0. */
+  {
+    const gsize m0 = 9 * sizeof (gint32) + (gsize) rec_len;
+    guint n_markup = 0;
+    for (gsize i = m0; i + 18 <= sh->len; i++)
+      if (sh->key[i] == ' ' && (sh->key[i + 1] == 'f' || sh->key[i + 1] == 'b') &&
+          memcmp (sh->key + i + 2, "gcolor=\"#", 9) == 0 && sh->key[i + 17] == '"')
+        n_markup++;
+    sh->colors = g_renew (ColorSource, sh->colors, sh->n_colors + n_markup + 1);
+    for (gsize i = m0; i + 18 <= sh->len; i++) {
+      if (sh->key[i] != ' ' || (sh->key[i + 1] != 'f' && sh->key[i + 1] != 'b') ||
+          memcmp (sh->key + i + 2, "gcolor=\"#", 9) != 0 || sh->key[i + 17] != '"')
+        continue;
+      guint v[3];
+      gboolean ok = TRUE;
+      for (guint c = 0; c < 3; c++) {
+        const gint hi = g_ascii_xdigit_value (sh->key[i + 11 + 2 * c]);
+        const gint lo = g_ascii_xdigit_value (sh->key[i + 12 + 2 * c]);
+        ok = ok && hi >= 0 && lo >= 0;
+        v[c] = (guint) (hi * 16 + lo);
+      }
+      if (!ok)
+        continue;
+      ColorSource *c = &sh->colors[sh->n_colors++];
+      c->type = sh->key[i + 1] == 'f' ? 1 : 2;
+      c->r = (guint16) (v[0] << 8 | v[0]);
+      c->g = (guint16) (v[1] << 8 | v[1]);
+      c->b = (guint16) (v[2] << 8 | v[2]);
+      memset (sh->key + i + 11, '0', 6);
+    }
+  }
+  for (gsize i = 0; i < sh->len; i++)
+    h = (h ^ sh->key[i]) * 0x100000001b3ull;
+  sh->hash = h;
+  g_object_set_qdata_full (G_OBJECT (layout), layout_shape_quark (), sh, layout_shape_free);
+}
+
 static gboolean
 layout_cache_key (GString *key, PangoContext *ctx, HipRegion *r, gint w, gint h,
     gboolean wrap, PangoAlignment align, gint spacing)
@@ -1510,6 +1618,7 @@ region_flush_paragraph (GstTTMLRender *render, HipRegion *r)
   }
 
   if (key) {
+    layout_attach_shape (layout, key);
     if (!priv->layouts)
       priv->layouts = g_hash_table_new_full (layout_key_hash, layout_key_equal, layout_key_free,
           g_object_unref);
@@ -1543,6 +1652,36 @@ set_smuggled_source (FlutlRecorder *rec, const PangoColor *c)
    * full 16 bits / 65535, alpha is the low byte of red / 255 */
   flutl_recorder_set_color (rec, (c->red & 0xFF00) / 65280.0, c->green / 65535.0,
       c->blue / 65535.0, (c->red & 0x00FF) / 255.0);
+}
+
+static guint32
+smuggled_pixel (const ColorSource *c)
+{
+  return flutl_recorder_pixel_of ((c->r & 0xFF00) / 65280.0, c->g / 65535.0, c->b / 65535.0,
+      (c->r & 0x00FF) / 255.0);
+}
+
+/* ... and the primitives drawn from here on say which colour attribute of the
+ * region they took their colour from (1-based into priv->color_sources) */
+static void
+set_attr_source (GstTTMLRender *render, FlutlRecorder *rec, guint16 type, const PangoColor *c)
+{
+  GstTTMLRenderPrivate *priv = get_priv (render);
+  GArray *a = priv->color_sources;
+  guint i;
+  set_smuggled_source (rec, c);
+  if (!a)
+    a = priv->color_sources = g_array_new (FALSE, FALSE, sizeof (ColorSource));
+  for (i = 0; i < a->len; i++) {
+    const ColorSource *s = &g_array_index (a, ColorSource, i);
+    if (s->type == type && s->r == c->red && s->g == c->green && s->b == c->blue)
+      break;
+  }
+  if (i == a->len) {
+    ColorSource s = { type, c->red, c->green, c->blue };
+    g_array_append_val (a, s);
+  }
+  flutl_recorder_set_color_tag (rec, (guint16) MIN (i + 1, 0xFFFF));
 }
 
 static void
@@ -1625,24 +1764,27 @@ walk_layout (GstTTMLRender *render, FlutlRecorder *rec, PangoLayout *layout,
       width /= PANGO_SCALE;
       stack[1] = m;
       double saved_color[4];
+      const guint16 saved_tag = flutl_recorder_get_color_tag (rec);
       flutl_recorder_get_color (rec, saved_color);
 
       /* pass 1: colours and span background */
       for (al = run->item->analysis.extra_attrs; al; al = al->next) {
         PangoAttribute *attr = al->data;
         if (attr->klass->type == PANGO_ATTR_FOREGROUND) {
-          set_smuggled_source (rec, &((PangoAttrColor *) attr)->color);
+          set_attr_source (render, rec, 1, &((PangoAttrColor *) attr)->color);
         } else if (attr->klass->type == PANGO_ATTR_BACKGROUND) {
           double keep[4];
+          const guint16 keep_tag = flutl_recorder_get_color_tag (rec);
           if (!show_background)
             continue;
           CTM_SYNC ();
           if (!fill)
             flutl_recorder_stroke (rec);   /* flush the outline path so far */
           flutl_recorder_get_color (rec, keep);
-          set_smuggled_source (rec, &((PangoAttrColor *) attr)->color);
+          set_attr_source (render, rec, 2, &((PangoAttrColor *) attr)->color);
           flutl_recorder_fill_rect (rec, 0, -pre, width, pre + post);
           flutl_recorder_set_color (rec, keep[0], keep[1], keep[2], keep[3]);
+          flutl_recorder_set_color_tag (rec, keep_tag);
         } else if (attr->klass == &hip_attr_klass[HIP_ATTR_REVERSE]) {
           reverse = TRUE;
         }
@@ -1730,6 +1872,7 @@ walk_layout (GstTTMLRender *render, FlutlRecorder *rec, PangoLayout *layout,
       /* (restoring the context also restores the source colour) */
       flutl_recorder_set_color (rec, saved_color[0], saved_color[1], saved_color[2],
           saved_color[3]);
+      flutl_recorder_set_color_tag (rec, saved_tag);
       CTM_TRANSLATE (width, 0);
     }
     m = stack[0];
@@ -2098,6 +2241,13 @@ typedef struct
   flutl_region region;
   gint clear_out;
   guint32 unsupported;
+  /* for playing it back in other colours: per primitive the colour attribute it
+   * was drawn under (1-based into sources, 0 none), and the key without colours */
+  guint16 *tags;
+  ColorSource *sources;
+  guint n_sources;
+  guint64 shape_hash;
+  gboolean recolourable;
 } RegionEntry;
 
 static void
@@ -2108,6 +2258,8 @@ region_entry_free (gpointer data)
     g_object_unref (e->layouts[i]);
   g_free (e->layouts);
   g_free (e->prims);
+  g_free (e->tags);
+  g_free (e->sources);
   g_free (e);
 }
 
@@ -2139,13 +2291,148 @@ region_key_fill (RegionKey *k, const HipRegion *r, FlutlRecorder *rec, gint w, g
 }
 
 static void
+region_replay (GstTTMLRender *render, const HipRegion *r, const RegionEntry *e,
+    const flutl_prim *prims)
+{
+  FlutlRecorder *rec = get_priv (render)->rec;
+  if (r->writing_mode == GST_TTML_WRITING_MODE_TBRL ||
+      r->writing_mode == GST_TTML_WRITING_MODE_TBLR) {
+    pango_context_set_base_gravity (render->pango_context, PANGO_GRAVITY_EAST);
+    pango_context_set_gravity_hint (render->pango_context, PANGO_GRAVITY_HINT_STRONG);
+    pango_cairo_update_context (flutl_recorder_cairo (rec), render->pango_context);
+  }
+  flutl_recorder_replay (rec, prims, e->n_prims, e->has_region ? &e->region : NULL,
+      e->clear_out, e->unsupported);
+}
+
+static RegionEntry *
+region_entry_new (GstTTMLRenderPrivate *priv, const HipRegion *r, const RegionKey *key,
+    guint64 hash, guint64 shape_hash, const flutl_prim *prims, guint32 n_prims,
+    const flutl_region *region, gint clear_out, guint32 unsupported)
+{
+  RegionEntry *e;
+  GList *l;
+  guint i;
+  if (priv->region_cache->len >= 256)           /* bound it: start over */
+    g_ptr_array_set_size (priv->region_cache, 0);
+  e = g_new0 (RegionEntry, 1);
+  e->key = *key;
+  e->hash = hash;
+  e->shape_hash = shape_hash;
+  e->layouts = g_new (PangoLayout *, key->n_layouts + 1);
+  for (l = r->layouts, i = 0; l; l = l->next)
+    e->layouts[i++] = g_object_ref (l->data);
+  e->prims = g_memdup (prims, n_prims * sizeof *prims);
+  e->n_prims = n_prims;
+  e->has_region = region != NULL;
+  if (region)
+    e->region = *region;
+  e->clear_out = clear_out;
+  e->unsupported = unsupported;
+  g_ptr_array_add (priv->region_cache, e);
+  return e;
+}
+
+/* r is e's region but for colours of its layouts?  Then e's primitives in r's
+ * colours are what recording r would give: a colour reaches a primitive as its
+ * colour word and through two flags, opaque and clear (flutl_recorder_set_color),
+ * which follow from the alpha and choose the compositing rule -- so only colours
+ * of the same class (opaque, translucent, clear) are exchanged.
+ * The colours are matched by value: two attributes of one colour may have fed
+ * one glyph run, so they must also end up in one colour. */
+static gboolean
+region_recolour (GstTTMLRender *render, HipRegion *r, RegionEntry *e, const RegionKey *key,
+    guint64 hash, guint64 shape_hash)
+{
+  GstTTMLRenderPrivate *priv = get_priv (render);
+  ColorSource to[64];
+  gboolean mapped[64] = { FALSE };
+  flutl_prim *prims;
+  RegionEntry *n;
+  GList *l;
+  guint k = 0, i, j;
+  /* (e itself may go when the new entry is made: the cache starts over when full) */
+  const guint32 n_prims = e->n_prims, unsupported = e->unsupported;
+  const guint n_sources = e->n_sources;
+  const gboolean has_region = e->has_region;
+  const flutl_region region = e->region;
+  const gint clear_out = e->clear_out;
+  guint16 *tags;
+  ColorSource *sources;
+
+  if (n_sources > G_N_ELEMENTS (to))
+    return FALSE;
+  for (l = r->layouts; l; l = l->next, k++) {
+    const LayoutShape *so = g_object_get_qdata (G_OBJECT (e->layouts[k]), layout_shape_quark ());
+    const LayoutShape *sn = g_object_get_qdata (l->data, layout_shape_quark ());
+    if (!so || !sn)
+      return FALSE;
+    if (so != sn && (so->hash != sn->hash || so->len != sn->len ||
+            so->n_colors != sn->n_colors || memcmp (so->key, sn->key, so->len) != 0))
+      return FALSE;
+    /* Pango merges adjoining attributes of one value (pango_attr_list_change), and
+     * which of two attributes over one range wins then depends on what was merged:
+     * the colours may change, not which of them are alike -- among the attributes
+     * and the markup's colours both (fuzz seed 510070: a span whose <set> ended took
+     * its paragraph's colour, its attribute went into the paragraph's, and the span
+     * of the markup showed through). */
+    if (so != sn)
+      for (i = 0; i < so->n_colors; i++)
+        for (j = i + 1; j < so->n_colors; j++)
+          if ((memcmp (&so->colors[i], &so->colors[j], sizeof (ColorSource)) == 0) !=
+              (memcmp (&sn->colors[i], &sn->colors[j], sizeof (ColorSource)) == 0))
+            return FALSE;
+    for (i = 0; i < so->n_colors; i++) {
+      const ColorSource *co = &so->colors[i], *cn = &sn->colors[i];
+      /* (the alpha, k / 255: Cairo's "opaque" is k == 255, "clear" k == 0.  Whether
+       * or not anything was drawn in it: a clear colour draws nothing and drops
+       * the pending path, and k17's regions found that out) */
+      if (((co->r & 0xFF) == 0xFF) != ((cn->r & 0xFF) == 0xFF) ||
+          ((co->r & 0xFF) == 0) != ((cn->r & 0xFF) == 0))
+        return FALSE;           /* opaque / translucent / clear: another rule */
+      /* (every source of that value: an earlier exchange may have made two alike;
+       * none: nothing was drawn in it -- a colour of the markup under an attribute,
+       * a clear one, the run of a line break) */
+      for (j = 0; j < n_sources; j++) {
+        if (memcmp (&e->sources[j], co, sizeof *co) != 0)
+          continue;
+        if (mapped[j] && memcmp (&to[j], cn, sizeof *cn) != 0)
+          return FALSE;         /* one colour then, two now */
+        mapped[j] = TRUE;
+        to[j] = *cn;
+      }
+    }
+  }
+  prims = g_memdup (e->prims, n_prims * sizeof *prims);
+  tags = g_memdup (e->tags, n_prims * sizeof *tags);
+  sources = g_memdup (e->sources, n_sources * sizeof *sources);
+  for (j = 0; j < n_sources; j++)
+    if (mapped[j])
+      sources[j] = to[j];
+  for (i = 0; i < n_prims; i++)
+    if (tags[i] && mapped[tags[i] - 1])
+      prims[i].color = smuggled_pixel (&to[tags[i] - 1]);
+  region_replay (render, r, e, prims);
+  /* ... and it is a region of its own from now on */
+  n = region_entry_new (priv, r, key, hash, shape_hash, prims, n_prims,
+      has_region ? &region : NULL, clear_out, unsupported);
+  n->recolourable = TRUE;
+  n->tags = tags;
+  n->sources = sources;
+  n->n_sources = n_sources;
+  g_free (prims);
+  return TRUE;
+}
+
+static void
 record_region (HipRegion *r, GstTTMLRender *render)
 {
   GstTTMLRenderPrivate *priv = get_priv (render);
   FlutlRecorder *rec = priv->rec;
   RegionKey key;
   RegionEntry *e;
-  guint64 hash = 0xcbf29ce484222325ull;
+  guint64 hash = 0xcbf29ce484222325ull, shape_hash;
+  gboolean all_shapes = TRUE;
   guint32 prim_mark, region_mark, n_prims, unsupported_before;
   const flutl_region *region;
   const flutl_prim *prims;
@@ -2167,8 +2454,13 @@ record_region (HipRegion *r, GstTTMLRender *render)
       render->base.state.frame_height);
   for (i = 0; i < sizeof key / sizeof (guint32); i++)
     hash = (hash ^ ((const guint32 *) &key)[i]) * 0x100000001b3ull;
-  for (l = r->layouts; l; l = l->next)
+  shape_hash = hash;
+  for (l = r->layouts; l; l = l->next) {
+    const LayoutShape *sh = g_object_get_qdata (l->data, layout_shape_quark ());
     hash = (hash ^ (guint64) (guintptr) l->data) * 0x100000001b3ull;
+    shape_hash = (shape_hash ^ (sh ? sh->hash : (guint64) (guintptr) l->data)) * 0x100000001b3ull;
+    all_shapes = all_shapes && sh != NULL;
+  }
   if (!priv->region_cache)
     priv->region_cache = g_ptr_array_new_with_free_func (region_entry_free);
   for (i = 0; i < priv->region_cache->len; i++) {
@@ -2183,21 +2475,29 @@ record_region (HipRegion *r, GstTTMLRender *render)
     /* the same region as before: its primitives, and what recording it does to
      * the shared Pango context (the reference switches it to east gravity for the
      * vertical writing modes and never back, :1313-1340) */
-    if (r->writing_mode == GST_TTML_WRITING_MODE_TBRL ||
-        r->writing_mode == GST_TTML_WRITING_MODE_TBLR) {
-      pango_context_set_base_gravity (render->pango_context, PANGO_GRAVITY_EAST);
-      pango_context_set_gravity_hint (render->pango_context, PANGO_GRAVITY_HINT_STRONG);
-      pango_cairo_update_context (flutl_recorder_cairo (rec), render->pango_context);
-    }
-    flutl_recorder_replay (rec, e->prims, e->n_prims, e->has_region ? &e->region : NULL,
-        e->clear_out, e->unsupported);
+    region_replay (render, r, e, e->prims);
     priv->region_hits++;
     return;
   }
+  /* the same region in other colours (a <set> on tts:color / tts:backgroundColor
+   * of a span -- the one thing most scene states of a subtitle differ in): the
+   * primitives of the earlier one with other colour words */
+  if (all_shapes && !priv->no_recolour)
+    for (i = 0; i < priv->region_cache->len; i++) {
+      e = g_ptr_array_index (priv->region_cache, i);
+      if (!e->recolourable || e->shape_hash != shape_hash || memcmp (&e->key, &key, sizeof key) != 0)
+        continue;
+      if (region_recolour (render, r, e, &key, hash, shape_hash)) {
+        priv->region_recoloured++;
+        return;
+      }
+    }
   priv->region_misses++;
   flutl_recorder_mark (rec, &prim_mark, &region_mark);
   unsupported_before = flutl_recorder_unsupported (rec);
   skipped_before = priv->skipped;
+  if (priv->color_sources)
+    g_array_set_size (priv->color_sources, 0);
   {
     gint64 t0 = priv->timing ? g_get_monotonic_time () : 0;
     record_region_body (r, render);
@@ -2208,22 +2508,27 @@ record_region (HipRegion *r, GstTTMLRender *render)
       &has_placeholder);
   if (has_placeholder || priv->skipped != skipped_before)
     return;                     /* not final yet (a mask is still being made), or failed */
-  if (priv->region_cache->len >= 256)           /* bound it: start over */
-    g_ptr_array_set_size (priv->region_cache, 0);
-  e = g_new0 (RegionEntry, 1);
-  e->key = key;
-  e->hash = hash;
-  e->layouts = g_new (PangoLayout *, key.n_layouts + 1);
-  for (l = r->layouts, i = 0; l; l = l->next)
-    e->layouts[i++] = g_object_ref (l->data);
-  e->prims = g_memdup (prims, n_prims * sizeof *prims);
-  e->n_prims = n_prims;
-  e->has_region = region != NULL;
-  if (region)
-    e->region = *region;
-  e->clear_out = flutl_recorder_frame_is_clear (rec);
-  e->unsupported = flutl_recorder_unsupported (rec) - unsupported_before;
-  g_ptr_array_add (priv->region_cache, e);
+  e = region_entry_new (priv, r, &key, hash, shape_hash, prims, n_prims, region,
+      flutl_recorder_frame_is_clear (rec), flutl_recorder_unsupported (rec) - unsupported_before);
+  /* (blurred outlines are images made of the text in its colours) */
+  e->recolourable = all_shapes &&
+      r->outline.length[1].unit == GST_TTML_LENGTH_UNIT_NOT_PRESENT;
+  e->tags = g_memdup (flutl_recorder_prim_tags (rec) + prim_mark, n_prims * sizeof (guint16));
+  for (i = 0; i < n_prims; i++)
+    if (e->tags[i] == 0xFFFF || (priv->color_sources && e->tags[i] > priv->color_sources->len))
+      e->recolourable = FALSE;  /* (one glyph run in one colour from two attributes) */
+  if (priv->color_sources && priv->color_sources->len) {
+    e->n_sources = priv->color_sources->len;
+    e->sources = g_memdup (priv->color_sources->data, e->n_sources * sizeof (ColorSource));
+    /* (a colour that was set but drew nothing -- the run of a line break -- is no
+     * source: type 0 matches no attribute) */
+    for (guint j = 0; j < e->n_sources; j++) {
+      for (i = 0; i < n_prims && e->tags[i] != j + 1; i++)
+        ;
+      if (i == n_prims)
+        e->sources[j].type = 0;
+    }
+  }
 }
 
 /* ---- device side -------------------------------------------------------------- */
@@ -2252,26 +2557,46 @@ static gboolean
 flush_atlas (GstTTMLRender *render)
 {
   GstTTMLRenderPrivate *priv = get_priv (render);
-  const uint32_t *off, *size;
-  size_t atlas_size;
-  const uint8_t *atlas;
+  const uint32_t *off_, *size_;
+  uint32_t *off, *size;
   uint32_t i, n;
   gboolean ok = TRUE;
+  const gint64 t_flush0 = g_get_monotonic_time ();
   /* (the streaming thread may be adding glyph masks: entries are uploaded in
-   * the order they were given their offsets, whichever frame they belong to) */
+   * the order they were given their offsets, whichever frame they belong to.
+   * The recorder is locked entry by entry -- its atlas may move when it grows --
+   * not for the whole upload: the first frame of a cue brings megabytes of
+   * outline masks, and the streaming thread recording the next buffer needs the
+   * recorder too.  Calls do not overlap: the finisher makes them, or the
+   * streaming thread when the finisher has nothing in flight.) */
   flutl_recorder_lock (priv->rec);
-  atlas = flutl_recorder_atlas (priv->rec, &atlas_size);
-  n = flutl_recorder_new_atlas_entries (priv->rec, &off, &size);
+  n = flutl_recorder_new_atlas_entries (priv->rec, &off_, &size_);
+  off = g_memdup (off_, n * sizeof *off);
+  size = g_memdup (size_, n * sizeof *size);
+  flutl_recorder_unlock (priv->rec);
   for (i = 0; i < n && ok; i++) {
     uint32_t dev_off = 0;
-    int rc = flutl_atlas_put (priv->ctx, atlas + off[i], size[i], &dev_off);
+    size_t atlas_size;
+    int rc;
+    flutl_recorder_lock (priv->rec);
+    rc = flutl_atlas_put (priv->ctx, flutl_recorder_atlas (priv->rec, &atlas_size) + off[i],
+        size[i], &dev_off);
+    flutl_recorder_unlock (priv->rec);
     if (rc != FLUTL_OK || dev_off != off[i]) {
       GST_ELEMENT_ERROR (render, LIBRARY, FAILED, ("ttmlrender: atlas upload failed"),
           ("flutl_atlas_put: %s (offset %u vs %u)", flutl_strerror (rc), dev_off, off[i]));
       ok = FALSE;
     }
   }
-  flutl_recorder_unlock (priv->rec);
+  if (priv->timing_trace && n) {
+    guint64 bytes = 0;
+    for (i = 0; i < n; i++)
+      bytes += size[i];
+    g_printerr ("ttmlrender-hip atlas flush: %u entries, %" G_GUINT64_FORMAT " bytes, %" G_GINT64_FORMAT
+        " us\n", n, bytes, g_get_monotonic_time () - t_flush0);
+  }
+  g_free (off);
+  g_free (size);
   return ok;
 }
 
@@ -2665,6 +2990,11 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
     gint64 t_end = g_get_monotonic_time ();
     /* (averages from the second buffer on, like the span: the first one makes
      * every mask of the document) */
+    if (priv->timing_trace)     /* FLUTL_TIMING=2: one line per buffer */
+      g_printerr ("ttmlrender-hip buffer %u: record_us=%" G_GINT64_FORMAT " device_us=%"
+          G_GINT64_FORMAT " hits=%u recoloured=%u misses=%u\n", priv->n_timed,
+          t_recorded - t_start, t_end - t_recorded, priv->region_hits, priv->region_recoloured,
+          priv->region_misses);
     if (priv->n_timed++ == 0) {
       priv->t_first_return = t_end;
     } else {
@@ -2802,7 +3132,7 @@ timing_report (GstTTMLRender *render)
   }
   g_printerr ("ttmlrender-hip timing: buffers=%u record_us=%.1f device_us=%.1f "
       "span_us=%" G_GINT64_FORMAT " drained_us=%" G_GINT64_FORMAT " delta_bytes=%.0f "
-      "deferred=%u resolve_wait_us=%.1f atlas_upload_us=%.1f build_us=%.1f layout_us=%.1f region_hits=%u region_misses=%u strokes=%u stroke_us=%.0f stroke_queued_us=%.0f pure_wait_us=%.0f submit_us=%.1f push_block_us=%.1f runs_merged=%u runs_clashed=%u path_us=%.0f extents_us=%.0f miss_us=%.1f\n",
+      "deferred=%u resolve_wait_us=%.1f atlas_upload_us=%.1f build_us=%.1f layout_us=%.1f region_hits=%u region_misses=%u strokes=%u stroke_us=%.0f stroke_queued_us=%.0f pure_wait_us=%.0f submit_us=%.1f push_block_us=%.1f runs_merged=%u runs_clashed=%u path_us=%.0f extents_us=%.0f miss_us=%.1f recoloured=%u\n",
       priv->n_timed, (double) priv->t_record / MAX (priv->n_timed - 1, 1),
       (double) (priv->t_device + priv->t_submit) / MAX (priv->n_timed - 1, 1),
       priv->t_last_return - priv->t_first_return,
@@ -2817,9 +3147,9 @@ timing_report (GstTTMLRender *render)
       (double) priv->t_submit / MAX (priv->n_deferred, 1),
       (double) priv->t_push_block / MAX (priv->n_deferred, 1), rm, rc_,
       sj ? (double) pp / sj : 0.0, sj ? (double) pe / sj : 0.0,
-      (double) priv->t_miss / MAX (priv->n_timed - 1, 1));
+      (double) priv->t_miss / MAX (priv->n_timed - 1, 1), priv->region_recoloured);
   priv->t_push_block = 0;
-  priv->region_hits = priv->region_misses = 0;
+  priv->region_hits = priv->region_misses = priv->region_recoloured = 0;
   priv->n_timed = priv->n_deferred = 0;
   priv->t_record = priv->t_device = priv->t_submit = priv->t_flush = priv->t_resolve = 0;
   priv->t_build = priv->t_layout = priv->t_miss = 0;
@@ -2893,6 +3223,10 @@ gst_ttmlrender_dispose (GObject *object)
   if (priv->region_cache) {
     g_ptr_array_unref (priv->region_cache);
     priv->region_cache = NULL;
+  }
+  if (priv->color_sources) {
+    g_array_unref (priv->color_sources);
+    priv->color_sources = NULL;
   }
   g_free (priv->blank);
   priv->blank = NULL;
@@ -3231,6 +3565,7 @@ gst_ttmlrender_init (GstTTMLRender *render)
   priv->dump_only = g_getenv ("FLUTL_DUMP_ONLY") != NULL;
   priv->dump_defer = g_getenv ("FLUTL_DUMP_DEFER") != NULL;
   priv->timing = g_getenv ("FLUTL_TIMING") != NULL;
+  priv->timing_trace = priv->timing && atoi (g_getenv ("FLUTL_TIMING")) >= 2;
   priv->full_d2h = g_getenv ("FLUTL_FULL_D2H") != NULL;
   priv->atlas_limit = (gsize) (g_getenv ("FLUTL_ATLAS_LIMIT_MB")
       ? MAX (1, atoi (g_getenv ("FLUTL_ATLAS_LIMIT_MB"))) : 256) << 20;
@@ -3256,5 +3591,6 @@ gst_ttmlrender_init (GstTTMLRender *render)
   g_cond_init (&priv->flight_cond);
   priv->no_layout_cache = g_getenv ("FLUTL_NO_LAYOUT_CACHE") != NULL;
   priv->no_region_cache = g_getenv ("FLUTL_NO_REGION_CACHE") != NULL;
+  priv->no_recolour = g_getenv ("FLUTL_NO_RECOLOUR") != NULL;
   priv->no_span_plans = g_getenv ("FLUTL_NO_SPAN_PLANS") != NULL;
 }

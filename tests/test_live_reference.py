@@ -93,3 +93,43 @@ def test_outlines_stroked_on_worker_threads_are_the_reference_s(ttml, tmp_path):
         import pyflutl as F
         assert F.validate(W, H, R, P, pk.atlas.size) == 0
         assert np.array_equal(O.render(W, H, R, P, pk.atlas), z["frames"][i]), i
+
+
+RECOLOURED = [s for s in SCENES if os.path.basename(s)[:3] in ("k06", "k17", "k18")]
+
+
+@pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
+                    reason="fluttml-hip plugin / GStreamer runtime not present")
+@pytest.mark.parametrize("ttml", RECOLOURED, ids=[os.path.basename(s)[:-5] for s in RECOLOURED])
+def test_regions_played_back_in_other_colours_are_the_reference_s(ttml, tmp_path):
+    """A region whose layouts differ from a cached one in colours only is played back
+    from that one's primitives with other colour words (region_recolour).  Recorded
+    with and without that (FLUTL_NO_RECOLOUR=1), both lists must composite -- through
+    the oracle -- to the REFERENCE's frames; k18 is made of the cases that may and
+    may not be exchanged, and must really exchange some."""
+    import re
+    import subprocess
+    import oracle_lib as O
+    import pyflutl as F
+    z = np.load(ttml[:-5] + ".npz")
+    W, H = int(z["width"]), int(z["height"])
+    for extra in ({}, {"FLUTL_NO_RECOLOUR": "1"}):
+        pk = scene_pack.load(gstenv.dump_pack(ttml, W, H, str(tmp_path / "p.flpk"),
+                                              extra_env=extra))
+        st = pk.states()
+        assert len(st) == int(z["n_states"])
+        for i, (R, P) in enumerate(st):
+            assert F.validate(W, H, R, P, pk.atlas.size) == 0
+            assert np.array_equal(O.render(W, H, R, P, pk.atlas), z["frames"][i]), (extra, i)
+    if os.path.basename(ttml).startswith("k18"):
+        counts = {}
+        for extra in ({}, {"FLUTL_NO_RECOLOUR": "1"}):
+            env = gstenv.env_for(gstenv.HIP_PLUGIN_DIR, dict(
+                extra, FLUTL_TIMING="1", FLUTL_DUMP_ONLY="1", FLUTL_DUMP_PACK=os.devnull))
+            r = subprocess.run([os.path.join(gstenv.CONDA, "bin", "gst-launch-1.0"), "-q",
+                                "filesrc", f"location={ttml}", "!", "ttmlrender", "!",
+                                f"video/x-raw,width={W},height={H}", "!", "fakesink"],
+                               env=env, capture_output=True, text=True, cwd=str(tmp_path))
+            assert r.returncode == 0, r.stderr[-800:]
+            counts[bool(extra)] = int(re.search(r"recoloured=(\d+)", r.stderr).group(1))
+        assert counts[False] >= 3 and counts[True] == 0, counts

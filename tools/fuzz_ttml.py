@@ -23,6 +23,27 @@ FAMS = ["DejaVu Sans", "DejaVu Serif", "DejaVu Sans Mono", "sansSerif", "serif",
         "default"]
 
 
+# FUZZ_SETS=1: colour animations inside paragraphs and spans (<set> on tts:color /
+# tts:backgroundColor, several per element, alphas of every class): what the element's
+# region cache plays back in other colours instead of recording anew
+SETS = bool(os.environ.get("FUZZ_SETS"))
+
+
+def color_sets(r):
+    if not SETS or r.random() < 0.35:
+        return ""
+    out = ""
+    for _ in range(r.randrange(1, 3)):
+        attr = r.choice(["tts:color", "tts:color", "tts:backgroundColor"])
+        t = r.choice([0.0, 0.25, 0.5])
+        # mostly opaque -> opaque (the common case), sometimes across alpha classes
+        alpha = 255 if r.random() < 0.6 else None
+        for k in range(r.randrange(1, 5)):
+            out += f'<set begin="{t:.2f}s" end="{t + 0.25:.2f}s" {attr}="{col(r, alpha)}"/>'
+            t += r.choice([0.25, 0.25, 0.5])
+    return out
+
+
 # FUZZ_E2E=1 (GPU box): the element renders for real and its frames are compared with
 # the reference's byte for byte -- kernel, read-back and device-made atlas entries
 # included; only then are blurred outlines generated (they need the device)
@@ -134,7 +155,7 @@ def gen(seed):
             body = ""
             for _ in range(r.randrange(1, 4)):
                 if r.random() < 0.5:
-                    body += f'<span {span_style(r)}>{text(r, r.randrange(1, 4))}</span> '
+                    body += f'<span {span_style(r)}>{color_sets(r)}{text(r, r.randrange(1, 4))}</span> '
                 else:
                     body += text(r, r.randrange(1, 4)) + " "
                 if r.random() < 0.2:
@@ -142,7 +163,7 @@ def gen(seed):
             st = span_style(r)
             if "tts:fontSize" not in st:
                 st += f' tts:fontSize="{r.randrange(12, 30)}px"'
-            ps.append(f'  <p region="r{i}" begin="{t0}s" end="{t1}s" {st}>{body}</p>')
+            ps.append(f'  <p region="r{i}" begin="{t0}s" end="{t1}s" {st}>{color_sets(r)}{body}</p>')
     # The reference reads an uninitialised pointer when a paragraph holds BOTH an
     # anamorphic font size and text that breaks its Pango markup (a raw '&':
     # pango_parse_markup fails and leaves pango_attr_list unset,
