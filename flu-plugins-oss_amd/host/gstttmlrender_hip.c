@@ -474,6 +474,7 @@ typedef struct
   GMutex flight_lock;
   GCond flight_cond;
   guint in_flight;
+  guint waiting_in_flight;   /* ... of which wait for masks made on worker threads */
   gint64 t_submit, t_flush, t_resolve;   /* (finisher's clocks, read when it is idle) */
   gint64 t_build, t_layout;  /* parts of t_record: spans -> regions, paragraphs -> layouts */
   gint64 t_miss;             /* ... and recording the regions the region cache did not have */
@@ -2666,12 +2667,15 @@ finisher_main (gpointer data)
     ticket_complete (job->ticket, rc);
     ticket_unref (job->ticket);
     gst_memory_unref (job->mem);
+    const gboolean waited = job->n_patches > 0;
     g_free (job->regions);
     g_free (job->prims);
     g_free (job->patches);
     g_free (job);
     g_mutex_lock (&priv->flight_lock);
     priv->in_flight--;
+    if (waited)
+      priv->waiting_in_flight--;
     g_cond_broadcast (&priv->flight_cond);
     g_mutex_unlock (&priv->flight_lock);
   }
@@ -2743,7 +2747,12 @@ pipeline_push (GstTTMLRender *render, gint width, gint height, const flutl_regio
   job->ticket = ticket_ref (ticket);
   if (!priv->finisher)
     priv->finisher = g_thread_new ("ttmlrender-finish", finisher_main, render);
-  const guint ahead = run_ahead (priv, width, height);
+  /* (as far ahead as the pool goes for frames that wait for outlines: the point is
+   * to get to the next outline early.  A complete frame behind them gains nothing
+   * from depth, and every further pool frame in use is one more whose first
+   * write-back is a whole frame over PCIe, a millisecond at 4K: 3 of those) */
+  const guint ahead = n_patches ? run_ahead (priv, width, height)
+                                : MIN (run_ahead (priv, width, height), 3);
   g_mutex_lock (&priv->flight_lock);
   if (priv->in_flight >= ahead) {
     const gint64 t_b = g_get_monotonic_time ();
@@ -2752,6 +2761,8 @@ pipeline_push (GstTTMLRender *render, gint width, gint height, const flutl_regio
     priv->t_push_block += g_get_monotonic_time () - t_b;
   }
   priv->in_flight++;
+  if (n_patches)
+    priv->waiting_in_flight++;
   g_mutex_unlock (&priv->flight_lock);
   g_async_queue_push (priv->jobs, job);
 }
@@ -2920,7 +2931,13 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
     uint32_t n_deferred = 0;
     (void) flutl_recorder_patches (rec, &n_deferred);
     g_mutex_lock (&priv->flight_lock);
-    const gboolean finisher_idle = priv->in_flight == 0;
+    /* (running ahead of the finisher pays while it waits for outlines; once
+     * the frames in its queue only need queueing on the device, a frame that is
+     * complete waits for them -- some tens of microseconds each -- and goes
+     * straight to the device again.  Frames that run ahead take pool frames
+     * many buffers old, and what differs from those is what crosses PCIe.) */
+    const gboolean finisher_idle = priv->in_flight == 0 ||
+        (priv->waiting_in_flight == 0 && n_deferred == 0 && !priv->queue_always);
     g_mutex_unlock (&priv->flight_lock);
     /* (a frame with all its masks there, and nothing ahead of it: queued on the
      * device right here -- a thread hop would only cost) */
