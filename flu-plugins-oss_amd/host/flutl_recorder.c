@@ -1470,10 +1470,27 @@ hexbox_show (FlutlRecorder *rec, PangoFont *font, const PangoGlyphInfo *gi)
   for (int row = 0; row < rows; row++) {
     const double y = y0 - (rows - 1 - row) * (hb->digit_height + hb->pad_y);
     for (int col = 0; col < cols; col++) {
-      const double x = x0 + col * (hb->digit_width + hb->pad_x);
+      /* cairo_move_to keeps the point in device space as 24.8 fixed point, and
+       * cairo_show_text asks for it back (cairo_get_current_point: through the
+       * inverse CTM): the digit sits on a 1/256 px grid, which decides the pixel
+       * it is rounded to when that grid point is n + 1/2 -- one digit in 256, or
+       * every second column at some sizes (fuzz seed 560001, scale 2: the right
+       * digits one pixel off under a vertical writing mode) */
+      double x = x0 + col * (hb->digit_width + hb->pad_x), yy = y;
+      {
+        cairo_matrix_t m, inv;
+        cairo_get_matrix (rec->cr, &m);
+        inv = m;
+        if (cairo_matrix_invert (&inv) == CAIRO_STATUS_SUCCESS) {
+          cairo_matrix_transform_point (&m, &x, &yy);
+          x = fixed_from_double (x) / 256.0;
+          yy = fixed_from_double (yy) / 256.0;
+          cairo_matrix_transform_point (&inv, &x, &yy);
+        }
+      }
       cairo_glyph_t *glyphs = NULL;
       int n = 0;
-      if (cairo_scaled_font_text_to_glyphs (smini, x, y, &buf[row * cols + col], 1, &glyphs,
+      if (cairo_scaled_font_text_to_glyphs (smini, x, yy, &buf[row * cols + col], 1, &glyphs,
               &n, NULL, NULL, NULL) != CAIRO_STATUS_SUCCESS)
         continue;
       for (int k = 0; k < n; k++)
@@ -2130,6 +2147,7 @@ stroke_job_wait (StrokeJob *j)
 }
 
 static gint64 stroke_jobs_done, stroke_jobs_us, stroke_jobs_queue_us;   /* statistics */
+static gint64 stroke_jobs_extents_us, stroke_jobs_draw_us, stroke_jobs_crop_us;
 static gint64 resolve_wait_us;  /* time flutl_recorder_resolve spent waiting for workers */
 
 uint64_t
@@ -2175,8 +2193,10 @@ stroke_job_run (gpointer data, gpointer user_data)
     /* what raster_prepare does on the streaming thread in the synchronous path:
      * the stroke's extents in device space (identity CTM), exactly */
     double ex1, ey1, ex2, ey2;
+    const gint64 t_e = g_get_monotonic_time ();
     cairo_stroke_extents (cr, &ex1, &ey1, &ex2, &ey2);
     raster_box_from_extents (&j->rb, ex1, ey1, ex2, ey2, j->sw, j->sh);
+    __atomic_fetch_add (&stroke_jobs_extents_us, g_get_monotonic_time () - t_e, __ATOMIC_RELAXED);
   }
   if (!j->rb.inside) {          /* under the reference's limits, see current_limits */
     cairo_path_t *pth = cairo_copy_path (cr);
@@ -2189,14 +2209,18 @@ stroke_job_run (gpointer data, gpointer user_data)
   }
   cairo_set_matrix (cr, &j->ctm);
   cairo_set_source_rgba (cr, 1, 1, 1, 1);
+  const gint64 t_d = g_get_monotonic_time ();
   if (j->rb.bx1 > j->rb.bx0 && j->rb.by1 > j->rb.by0)
     cairo_stroke (cr);
   cairo_destroy (cr);
+  const gint64 t_c = g_get_monotonic_time ();
   j->tight = crop_coverage (ws->s, &j->rb, &j->x, &j->y, &j->w, &j->h);
   if (j->tight) {
     j->padded = mask_padded (j->tight, j->w, j->h, &j->padded_bytes);
     j->padded_hash = hash_bytes (j->padded, j->padded_bytes);
   }
+  __atomic_fetch_add (&stroke_jobs_draw_us, t_c - t_d, __ATOMIC_RELAXED);
+  __atomic_fetch_add (&stroke_jobs_crop_us, g_get_monotonic_time () - t_c, __ATOMIC_RELAXED);
   __atomic_fetch_add (&stroke_jobs_done, 1, __ATOMIC_RELAXED);
   __atomic_fetch_add (&stroke_jobs_us, g_get_monotonic_time () - t_run, __ATOMIC_RELAXED);
   __atomic_fetch_add (&stroke_jobs_queue_us, t_run - j->t_pushed, __ATOMIC_RELAXED);
@@ -2224,6 +2248,14 @@ stroke_pool_get (void)
   }
   g_mutex_unlock (&stroke_pool_lock);
   return stroke_pool;
+}
+
+void
+flutl_recorder_stroke_split (uint64_t *extents_us, uint64_t *draw_us, uint64_t *crop_us)
+{
+  *extents_us = (uint64_t) __atomic_exchange_n (&stroke_jobs_extents_us, 0, __ATOMIC_RELAXED);
+  *draw_us = (uint64_t) __atomic_exchange_n (&stroke_jobs_draw_us, 0, __ATOMIC_RELAXED);
+  *crop_us = (uint64_t) __atomic_exchange_n (&stroke_jobs_crop_us, 0, __ATOMIC_RELAXED);
 }
 
 void

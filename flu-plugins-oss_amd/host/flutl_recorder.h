@@ -159,6 +159,7 @@ void flutl_recorder_stroke_stats (uint64_t *jobs, uint64_t *busy_us, uint64_t *q
 uint64_t flutl_recorder_resolve_wait_us (void);
 void flutl_recorder_prepare_stats (uint64_t *path_us, uint64_t *extents_us);
 /* glyph runs turned into one mask so far / left as they are because two glyphs meet */
+void flutl_recorder_stroke_split (uint64_t *extents_us, uint64_t *draw_us, uint64_t *crop_us);
 void flutl_recorder_run_stats (FlutlRecorder *rec, uint32_t *merged, uint32_t *clashed);
 void flutl_recorder_lock (FlutlRecorder *rec);
 void flutl_recorder_unlock (FlutlRecorder *rec);

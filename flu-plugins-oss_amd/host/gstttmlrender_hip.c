@@ -3138,6 +3138,8 @@ timing_report (GstTTMLRender *render)
   uint64_t pp = 0, pe = 0;
   flutl_recorder_run_stats (priv->rec, &rm, &rc_);
   flutl_recorder_prepare_stats (&pp, &pe);
+  uint64_t we = 0, wd = 0, wc = 0;
+  flutl_recorder_stroke_split (&we, &wd, &wc);
   pipeline_drain (render);
   if (priv->ctx) {
     flutl_ctx_sync (priv->ctx);
@@ -3149,7 +3151,7 @@ timing_report (GstTTMLRender *render)
   }
   g_printerr ("ttmlrender-hip timing: buffers=%u record_us=%.1f device_us=%.1f "
       "span_us=%" G_GINT64_FORMAT " drained_us=%" G_GINT64_FORMAT " delta_bytes=%.0f "
-      "deferred=%u resolve_wait_us=%.1f atlas_upload_us=%.1f build_us=%.1f layout_us=%.1f region_hits=%u region_misses=%u strokes=%u stroke_us=%.0f stroke_queued_us=%.0f pure_wait_us=%.0f submit_us=%.1f push_block_us=%.1f runs_merged=%u runs_clashed=%u path_us=%.0f extents_us=%.0f miss_us=%.1f recoloured=%u\n",
+      "deferred=%u resolve_wait_us=%.1f atlas_upload_us=%.1f build_us=%.1f layout_us=%.1f region_hits=%u region_misses=%u strokes=%u stroke_us=%.0f stroke_queued_us=%.0f pure_wait_us=%.0f submit_us=%.1f push_block_us=%.1f runs_merged=%u runs_clashed=%u path_us=%.0f extents_us=%.0f miss_us=%.1f recoloured=%u worker_extents_us=%.0f worker_draw_us=%.0f worker_crop_us=%.0f\n",
       priv->n_timed, (double) priv->t_record / MAX (priv->n_timed - 1, 1),
       (double) (priv->t_device + priv->t_submit) / MAX (priv->n_timed - 1, 1),
       priv->t_last_return - priv->t_first_return,
@@ -3164,7 +3166,8 @@ timing_report (GstTTMLRender *render)
       (double) priv->t_submit / MAX (priv->n_deferred, 1),
       (double) priv->t_push_block / MAX (priv->n_deferred, 1), rm, rc_,
       sj ? (double) pp / sj : 0.0, sj ? (double) pe / sj : 0.0,
-      (double) priv->t_miss / MAX (priv->n_timed - 1, 1), priv->region_recoloured);
+      (double) priv->t_miss / MAX (priv->n_timed - 1, 1), priv->region_recoloured,
+      sj ? (double) we / sj : 0.0, sj ? (double) wd / sj : 0.0, sj ? (double) wc / sj : 0.0);
   priv->t_push_block = 0;
   priv->region_hits = priv->region_misses = priv->region_recoloured = 0;
   priv->n_timed = priv->n_deferred = 0;
@@ -3599,7 +3602,7 @@ gst_ttmlrender_init (GstTTMLRender *render)
   priv->sync_mode = g_getenv ("FLUTL_SYNC") != NULL;
   priv->queue_always = g_getenv ("FLUTL_QUEUE_ALWAYS") != NULL;
   priv->max_ahead = g_getenv ("FLUTL_MAX_AHEAD")
-      ? (guint) CLAMP (atoi (g_getenv ("FLUTL_MAX_AHEAD")), 1, MAX_IN_FLIGHT) : 0;
+      ? (guint) CLAMP (atoi (g_getenv ("FLUTL_MAX_AHEAD")), 1, 4 * MAX_IN_FLIGHT) : 0;
   priv->pool_prefill_set = g_getenv ("FLUTL_POOL_PREFILL") != NULL;
   priv->pool_prefill = g_getenv ("FLUTL_POOL_PREFILL")
       ? (guint) CLAMP (atoi (g_getenv ("FLUTL_POOL_PREFILL")), 0, POOL_MAX_FREE) : 8;
