@@ -1887,6 +1887,12 @@ static uint8_t *
 crop_coverage (cairo_surface_t *surf, const RasterBox *rb, int *ox, int *oy, int *ow, int *oh)
 {
   const int bx0 = rb->bx0, by0 = rb->by0, bx1 = rb->bx1, by1 = rb->by1;
+  *ox = *oy = *ow = *oh = 0;
+  /* (nothing to look at: a stroke that lies outside the surface altogether -- its
+   * exact extents, taken on the worker, can say so where the bounds of them the
+   * streaming thread went by could not; fuzz seed 610052) */
+  if (bx1 <= bx0 || by1 <= by0)
+    return NULL;
   cairo_surface_flush (surf);
   uint8_t *data = cairo_image_surface_get_data (surf);
   int stride = cairo_image_surface_get_stride (surf);

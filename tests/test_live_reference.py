@@ -70,7 +70,7 @@ def test_embedded_images_record_like_file_images(tmp_path):
 
 
 OUTLINED = [s for s in SCENES if os.path.basename(s)[:3] in
-            ("k04", "k07", "k10", "k12", "k13", "k14", "k15")]
+            ("k04", "k07", "k10", "k12", "k13", "k14", "k15", "k18", "k19")]
 
 
 @pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
