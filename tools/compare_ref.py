@@ -24,7 +24,10 @@ def compare(ttml, W, H, verbose=True):
     ref = np.frombuffer(gstenv.render(gstenv.REF_PLUGIN_DIR, ttml, W, H),
                         np.uint32).reshape(-1, H, W)
     with tempfile.TemporaryDirectory() as d:
-        pk = scene_pack.load(gstenv.dump_pack(ttml, W, H, os.path.join(d, "p.flpk")))
+        path = gstenv.dump_pack(ttml, W, H, os.path.join(d, "p.flpk"))
+        if not os.path.exists(path) and len(ref) == 0:
+            return True, ref, None      # a document neither element makes a buffer of
+        pk = scene_pack.load(path)
     states = pk.states()
     ok = len(states) == len(ref)
     if verbose:
