@@ -899,7 +899,7 @@ extern "C" uint64_t flutl_ctx_delta_bytes (flutl_ctx *c)
   if (!hip_ok (hipMemcpyAsync (&n, c->delta_segments, sizeof n, hipMemcpyDeviceToHost, c->stream)) ||
       !hip_ok (hipStreamSynchronize (c->stream)))
     return 0;
-  return n * 256u;
+  return n * flutl_delta_segment_bytes ();
 }
 
 extern "C" int flutl_frame_submit (flutl_ctx *c, flutl_frame *f,

@@ -1170,6 +1170,9 @@ __global__ __launch_bounds__ (256) void flutl_rotate_cw_kernel_dev (
 // Rows [y0, y1) only: the caller passes the union of what the twin holds and
 // what the new frame holds (both are transparent elsewhere).
 // WIDE: rows are 16-byte aligned multiples of 16 bytes; else per-pixel chunks.
+#ifndef FLUTL_DELTA_LANES
+#define FLUTL_DELTA_LANES 16     // 256-byte segments (8: 128, 4: 64; FLUTL_DELTA_SEGMENT_BYTES)
+#endif
 template <bool WIDE>
 __global__ __launch_bounds__ (256) void flutl_delta_kernel (
     const uint8_t *__restrict__ fresh, uint8_t *__restrict__ twin,
@@ -1211,7 +1214,9 @@ __global__ __launch_bounds__ (256) void flutl_delta_kernel (
   const bool diff = (v.x != t.x) | (v.y != t.y) | (v.z != t.z) | (v.w != t.w);
   const unsigned long long b = __ballot (diff);
   const uint32_t lane = threadIdx.x & 63u;
-  const bool seg = ((b >> (lane & 48u)) & 0xffffull) != 0ull;   // my 16-lane segment changed
+  // my segment (FLUTL_DELTA_LANES lanes x 16 bytes) changed
+  constexpr uint32_t kSegLanes = FLUTL_DELTA_LANES;
+  const bool seg = ((b >> (lane & (64u - kSegLanes))) & ((1ull << kSegLanes) - 1ull)) != 0ull;
   if (seg && live) {
     if (WIDE) {
       *reinterpret_cast<uint4 *> (twin + off) = v;
@@ -1225,8 +1230,10 @@ __global__ __launch_bounds__ (256) void flutl_delta_kernel (
     }
   }
   if (changed_segments && b != 0ull && lane == 0u) {     // one atomic per wave
-    const uint32_t n = ((b & 0xffffull) != 0) + ((b & 0xffff0000ull) != 0) +
-        ((b & 0xffff00000000ull) != 0) + ((b >> 48) != 0);
+    uint32_t n = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 64u; k += kSegLanes)
+      n += ((b >> k) & ((1ull << kSegLanes) - 1ull)) != 0ull;
     atomicAdd (changed_segments, (unsigned long long) n);
   }
 }
@@ -1312,6 +1319,11 @@ int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst
 }
 
 }  // namespace
+
+extern "C" uint32_t flutl_delta_segment_bytes (void)
+{
+  return FLUTL_DELTA_LANES * 16u;
+}
 
 extern "C" int flutl_launch_frame (void *stream, uint32_t width, uint32_t height,
     void *dst, size_t dst_stride_bytes, const flutl_region *regions,

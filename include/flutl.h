@@ -240,7 +240,8 @@ int flutl_launch_rotate_cw (void *stream, const void *src, void *dst,
  * what changed crosses PCIe.  This is the "dirty-rect D2H into pre-zeroed
  * buffers" of a pooled output frame (replaces the whole-frame write of
  * gstttmlrender.c:1442-1452).  changed_segments (device, or NULL): incremented
- * by the number of 256-byte segments written. */
+ * by the number of segments written (flutl_delta_segment_bytes () each). */
+uint32_t flutl_delta_segment_bytes (void);
 int flutl_launch_delta (void *stream, const void *fresh, void *twin, void *host,
     uint32_t width, uint32_t height, uint32_t row0, uint32_t row1,
     uint64_t *changed_segments);
