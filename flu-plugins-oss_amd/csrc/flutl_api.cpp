@@ -960,10 +960,21 @@ extern "C" int flutl_frame_submit (flutl_ctx *c, flutl_frame *f,
     memcpy (sl.host, regions, (size_t) n_regions * sizeof (flutl_region));
   if (n_prims)
     memcpy (static_cast<uint8_t *> (sl.host) + rb, prims, (size_t) n_prims * sizeof (flutl_prim));
-  // the supertile rows of the regions, heaviest first (flutl_launch_frame_ordered)
+  // rows of this submission: what the frame held before + what it holds now
+  uint32_t y0 = now[1], y1 = now[3];
+  if (f->ext[3] > f->ext[1]) {
+    if (y1 <= y0) {
+      y0 = f->ext[1];
+      y1 = f->ext[3];
+    } else {
+      y0 = f->ext[1] < y0 ? f->ext[1] : y0;
+      y1 = f->ext[3] > y1 ? f->ext[3] : y1;
+    }
+  }
+  // their supertile rows, heaviest first (flutl_launch_frame_ordered)
   const uint32_t n_order = flutl_row_order (width, height, regions, n_regions, prims, n_prims,
-      now[1], now[3], reinterpret_cast<uint16_t *> (static_cast<uint8_t *> (sl.host) + rb + pb));
-  // scratch frame of the context
+      y0, y1, reinterpret_cast<uint16_t *> (static_cast<uint8_t *> (sl.host) + rb + pb));
+  // scratch frame of the context (here: where translucent groups park pixels)
   const size_t need = (size_t) width * 4 * height;
   if (need > c->frame_cap) {
     (void) hipStreamSynchronize (c->stream);
@@ -976,42 +987,25 @@ extern "C" int flutl_frame_submit (flutl_ctx *c, flutl_frame *f,
     c->frame_cap = need;
   }
   bool ok = true;
-  if (rb + pb)
+  if (rb + pb + (n_order ? ob : 0))
     ok = hip_ok (hipMemcpyAsync (sl.dev, sl.host, rb + pb + (n_order ? ob : 0),
         hipMemcpyHostToDevice, c->stream));
   if (!ok)
     return FLUTL_ENODEV;
   const flutl_region *rd = static_cast<const flutl_region *> (sl.dev);
   const flutl_prim *pd = reinterpret_cast<const flutl_prim *> (static_cast<uint8_t *> (sl.dev) + rb);
-  // only the rows the regions span are composited (whole supertiles of 16 rows);
-  // the delta takes the new frame as transparent everywhere else
-  const uint32_t fy0 = now[1] & ~15u, fy1 = now[3] > now[1] ? ((now[3] + 15u) & ~15u) : fy0;
-  if (n_order)
-    rc = flutl_launch_frame_ordered (c->stream, width, height, c->frame, (size_t) width * 4, rd,
-        n_regions, pd, c->atlas, now[1], now[3],
-        reinterpret_cast<const uint16_t *> (static_cast<uint8_t *> (sl.dev) + rb + pb));
-  else
-    rc = flutl_launch_frame_rows (c->stream, width, height, c->frame, (size_t) width * 4, rd,
-        n_regions, pd, c->atlas, now[1], now[3]);
-  // rows of the delta: what the frame held before + what it holds now
-  uint32_t y0 = now[1], y1 = now[3];
-  if (f->ext[3] > f->ext[1]) {
-    if (y1 <= y0) {
-      y0 = f->ext[1];
-      y1 = f->ext[3];
-    } else {
-      y0 = f->ext[1] < y0 ? f->ext[1] : y0;
-      y1 = f->ext[3] > y1 ? f->ext[3] : y1;
-    }
-  }
-  if (rc == FLUTL_OK && !c->delta_segments) {
+  if (!c->delta_segments) {
     if (!hip_ok (hipMalloc (reinterpret_cast<void **> (&c->delta_segments), sizeof (uint64_t))) ||
         !hip_ok (hipMemsetAsync (c->delta_segments, 0, sizeof (uint64_t), c->stream)))
       rc = FLUTL_ENOMEM;
   }
-  if (rc == FLUTL_OK)
-    rc = flutl_launch_delta_window (c->stream, c->frame, f->twin, f->host_dev, width, height,
-        y0, y1, fy0, fy1 < height ? fy1 : height, c->delta_segments);
+  // one launch: composite those rows, compare with the twin, write what differs
+  // into the twin and the host block (flutl_launch_frame_delta)
+  if (rc == FLUTL_OK && n_order)
+    rc = flutl_launch_frame_delta (c->stream, width, height, f->twin, f->host_dev, c->frame,
+        (size_t) width * 4, rd, n_regions, pd, c->atlas, y0, y1,
+        reinterpret_cast<const uint16_t *> (static_cast<uint8_t *> (sl.dev) + rb + pb),
+        c->delta_segments);
   ok = rc == FLUTL_OK && hip_ok (hipEventRecord (sl.done, c->stream)) &&
       hip_ok (hipEventRecord (f->done, c->stream));
   sl.busy = true;

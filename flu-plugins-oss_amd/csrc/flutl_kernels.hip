@@ -399,6 +399,9 @@ __device__ __forceinline__ uint32_t uniform_over (uint32_t d, uint32_t s)
   return (uint32_t) __builtin_amdgcn_readfirstlane ((int) pack (v));
 }
 
+#ifndef FLUTL_DELTA_LANES
+#define FLUTL_DELTA_LANES 16     // delta read-back: 256-byte segments (8: 128, 4: 64)
+#endif
 // At least 6 waves per SIMD (4 KB of LDS per wave allows 8): measured 5 -> 6
 // waves +4 %, 6 = 7 = 8 -- and at 8 the 96-SGPR budget makes the compiler
 // spill scalars into VGPR lanes, +60 VALU per wave on a VALU-bound kernel.
@@ -423,14 +426,24 @@ __device__ __forceinline__ uint32_t uniform_over (uint32_t d, uint32_t s)
 // rows are taken in the order of a table made on the host, heaviest first.  A
 // single frame is one round of waves; its time is the time of the LAST wave, and
 // with rows dealt top to bottom the text of the bottom region starts last.
-template <bool VIDEO, bool ORDERED>
+// DELTA (the element's per-buffer launch, flutl_frame_submit): dst is the HBM twin
+// of a pooled host frame and is not overwritten but COMPARED with, segment by
+// segment, in the store epilogue; the segments that differ go into the twin and
+// straight into the page-locked host block over PCIe (`host`, device mapped).  The
+// delta read-back fused into its producer: the frame is never written to a scratch
+// surface and read back (66 MB of HBM traffic and a launch per 4K buffer).  What a
+// translucent group parks (see below) goes to `park`, a scratch frame of the same
+// geometry, since the twin must stay what it is until the comparison.
+template <bool VIDEO, bool ORDERED, bool DELTA>
 __attribute__ ((amdgpu_waves_per_eu (FLUTL_WAVES)))
 __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
     FrameParams fp, uint8_t *__restrict__ dst, const uint8_t *__restrict__ video,
     const uint16_t *__restrict__ row_order,
     const flutl_frame_desc *__restrict__ frames,
     const flutl_region *__restrict__ regions,
-    const flutl_prim *__restrict__ prims, const uint8_t *__restrict__ atlas)
+    const flutl_prim *__restrict__ prims, const uint8_t *__restrict__ atlas,
+    uint8_t *__restrict__ host, uint8_t *__restrict__ park,
+    unsigned long long *__restrict__ changed_segments)
 {
   // The supertile's pixels live in LDS, not in registers.  Every lane only
   // ever touches its own 16-byte slots, so there is no barrier and no bank
@@ -517,6 +530,7 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
   uint32_t base = 0, base_frame = 0;
   uint32_t st = (sx0 + kSuperW <= (int) fp.width && sy0 + kSuperH <= (int) fp.height &&
       ((reinterpret_cast<uintptr_t> (dst) | (VIDEO ? reinterpret_cast<uintptr_t> (video) : 0) |
+          (DELTA ? reinterpret_cast<uintptr_t> (host) | reinterpret_cast<uintptr_t> (park) : 0) |
           dst_off | fp.stride) & 15u) == 0) ? kStInterior : 0u;   // scalar
 
 #define ST_TOUCHED      (st & 0xffu)
@@ -553,6 +567,9 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
   // first pixel of strip 0; recomputed where needed, not kept in registers)
 #define STRIP_OUT(r, x, y0) \
   (dst + dst_off + (size_t) ((y0) + 4 * (r)) * fp.stride + (size_t) (x) * 4)
+  // ... and where a group parks them
+#define PARK_OUT(r, x, y0) \
+  ((DELTA ? park : dst) + dst_off + (size_t) ((y0) + 4 * (r)) * fp.stride + (size_t) (x) * 4)
 
 #if FLUTL_EXP == 2    // ablation: store floor, no display list at all
   rcount = 0;
@@ -772,7 +789,7 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
 #pragma unroll
             for (int r = 0; r < kRG; r++)
               if (ST_T (r))
-                park_store (STRIP_OUT (r, x, y0), s_surf[r][lane], ST_INTERIOR,
+                park_store (PARK_OUT (r, x, y0), s_surf[r][lane], ST_INTERIOR,
                     (int) fp.width - x, (int) fp.height - (y0 + 4 * r));
             // touched_frame = touched, solid_frame = solid, nothing in the group yet
             base_frame = base;
@@ -835,7 +852,7 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
                 if (src_solid) {
                   d = s_surf[r][lane];          // never overwritten by the group
                 } else {
-                  d = park_load (STRIP_OUT (r, x, y0), ST_INTERIOR,
+                  d = park_load (PARK_OUT (r, x, y0), ST_INTERIOR,
                       (int) fp.width - x, (int) fp.height - y);
                   STRIP_STORE (r, d);           // the frame strip is back
                 }
@@ -916,7 +933,57 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
   uint8_t *const out = STRIP_OUT (0, x_lane, y_lane);
   const uint8_t *const vin = VIDEO
       ? video + dst_off + (size_t) y_lane * fp.stride + (size_t) x_lane * 4 : nullptr;
-  if (ST_INTERIOR) {
+  if (DELTA) {
+    // compare with the twin; a segment = kSegLanes lanes x 16 bytes of one row (a
+    // row of the supertile is 16 lanes): whole segments keep the PCIe writes at
+    // full payload size
+    constexpr uint32_t kSegLanes = FLUTL_DELTA_LANES;
+    static_assert (kSegLanes == 16 || kSegLanes == 8 || kSegLanes == 4, "segments within a row");
+    uint8_t *const hout = host + (out - dst);
+    uint32_t n_seg = 0;         // scalar
+    if (ST_INTERIOR) {
+#pragma unroll
+      for (int r = 0; r < kRG; r++) {
+        const uint4 v = STRIP_LOAD (r);
+        const size_t o = (size_t) (4 * r) * fp.stride;
+        const uint4 t = *reinterpret_cast<const uint4 *> (out + o);
+        const bool diff = (v.x != t.x) | (v.y != t.y) | (v.z != t.z) | (v.w != t.w);
+        const unsigned long long b = __ballot (diff);
+        if (b == 0ull)
+          continue;
+        if (((b >> (lane & (64u - kSegLanes))) & ((1ull << kSegLanes) - 1ull)) != 0ull) {
+          *reinterpret_cast<uint4 *> (out + o) = v;
+          *reinterpret_cast<uint4 *> (hout + o) = v;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 64u; k += kSegLanes)
+          n_seg += ((b >> k) & ((1ull << kSegLanes) - 1ull)) != 0ull;
+      }
+    } else if (x_lane < (int) fp.width) {
+      // frame edge or rows that are not 16-byte multiples: pixel by pixel
+#pragma unroll
+      for (int r = 0; r < kRG; r++) {
+        if (y_lane + 4 * r >= (int) fp.height)
+          continue;
+        const uint4 v = STRIP_LOAD (r);
+        const uint32_t e[4] = { v.x, v.y, v.z, v.w };
+        uint32_t *tw = reinterpret_cast<uint32_t *> (out + (size_t) (4 * r) * fp.stride);
+        uint32_t *ho = reinterpret_cast<uint32_t *> (hout + (size_t) (4 * r) * fp.stride);
+        bool any = false;
+        for (int k = 0; k < 4 && x_lane + k < (int) fp.width; k++)
+          if (tw[k] != e[k]) {
+            tw[k] = e[k];
+            ho[k] = e[k];
+            any = true;
+          }
+        const unsigned long long b = __ballot (any);
+        for (uint32_t k = 0; k < 64u; k += kSegLanes)
+          n_seg += ((b >> k) & ((1ull << kSegLanes) - 1ull)) != 0ull;
+      }
+    }
+    if (changed_segments && n_seg && lane == 0)
+      atomicAdd (changed_segments, (unsigned long long) n_seg);
+  } else if (ST_INTERIOR) {
 #pragma unroll
     for (int r = 0; r < kRG; r++) {
       // streaming (nt) stores: the frame is written once and never read here,
@@ -971,6 +1038,7 @@ __global__ __launch_bounds__ (kThreads) void flutl_composite_kernel (
   }
 #endif
 #undef STRIP_OUT
+#undef PARK_OUT
 #undef STRIP_LOAD
 #undef STRIP_STORE
 #undef STRIPS_SET_UNIFORM
@@ -1170,9 +1238,6 @@ __global__ __launch_bounds__ (256) void flutl_rotate_cw_kernel_dev (
 // Rows [y0, y1) only: the caller passes the union of what the twin holds and
 // what the new frame holds (both are transparent elsewhere).
 // WIDE: rows are 16-byte aligned multiples of 16 bytes; else per-pixel chunks.
-#ifndef FLUTL_DELTA_LANES
-#define FLUTL_DELTA_LANES 16     // 256-byte segments (8: 128, 4: 64; FLUTL_DELTA_SEGMENT_BYTES)
-#endif
 template <bool WIDE>
 __global__ __launch_bounds__ (256) void flutl_delta_kernel (
     const uint8_t *__restrict__ fresh, uint8_t *__restrict__ twin,
@@ -1242,7 +1307,8 @@ int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst
     const void *video, size_t stride, const flutl_frame_desc *frames, uint32_t n_frames,
     uint32_t region_first, uint32_t region_count, const flutl_region *regions,
     const flutl_prim *prims, const uint8_t *atlas, uint32_t row0 = 0, uint32_t row1 = 0,
-    const uint16_t *row_order = nullptr)
+    const uint16_t *row_order = nullptr, void *delta_host = nullptr, void *delta_park = nullptr,
+    unsigned long long *delta_segments = nullptr)
 {
   if (!dst || width == 0 || height == 0 || n_frames == 0 || width > 32767 ||
       height > 32767 || (stride & 3) || stride < (size_t) width * 4)
@@ -1260,6 +1326,8 @@ int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst
   const uint32_t n_rows = fp.row_end - fp.row_base;
   if (row_order && (n_frames != 1 || video))
     return FLUTL_EINVAL;        // one table, one frame
+  if (delta_host && (!row_order || !delta_park))
+    return FLUTL_EINVAL;        // the fused delta read-back: single ordered frames
   fp.n_frames = n_frames;
   fp.region_first = region_first;
   fp.region_count = region_count;
@@ -1280,17 +1348,27 @@ int launch_tiles (hipStream_t stream, uint32_t width, uint32_t height, void *dst
     if (launch_error != hipSuccess) \
       break; \
     if (video) \
-      hipLaunchKernelGGL ((flutl_composite_kernel<true, false>), grid, dim3 (kThreads), 0, stream, fp, \
+      hipLaunchKernelGGL ((flutl_composite_kernel<true, false, false>), grid, dim3 (kThreads), 0, stream, fp, \
           static_cast<uint8_t *> (dst), static_cast<const uint8_t *> (video), \
-          static_cast<const uint16_t *> (nullptr), frames, regions, prims, atlas); \
-    else if (row_order) \
-      hipLaunchKernelGGL ((flutl_composite_kernel<false, true>), grid, dim3 (kThreads), 0, stream, fp, \
+          static_cast<const uint16_t *> (nullptr), frames, regions, prims, atlas, \
+          static_cast<uint8_t *> (nullptr), static_cast<uint8_t *> (nullptr), \
+          static_cast<unsigned long long *> (nullptr)); \
+    else if (delta_host) \
+      hipLaunchKernelGGL ((flutl_composite_kernel<false, true, true>), grid, dim3 (kThreads), 0, stream, fp, \
           static_cast<uint8_t *> (dst), static_cast<const uint8_t *> (nullptr), row_order, \
-          frames, regions, prims, atlas); \
+          frames, regions, prims, atlas, static_cast<uint8_t *> (delta_host), \
+          static_cast<uint8_t *> (delta_park), delta_segments); \
+    else if (row_order) \
+      hipLaunchKernelGGL ((flutl_composite_kernel<false, true, false>), grid, dim3 (kThreads), 0, stream, fp, \
+          static_cast<uint8_t *> (dst), static_cast<const uint8_t *> (nullptr), row_order, \
+          frames, regions, prims, atlas, static_cast<uint8_t *> (nullptr), \
+          static_cast<uint8_t *> (nullptr), static_cast<unsigned long long *> (nullptr)); \
     else \
-      hipLaunchKernelGGL ((flutl_composite_kernel<false, false>), grid, dim3 (kThreads), 0, stream, fp, \
+      hipLaunchKernelGGL ((flutl_composite_kernel<false, false, false>), grid, dim3 (kThreads), 0, stream, fp, \
           static_cast<uint8_t *> (dst), static_cast<const uint8_t *> (nullptr), \
-          static_cast<const uint16_t *> (nullptr), frames, regions, prims, atlas); \
+          static_cast<const uint16_t *> (nullptr), frames, regions, prims, atlas, \
+          static_cast<uint8_t *> (nullptr), static_cast<uint8_t *> (nullptr), \
+          static_cast<unsigned long long *> (nullptr)); \
     launch_error = hipGetLastError (); \
   } while (0)
   // one workgroup (= one wave) per supertile; grid.x is a multiple of 8 so
@@ -1357,6 +1435,20 @@ extern "C" int flutl_launch_frame_ordered (void *stream, uint32_t width, uint32_
     return FLUTL_OK;
   return launch_tiles (static_cast<hipStream_t> (stream), width, height, dst, nullptr,
       dst_stride_bytes, nullptr, 1, 0, n_regions, regions, prims, atlas, row0, row1, row_order);
+}
+
+extern "C" int flutl_launch_frame_delta (void *stream, uint32_t width, uint32_t height,
+    void *twin, void *host, void *park, size_t stride_bytes, const flutl_region *regions,
+    uint32_t n_regions, const flutl_prim *prims, const uint8_t *atlas, uint32_t row0,
+    uint32_t row1, const uint16_t *row_order, uint64_t *changed_segments)
+{
+  if (row0 > row1 || row1 > height || !row_order || !twin || !host || !park)
+    return FLUTL_EINVAL;
+  if (row0 == row1)
+    return FLUTL_OK;
+  return launch_tiles (static_cast<hipStream_t> (stream), width, height, twin, nullptr,
+      stride_bytes, nullptr, 1, 0, n_regions, regions, prims, atlas, row0, row1, row_order,
+      host, park, reinterpret_cast<unsigned long long *> (changed_segments));
 }
 
 extern "C" int flutl_launch_frame_over_rows (void *stream, uint32_t width, uint32_t height,

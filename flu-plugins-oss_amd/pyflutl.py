@@ -52,6 +52,7 @@ EXPORTS = [
     "flutl_render_frame_rows_to_host", "flutl_render_frame_window_to_host",
     "flutl_atlas_put_blurred",
     "flutl_launch_delta", "flutl_launch_delta_window", "flutl_delta_segment_bytes",
+    "flutl_launch_frame_delta",
     "flutl_launch_frame_rows",
     "flutl_launch_frame_over_rows", "flutl_blend_over_host",
     "flutl_launch_frame_ordered", "flutl_row_order",

@@ -150,6 +150,21 @@ int flutl_launch_frame_ordered (void *stream, uint32_t width, uint32_t height,
     const flutl_region *regions, uint32_t n_regions,
     const flutl_prim *prims, const uint8_t *atlas, uint32_t row0, uint32_t row1,
     const uint16_t *row_order);
+/* ... and with the delta read-back fused into the store: the rows [row0, row1) of the
+ * frame are composited and COMPARED with `twin` (HBM; what the host block holds);
+ * the segments that differ (flutl_delta_segment_bytes ()) are written into the twin
+ * and into `host` (page-locked, device mapped: over PCIe), everything else is left
+ * alone.  The frame is never written to a scratch surface and read back (what
+ * flutl_launch_frame_ordered + flutl_launch_delta_window cost: 8 more bytes of HBM
+ * traffic per pixel and a launch).  The window must cover what the twin holds as
+ * well as what the list draws.  park: a scratch frame of the same geometry (what a
+ * translucent group sets aside while it draws).  This is what flutl_frame_submit
+ * launches per buffer (replaces gstttmlrender.c:1442-1472 + the push of the frame). */
+int flutl_launch_frame_delta (void *stream, uint32_t width, uint32_t height,
+    void *twin, void *host, void *park, size_t stride_bytes,
+    const flutl_region *regions, uint32_t n_regions,
+    const flutl_prim *prims, const uint8_t *atlas, uint32_t row0, uint32_t row1,
+    const uint16_t *row_order, uint64_t *changed_segments);
 /* Host helper: the supertile rows of the window [row0, row1), as indices relative
  * to its first one, sorted by how much coverage work the (validated) list brings
  * to each, descending.  order_out: room for (height + 15) / 16 entries; returns
