@@ -400,7 +400,7 @@ __device__ __forceinline__ uint32_t uniform_over (uint32_t d, uint32_t s)
 }
 
 #ifndef FLUTL_DELTA_LANES
-#define FLUTL_DELTA_LANES 16     // delta read-back: 256-byte segments (8: 128, 4: 64)
+#define FLUTL_DELTA_LANES 4      // delta read-back: 64-byte segments (8: 128, 16: 256 bytes)
 #endif
 // At least 6 waves per SIMD (4 KB of LDS per wave allows 8): measured 5 -> 6
 // waves +4 %, 6 = 7 = 8 -- and at 8 the 96-SGPR budget makes the compiler
