@@ -179,13 +179,15 @@ def test_two_elements_in_one_process_and_a_thread_boundary_downstream(gpu, tmp_p
                                    {"FLUTL_MAX_AHEAD": "1", "FLUTL_STROKE_THREADS": "1"},
                                    {"FLUTL_FULL_D2H": "1"}, {"FLUTL_POOL_PREFILL": "0"},
                                    {"FLUTL_NO_SPAN_PLANS": "1", "FLUTL_NO_RUN_MERGE": "1"},
-                                   {"FLUTL_QUEUE_ALWAYS": "1", "FLUTL_NO_LAYOUT_CACHE": "1"}],
+                                   {"FLUTL_QUEUE_ALWAYS": "1", "FLUTL_NO_LAYOUT_CACHE": "1"},
+                                   {"FLUTL_NO_RECOLOUR": "1"}],
                          ids=["sync", "no-region-cache", "ahead1", "full-d2h", "no-prefill",
-                              "no-plans-no-merge", "queue-always"])
+                              "no-plans-no-merge", "queue-always", "no-recolour"])
 def test_element_modes_all_reproduce_the_reference(gpu, knobs):
     """The element's pipeline knobs change how a buffer is produced, never what it
     holds: an outlined, animated scene and a moving outline under each of them."""
-    for name in ("k06_animation", "k12_moving_outline", "k13_vertical_group", "k17_glyph_runs"):
+    for name in ("k06_animation", "k12_moving_outline", "k13_vertical_group", "k17_glyph_runs",
+                 "k18_recolour"):
         path = [s for s in SCENES if name in s][0]
         z = np.load(path)
         W, H = int(z["width"]), int(z["height"])
