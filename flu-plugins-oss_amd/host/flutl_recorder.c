@@ -172,6 +172,7 @@ struct FlutlRecorder
   uint32_t pixel;             /* quantised premultiplied a8r8g8b8 */
   int color_opaque, color_clear;
   uint16_t color_tag;           /* who set the colour (element's numbering; 0: not said) */
+  const cairo_matrix_t *ctm_inverse;   /* the reference's inverse CTM, if the caller keeps it */
   uint16_t *prim_tags;          /* per primitive, parallel to prims */
 
   uint32_t unsupported;
@@ -854,6 +855,16 @@ flutl_recorder_pixel_of (double r, double g, double b, double a)
  * under.  A region whose layouts change in nothing but such colours is then the
  * same primitives with other colour words (the element's region cache).
  * set_color clears the tag. */
+/* The caller moves the CTM about with cairo_set_matrix (walk_layout) where the
+ * reference uses translate / transform calls: the context's own inverse is then
+ * an inversion, not the reference's product of inverses.  Whoever needs the
+ * reference's (hexbox_show) takes it from here while it is set. */
+void
+flutl_recorder_set_ctm_inverse (FlutlRecorder *rec, const cairo_matrix_t *inverse)
+{
+  rec->ctm_inverse = inverse;
+}
+
 void
 flutl_recorder_set_color_tag (FlutlRecorder *rec, uint16_t tag)
 {
@@ -1478,10 +1489,15 @@ hexbox_show (FlutlRecorder *rec, PangoFont *font, const PangoGlyphInfo *gi)
        * digits one pixel off under a vertical writing mode) */
       double x = x0 + col * (hb->digit_width + hb->pad_x), yy = y;
       {
+        /* (the inverse as the reference's context holds it: kept up call by call,
+         * not inverted afresh -- under a rotated CTM the two differ in the last
+         * bit, which decides where a grid point at n + 1/2 goes; fuzz seed 800452) */
         cairo_matrix_t m, inv;
         cairo_get_matrix (rec->cr, &m);
         inv = m;
-        if (cairo_matrix_invert (&inv) == CAIRO_STATUS_SUCCESS) {
+        if (rec->ctm_inverse)
+          inv = *rec->ctm_inverse;
+        if (rec->ctm_inverse || cairo_matrix_invert (&inv) == CAIRO_STATUS_SUCCESS) {
           cairo_matrix_transform_point (&m, &x, &yy);
           x = fixed_from_double (x) / 256.0;
           yy = fixed_from_double (yy) / 256.0;

@@ -62,6 +62,7 @@ void flutl_recorder_get_color (FlutlRecorder *rec, double rgba[4]);
 /* colour tags (see flutl_recorder.c): the source of the colour just set, kept per primitive */
 uint32_t flutl_recorder_pixel_of (double r, double g, double b, double a);
 void flutl_recorder_set_color_tag (FlutlRecorder *rec, uint16_t tag);
+void flutl_recorder_set_ctm_inverse (FlutlRecorder *rec, const cairo_matrix_t *inverse);
 uint16_t flutl_recorder_get_color_tag (FlutlRecorder *rec);
 const uint16_t *flutl_recorder_prim_tags (FlutlRecorder *rec);
 

@@ -1715,10 +1715,29 @@ walk_layout (GstTTMLRender *render, FlutlRecorder *rec, PangoLayout *layout,
    * cairo_matrix_translate on the CTM (_cairo_gstate_translate), a restore is a
    * copy -- and handed to the context only where something reads it. */
   cairo_matrix_t m, stack[3];
+  /* ... and its inverse, the way the context keeps it (_cairo_gstate_translate:
+   * inverse = inverse x translate (-tx, -ty)): cairo_move_to + cairo_show_text, which
+   * Pango draws the digits of a hex box with, go through it.  The context's own
+   * inverse at this point is the reference's (the calls so far were the
+   * reference's); it is read out exactly: x * 1 + y * 0 is x. */
+  cairo_matrix_t minv, stack_inv[3];
   gboolean m_dirty = FALSE;
   cairo_get_matrix (cr, &m);
+  {
+    double ax = 1, ay = 0, bx = 0, by = 1, ox = 0, oy = 0;
+    cairo_device_to_user_distance (cr, &ax, &ay);
+    cairo_device_to_user_distance (cr, &bx, &by);
+    cairo_device_to_user (cr, &ox, &oy);
+    cairo_matrix_init (&minv, ax, ay, bx, by, ox, oy);
+  }
+  flutl_recorder_set_ctm_inverse (rec, &minv);
 #define CTM_SYNC() G_STMT_START { if (m_dirty) { cairo_set_matrix (cr, &m); m_dirty = FALSE; } } G_STMT_END
-#define CTM_TRANSLATE(tx, ty) G_STMT_START { cairo_matrix_translate (&m, (tx), (ty)); m_dirty = TRUE; } G_STMT_END
+#define CTM_TRANSLATE(tx, ty) G_STMT_START { \
+    cairo_matrix_t t_; \
+    cairo_matrix_translate (&m, (tx), (ty)); \
+    cairo_matrix_init_translate (&t_, -(tx), -(ty)); \
+    cairo_matrix_multiply (&minv, &minv, &t_); \
+    m_dirty = TRUE; } G_STMT_END
 
   if (pango_layout_get_width (layout) == -1) {
     /* no wrapping: alignment is applied by hand against the region width */
@@ -1751,6 +1770,7 @@ walk_layout (GstTTMLRender *render, FlutlRecorder *rec, PangoLayout *layout,
 
     CTM_TRANSLATE (line_dx, writing_mode != GST_TTML_WRITING_MODE_TBLR ? pre : -post);
     stack[0] = m;
+    stack_inv[0] = minv;
     for (rl = line->runs; rl; rl = rl->next) {
       PangoGlyphItem *run = rl->data;
       PangoGlyphString *gs = run->glyphs;
@@ -1764,6 +1784,7 @@ walk_layout (GstTTMLRender *render, FlutlRecorder *rec, PangoLayout *layout,
         width += gs->glyphs[i].geometry.width;
       width /= PANGO_SCALE;
       stack[1] = m;
+      stack_inv[1] = minv;
       double saved_color[4];
       const guint16 saved_tag = flutl_recorder_get_color_tag (rec);
       flutl_recorder_get_color (rec, saved_color);
@@ -1847,12 +1868,16 @@ walk_layout (GstTTMLRender *render, FlutlRecorder *rec, PangoLayout *layout,
         for (i = 0; i < n; i++) {
           PangoGlyphInfo *gi = &gs->glyphs[reverse ? n - 1 - i : i];
           stack[2] = m;
+          stack_inv[2] = minv;
           if (oblique) {
             /* reference :1125, :1141-1143: reverseOblique = x += y / 4
              * (cairo_transform: ctm = shear x ctm, _cairo_gstate_transform) */
-            cairo_matrix_t shear;
+            cairo_matrix_t shear, unshear;
             cairo_matrix_init (&shear, 1, 0, 0.25, 1, 0, 0);
+            unshear = shear;
+            cairo_matrix_invert (&unshear);
             cairo_matrix_multiply (&m, &shear, &m);
+            cairo_matrix_multiply (&minv, &minv, &unshear);
             m_dirty = TRUE;
           }
           /* reference: the glyph offsets are applied here AND again by Pango */
@@ -1865,10 +1890,12 @@ walk_layout (GstTTMLRender *render, FlutlRecorder *rec, PangoLayout *layout,
             flutl_recorder_path_glyph (rec, run->item->analysis.font, gi);
           }
           m = stack[2];
+          minv = stack_inv[2];
           CTM_TRANSLATE (gi->geometry.width / (double) PANGO_SCALE, 0);
         }
       }
       m = stack[1];
+      minv = stack_inv[1];
       m_dirty = TRUE;
       /* (restoring the context also restores the source colour) */
       flutl_recorder_set_color (rec, saved_color[0], saved_color[1], saved_color[2],
@@ -1877,9 +1904,11 @@ walk_layout (GstTTMLRender *render, FlutlRecorder *rec, PangoLayout *layout,
       CTM_TRANSLATE (width, 0);
     }
     m = stack[0];
+    minv = stack_inv[0];
     CTM_TRANSLATE (-line_dx, writing_mode != GST_TTML_WRITING_MODE_TBLR ? post : -pre);
   }
   CTM_SYNC ();
+  flutl_recorder_set_ctm_inverse (rec, NULL);
 #undef CTM_SYNC
 #undef CTM_TRANSLATE
 }
