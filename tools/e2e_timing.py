@@ -60,6 +60,39 @@ def measure(ttml, W, H, extra_env=None, log_path=None, sink="fakesink"):
     return out
 
 
+def measure_streams(ttml, W, H, n, extra_env=None, log_path=None):
+    """n element pipelines in ONE gst-launch process (n unlinked chains: they go to
+    PLAYING together), one HIP context each.  Frames/s = all buffers but the n first
+    ones / (earliest end of a first gen_buffer -> latest frame complete), from the
+    elements' CLOCK_MONOTONIC stamps; also how much of that span each stream was in."""
+    extra = {"FLUTL_TIMING": "1"}
+    for k, v in os.environ.items():
+        if k.startswith("FLUTL_") and k != "FLUTL_BENCH_REHEARSAL":
+            extra[k] = v
+    extra.update(extra_env or {})
+    env = gstenv.env_for(gstenv.HIP_PLUGIN_DIR, extra)
+    cmd = [os.path.join(gstenv.CONDA, "bin", "gst-launch-1.0"), "-q"]
+    for _ in range(n):
+        cmd += ["filesrc", f"location={os.path.abspath(ttml)}", "!", "ttmlrender", "!",
+                f"video/x-raw,width={W},height={H}", "!", "fakesink"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=tempfile.gettempdir())
+    lines = [l for l in r.stderr.split("\n") if "ttmlrender-hip timing" in l and "buffers=0 " not in l]
+    if log_path:
+        with open(log_path, "a") as f:
+            f.write(f"$ {n} x ({' '.join(cmd[2:9])})   (rc {r.returncode})\n" + "\n".join(lines) + "\n")
+    if r.returncode != 0 or len(lines) < n:
+        raise RuntimeError(f"{n}-stream pipeline failed (rc {r.returncode}, {len(lines)} reports): "
+                           f"{r.stderr[-1500:]}")
+    kvs = [{k: float(v) for k, v in re.findall(r"(\w+)=([0-9.]+)", l)} for l in lines[-n:]]
+    t0 = min(kv["t_first_us"] for kv in kvs)
+    t1 = max(kv["t_end_us"] for kv in kvs)
+    frames = sum(int(kv["buffers"]) - 1 for kv in kvs)
+    return {"frames_per_s": round(frames / ((t1 - t0) * 1e-6), 1), "streams": n,
+            "span_s": round((t1 - t0) * 1e-6, 4),
+            "per_stream": [round((kv["buffers"] - 1) / (kv["drained_us"] * 1e-6), 1) for kv in kvs],
+            "in_span": [round(kv["drained_us"] / (t1 - t0), 2) for kv in kvs]}
+
+
 if __name__ == "__main__":
     cfg, W, H = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     ttml = cfg if os.path.exists(cfg) else os.path.join(ROOT, "bench_data", cfg + ".ttml")
