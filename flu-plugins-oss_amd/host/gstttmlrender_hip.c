@@ -3594,8 +3594,17 @@ gst_ttmlrender_init (GstTTMLRender *render)
     g_once_init_leave (&registered, 1);
   }
 
-  render->pango_context =
-      pango_font_map_create_context (pango_cairo_font_map_get_default ());
+  /* The reference takes its context from pango_cairo_font_map_get_default () here
+   * (:1727), in whatever thread creates the element: every ttmlrender of a process
+   * made by one thread then shares ONE font map, and a PangoFontMap is not safe
+   * for use from several streaming threads at once -- four elements in one
+   * gst-launch crash or hang one run in three, the reference's own included.  A font
+   * map of its own per element: same backend, same defaults, same fonts. */
+  {
+    PangoFontMap *fontmap = pango_cairo_font_map_new ();
+    render->pango_context = pango_font_map_create_context (fontmap);
+    g_object_unref (fontmap);   /* (the context keeps it) */
+  }
   /* reference :1739: the instance default is "Serif" whatever the param spec says */
   render->default_font_family = g_strdup ("Serif");
   render->default_font_size = NULL;

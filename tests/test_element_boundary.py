@@ -91,3 +91,22 @@ def test_video_pad_dataflow_without_a_device():
     v, o = gstenv.render_over_video(ttml, 320, 180, 9, 3, extra_env={
         "FLUTL_DUMP_ONLY": "1", "FLUTL_DUMP_PACK": os.devnull})
     assert len(v) == 9 * 320 * 180 * 4 and v == o
+
+
+@pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
+                    reason="fluttml-hip plugin / GStreamer runtime not present")
+def test_six_elements_in_one_process_record_side_by_side():
+    """Several ttmlrender in one gst-launch (one streaming thread each).  The reference
+    creates its Pango context from the DEFAULT font map of the thread that creates the
+    element (gstttmlrender.c:1727): all elements of a pipeline share one font map, which
+    Pango does not allow to be used from several threads -- four elements crashed or hung
+    one run in three, the reference's own included.  This element has a font map of its
+    own; here six of them record the same outlined, animated 4K document at once, three
+    times over (record-only: no device needed), and every one must report all buffers."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import e2e_timing
+    ttml = os.path.join(ROOT, "bench_data", "cfg2.ttml")
+    for _ in range(3):
+        r = e2e_timing.measure_streams(ttml, 3840, 2160, 6, extra_env={
+            "FLUTL_DUMP_ONLY": "1", "MALLOC_CHECK_": "3"})
+        assert r["streams"] == 6 and len(r["per_stream"]) == 6
