@@ -63,8 +63,12 @@ def text(rng, lines):
     return "<br/>".join(out)
 
 
-def gen(cfg, seed):
+def gen(cfg, seed, n_states=None):
+    """n_states (cfg1 / cfg2 only): more scene states than the config names -- a longer
+    stream of the same kind (bench.py's steady-state figure; other texts and colours: the
+    generator draws them in sequence)."""
     rng = Rng(seed)
+    more_states = n_states
     W, H = SIZES[cfg]
     regs, body = [], []
     if cfg == "cfg0":
@@ -79,7 +83,7 @@ def gen(cfg, seed):
     elif cfg in ("cfg1", "cfg2"):
         n = 4 if cfg == "cfg1" else 8
         font = 54 if cfg == "cfg1" else 96
-        n_states = 60 if cfg == "cfg1" else 120
+        n_states = more_states or (60 if cfg == "cfg1" else 120)
         slot = 100.0 / n
         for i in range(n):
             alpha = rng.rint(0x99, 0xE0) if cfg == "cfg2" else (0x80 if i % 2 else 0xC0)
