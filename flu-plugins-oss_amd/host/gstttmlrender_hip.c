@@ -2343,8 +2343,8 @@ region_entry_new (GstTTMLRenderPrivate *priv, const HipRegion *r, const RegionKe
   RegionEntry *e;
   GList *l;
   guint i;
-  if (priv->region_cache->len >= 256)           /* bound it: start over */
-    g_ptr_array_set_size (priv->region_cache, 0);
+  if (priv->region_cache->len >= 256)           /* bound it: the least recently used go */
+    g_ptr_array_remove_range (priv->region_cache, 0, 64);
   e = g_new0 (RegionEntry, 1);
   e->key = *key;
   e->hash = hash;
@@ -2381,7 +2381,7 @@ region_recolour (GstTTMLRender *render, HipRegion *r, RegionEntry *e, const Regi
   RegionEntry *n;
   GList *l;
   guint k = 0, i, j;
-  /* (e itself may go when the new entry is made: the cache starts over when full) */
+  /* (e itself may go when the new entry is made: the oldest entries of a full cache do) */
   const guint32 n_prims = e->n_prims, unsupported = e->unsupported;
   const guint n_sources = e->n_sources;
   const gboolean has_region = e->has_region;
@@ -2507,6 +2507,12 @@ record_region (HipRegion *r, GstTTMLRender *render)
      * vertical writing modes and never back, :1313-1340) */
     region_replay (render, r, e, e->prims);
     priv->region_hits++;
+    /* (most recently used last: what goes when the cache is full is the oldest) */
+    if (i + 1 < priv->region_cache->len) {
+      gpointer *pd = priv->region_cache->pdata;
+      memmove (pd + i, pd + i + 1, (priv->region_cache->len - 1 - i) * sizeof *pd);
+      pd[priv->region_cache->len - 1] = e;
+    }
     return;
   }
   /* the same region in other colours (a <set> on tts:color / tts:backgroundColor
