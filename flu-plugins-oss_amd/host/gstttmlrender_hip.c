@@ -429,6 +429,7 @@ typedef struct
   gboolean ctx_failed;
   FlutlPackWriter *dump;     /* FLUTL_DUMP_PACK=<file>: scene-pack dump */
   gboolean dump_only;        /* FLUTL_DUMP_ONLY=1: record, do not render */
+  gboolean dump_discard;     /* the pack goes to /dev/null: not written at all */
   guint8 *blank;             /* ... and hand out this blank frame */
   gsize blank_size;
   gboolean dump_defer;       /* FLUTL_DUMP_DEFER=1: dump with strokes made on worker threads */
@@ -2912,8 +2913,10 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
     flutl_recorder_resolve (rec, (flutl_region *) rg, n_rg, (flutl_prim *) pr, n_pr, patches,
         n_patches);
     atlas = flutl_recorder_atlas (rec, &atlas_size);
-    flutl_pack_writer_add (priv->dump, width, height, rg, n_rg, pr, n_pr, atlas,
-        atlas_size);
+    /* (FLUTL_DUMP_PACK=/dev/null, host-side profiles: everything but the writing) */
+    if (!priv->dump_discard)
+      flutl_pack_writer_add (priv->dump, width, height, rg, n_rg, pr, n_pr, atlas,
+          atlas_size);
   }
   if (priv->video_pad) {
     /* fused over-video: this interval is a cue for the video side; no buffer */
@@ -3628,6 +3631,7 @@ gst_ttmlrender_init (GstTTMLRender *render)
   priv->images = NULL;
   dump = g_getenv ("FLUTL_DUMP_PACK");
   priv->dump = dump ? flutl_pack_writer_new (dump) : NULL;
+  priv->dump_discard = dump && strcmp (dump, "/dev/null") == 0;
   priv->dump_only = g_getenv ("FLUTL_DUMP_ONLY") != NULL;
   priv->dump_defer = g_getenv ("FLUTL_DUMP_DEFER") != NULL;
   priv->timing = g_getenv ("FLUTL_TIMING") != NULL;
