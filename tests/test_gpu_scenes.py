@@ -150,13 +150,17 @@ def test_element_fused_over_video_through_its_request_pad(gpu, name):
 
 @pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
                     reason="fluttml-hip plugin / GStreamer runtime not present")
-def test_two_elements_in_one_process_and_a_thread_boundary_downstream(gpu, tmp_path):
-    """Two ttmlrender instances in ONE pipeline process (each with its own context,
-    finisher thread and frame pool; the stroke workers are shared), each followed by
-    a queue: buffers pile up downstream and are mapped on another thread than the
-    one that made them.  Both outputs must be the reference's frames."""
+@pytest.mark.parametrize("names", [["k04_outline", "k12_moving_outline"],
+                                   ["k16_unknown_glyphs", "k18_recolour", "k13_vertical_group",
+                                    "k20_hexbox_vertical", "k06_animation"]],
+                         ids=["two", "five"])
+def test_two_elements_in_one_process_and_a_thread_boundary_downstream(gpu, tmp_path, names):
+    """Several ttmlrender instances in ONE pipeline process (each with its own context,
+    finisher thread, frame pool and -- unlike the reference's -- font map; the stroke
+    workers are shared), each followed by a queue: buffers pile up downstream and are
+    mapped on another thread than the one that made them.  All outputs must be the
+    reference's frames."""
     import subprocess
-    names = ["k04_outline", "k12_moving_outline"]
     outs = [str(tmp_path / (n + ".raw")) for n in names]
     cmd = [os.path.join(gstenv.CONDA, "bin", "gst-launch-1.0"), "-q", "--no-fault"]
     for n, o in zip(names, outs):
