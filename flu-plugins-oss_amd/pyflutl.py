@@ -121,6 +121,9 @@ def lib():
         L.flutl_blend_over_host.argtypes = [vp, u32, u32, vp, u32, vp, u32, vp, sz]
         L.flutl_launch_frame_ordered.argtypes = [vp, u32, u32, vp, sz, vp, u32, vp, vp, u32, u32, vp]
         L.flutl_row_order.argtypes = [u32, u32, vp, u32, vp, u32, u32, u32, vp]
+        L.flutl_launch_frame_delta.argtypes = [vp, u32, u32, vp, vp, vp, sz, vp, u32, vp, vp,
+                                               u32, u32, vp, vp]
+        L.flutl_delta_segment_bytes.restype = u32
         L.flutl_row_order.restype = u32
         L.flutl_frame_create.argtypes = [vp, u32, u32, ctypes.POINTER(vp)]
         L.flutl_frame_destroy.argtypes = [vp]
@@ -211,6 +214,23 @@ def launch_frame_ordered(stream, width, height, dst, regions_dev, n_regions, pri
                                             p(prims_dev), p(atlas_dev), row0, row1,
                                             p(order_dev)),
            "flutl_launch_frame_ordered")
+
+
+def launch_frame_delta(stream, width, height, twin, host, park, regions_dev, n_regions,
+                       prims_dev, atlas_dev, row0, row1, order_dev, changed_dev=None, stride=None):
+    """composite rows [row0, row1), compare with `twin`, write what differs into `twin`
+    and `host` (any device-accessible memory); `park`: a scratch frame"""
+    p = _dev_ptr
+    _check(lib().flutl_launch_frame_delta(ctypes.c_void_p(stream), width, height, p(twin), p(host),
+                                          p(park), stride or width * 4, p(regions_dev),
+                                          n_regions, p(prims_dev), p(atlas_dev), row0, row1,
+                                          p(order_dev),
+                                          p(changed_dev) if changed_dev is not None else None),
+           "flutl_launch_frame_delta")
+
+
+def delta_segment_bytes():
+    return int(lib().flutl_delta_segment_bytes())
 
 
 def launch_batch(stream, width, height, dst, frames_dev, n_frames, regions_dev,

@@ -541,3 +541,48 @@ def test_ordered_launch_gives_the_same_frame(gpu, size):
     got = dst.cpu().numpy().view(np.uint32).reshape(H, W)
     assert np.array_equal(got[y0:y1], O.render(W, H, R, P, A)[y0:y1])
     assert (got[:y0] == 0xABABABAB).all() and (got[y1:] == 0xABABABAB).all()
+
+
+@pytest.mark.parametrize("size", [(320, 180), (333, 77), (1280, 720)])
+def test_fused_delta_launch_tracks_a_sequence_of_lists(gpu, size):
+    """flutl_launch_frame_delta, stateless: a sequence of different lists (overlapping
+    translucent groups among them: they park pixels in the scratch frame) into ONE
+    twin / host pair, each launch over the rows the old and the new content span.
+    After each: twin == host == the oracle's frame; the segment counter moves only
+    when something changed; a second launch of the same list writes nothing."""
+    import torch
+    W, H = size
+    st = torch.cuda.current_stream().cuda_stream
+    twin = torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda")
+    host = torch.zeros_like(twin)
+    park = torch.full_like(twin, 0x5A)
+    changed = torch.zeros(1, dtype=torch.int64, device="cuda")
+    seg = F.delta_segment_bytes()
+    assert seg in (64, 128, 256)
+    prev = (0, 0)
+    for i in range(7):
+        if i == 4:
+            R, P, A = scenes.random_scene(900, W, H, n_regions=0)      # an empty frame in between
+        else:
+            R, P, A = scenes.random_scene(900 + i, W, H, n_regions=2 + i % 4)
+        ys = [int(r["y0"]) for r in R if r["y1"] > r["y0"]] + [prev[0]] * (prev[1] > prev[0])
+        ye = [int(r["y1"]) for r in R if r["y1"] > r["y0"]] + [prev[1]] * (prev[1] > prev[0])
+        now = (min([int(r["y0"]) for r in R if r["y1"] > r["y0"]], default=0),
+               max([int(r["y1"]) for r in R if r["y1"] > r["y0"]], default=0))
+        if not ys:
+            continue
+        y0, y1 = min(ys), max(ye)
+        order = F.row_order(W, H, R, P, y0, y1)
+        rd, pd, ad, od = gpu.to_dev(R), gpu.to_dev(P), gpu.to_dev(A), gpu.to_dev(order)
+        for again in (False, True):
+            before = int(changed.item())
+            F.launch_frame_delta(st, W, H, twin, host, park, rd, len(R), pd, ad, y0, y1, od, changed)
+            torch.cuda.synchronize()
+            exp = O.render(W, H, R, P, A)
+            t = twin.cpu().numpy().view(np.uint32).reshape(H, W)
+            h = host.cpu().numpy().view(np.uint32).reshape(H, W)
+            assert np.array_equal(t, exp) and np.array_equal(h, exp), (i, again)
+            if again:
+                assert int(changed.item()) == before, "an unchanged frame wrote segments"
+        prev = now
+    assert 0 < int(changed.item()) * seg <= 7 * (W * 4 + seg) * H
