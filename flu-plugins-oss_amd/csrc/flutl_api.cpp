@@ -59,7 +59,7 @@ struct flutl_ctx {
   uint32_t next_slot;
   uint8_t *stage;      // page-locked staging for atlas uploads (no wait per entry)
   size_t stage_cap, stage_used;
-  uint64_t *delta_segments;   // device: 256-byte segments the delta read-backs wrote
+  uint64_t *delta_segments;   // device: segments (flutl_delta_segment_bytes) the delta read-backs wrote
 };
 
 struct flutl_frame {

@@ -72,9 +72,9 @@ enum
  * because buffers may outlive the element.
  *
  * Asynchronous completion + delta read-back: gen_buffer only QUEUES
- * the device work of a buffer (list upload, composite, and a kernel that writes
- * just the 256-byte segments that differ from what the frame held before, into
- * the host block and the twin) and returns; the streaming thread records the
+ * the device work of a buffer (list upload and ONE kernel that composites, compares
+ * with the twin and writes just the 64-byte segments that differ from what the
+ * frame held before into the host block and the twin) and returns; the streaming thread records the
  * next buffer meanwhile.  Mapping the memory waits for the frame (any thread).
  * The memory is handed out READONLY so that nobody scribbles into the block --
  * block and twin must stay equal (a downstream element that wants to write

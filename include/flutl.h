@@ -248,7 +248,7 @@ int flutl_launch_rotate_cw (void *stream, const void *src, void *dst,
 
 /* Delta read-back: compares the rows [row0, row1) of a freshly composited frame
  * (`fresh`, device, tight rows of 4*width bytes) with `twin` (device, same
- * layout) 256 bytes at a time and writes the segments that differ into `twin`
+ * layout) a segment (flutl_delta_segment_bytes ()) at a time and writes the segments that differ into `twin`
  * and into `host` -- page-locked host memory mapped into the device (the device
  * address of a flutl_host_alloc block), same layout.  With twin == host's
  * content before the call, both equal `fresh` on those rows afterwards; only
