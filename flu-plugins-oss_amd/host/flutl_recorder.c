@@ -1219,6 +1219,14 @@ run_flush (FlutlRecorder *rec)
       break;
     }
   if (!e) {                     /* first sighting: remember it, emit as before */
+    /* (a live stream without outlines never fills the atlas, so nothing else ever
+     * clears this table: bound it -- a run forgotten is a run seen for the first
+     * time again, its mask, if it has one, stays where the lists point) */
+    if (rec->n_runs >= 4096) {
+      for (uint32_t i = 0; i < rec->n_runs; i++)
+        free (rec->runs[i].key);
+      rec->n_runs = 0;
+    }
     if (rec->n_runs == rec->cap_runs) {
       rec->cap_runs = rec->cap_runs ? rec->cap_runs * 2 : 32;
       rec->runs = xrealloc (rec->runs, rec->cap_runs * sizeof (RunEntry));
