@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU-box tool: the element end to end with libflutl built for other delta segment
-sizes (flu-plugins-oss_amd/lib/dl16, dl8: -DFLUTL_DELTA_LANES=16 / 8 = 256 / 128 bytes; the default is 4 = 64).
+sizes (flu-plugins-oss_amd/lib/dl16, dl8: built beforehand with hipcc -DFLUTL_DELTA_LANES=16 / 8 = 256 / 128 bytes (command in tools/b1_variants.sh); the default is 4 = 64).
     python tools/delta_segment_ab.py [cfg2|typical_4k] [runs]"""
 import os
 import sys
