@@ -200,7 +200,29 @@ def main():
         with tempfile.NamedTemporaryFile("w", suffix=".ttml", delete=False) as f:
             f.write(doc)
         try:
-            if E2E:
+            if E2E and os.environ.get("FUZZ_VIDEO"):
+                # FUZZ_VIDEO=1: through the element's request pad (fused over-video,
+                # SURVEY 8f-3): every output frame = the REFERENCE's overlay frame of
+                # that time OVER the video frame, pixman's rule (oracle_lib.over)
+                import numpy as np
+                import gstenv
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import oracle_lib as O
+                W, H, fps, n = 320 * scale, 180 * scale, 8, 24
+                refb = gstenv.render(gstenv.REF_PLUGIN_DIR, f.name, W, H)
+                ref = np.frombuffer(refb, np.uint32).reshape(-1, H, W)
+                times = gstenv.buffer_times(gstenv.HIP_PLUGIN_DIR, f.name, W, H)
+                vraw, oraw = gstenv.render_over_video(f.name, W, H, n, fps, pattern="smpte")
+                video = np.frombuffer(vraw, np.uint32).reshape(n, H, W)
+                out = np.frombuffer(oraw, np.uint32).reshape(n, H, W)
+                ok = len(times) == len(ref)
+                for k in range(n if ok else 0):
+                    t = k * 10**9 // fps
+                    st = [i for i, (p, d) in enumerate(times) if p <= t and (d is None or t < p + d)]
+                    exp = O.over(ref[st[0]].reshape(-1), video[k].reshape(-1)).reshape(H, W) \
+                        if st else video[k]
+                    ok = ok and bool(np.array_equal(out[k], exp))
+            elif E2E:
                 import gstenv
                 W, H = 320 * scale, 180 * scale
                 ref = gstenv.render(gstenv.REF_PLUGIN_DIR, f.name, W, H)

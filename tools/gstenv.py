@@ -136,7 +136,7 @@ def buffer_times(plugin_dir, ttml_path, width, height):
         h, m, sec = t.split(":")
         return (int(h) * 3600 + int(m) * 60) * 10**9 + int(round(float(sec) * 1e9))
     out = []
-    for m in re.finditer(r"chain .*?pts: ([0-9:.]+), duration: ([0-9:.]+)", r.stdout):
-        d = ns(m.group(2))
-        out.append((ns(m.group(1)), d if d < 10**15 else None))
+    for m in re.finditer(r"chain .*?pts: ([0-9:.]+), duration: ([0-9:.]+|none)", r.stdout):
+        d = None if m.group(2) == "none" else ns(m.group(2))
+        out.append((ns(m.group(1)), d if d is not None and d < 10**15 else None))
     return out
