@@ -60,3 +60,19 @@ def test_every_stream_of_config3_has_reference_hashes():
         meta = json.load(open(os.path.join(ROOT, "bench_data", f"cfg2_seed{seed}.sha256.json")))
         assert meta["states"] == 64 and len(meta["sha256"]) == 64
         assert (meta["width"], meta["height"]) == (3840, 2160)
+
+
+def test_end_to_end_documents_have_reference_hashes_of_every_frame():
+    """The documents the element's end-to-end figures are measured on come with the
+    SHA-256 of every frame the reference renders for them (tools/make_e2e_sha.py; checked
+    on the GPU through the real pipeline by test_element_at_full_size_is_the_reference_s);
+    cfg2's agree with the per-state hashes of its scene pack."""
+    import json
+    for doc, frames in (("cfg2", 241), ("typical_4k", 121)):
+        meta = json.load(open(os.path.join(ROOT, "bench_data", doc + ".e2e_sha256.json")))
+        assert os.path.exists(os.path.join(ROOT, "bench_data", meta["document"]))
+        assert (meta["width"], meta["height"], meta["frames"]) == (3840, 2160, frames)
+        assert len(meta["sha256"]) == frames and all(len(s) == 64 for s in meta["sha256"])
+    pack = json.load(open(os.path.join(ROOT, "bench_data", "cfg2.sha256.json")))
+    e2e = json.load(open(os.path.join(ROOT, "bench_data", "cfg2.e2e_sha256.json")))
+    assert e2e["sha256"][:pack["states"]] == pack["sha256"]

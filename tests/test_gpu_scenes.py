@@ -222,3 +222,29 @@ def test_promise_buffers_through_a_converting_element(gpu, tmp_path):
     got = np.fromfile(out, np.uint8).reshape(-1, H, W, 4)
     exp = z["frames"].view(np.uint8).reshape(-1, H, W, 4)[..., [2, 1, 0, 3]]
     assert np.array_equal(got, exp)
+
+
+@pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
+                    reason="fluttml-hip plugin / GStreamer runtime not present")
+@pytest.mark.parametrize("doc,knobs", [("cfg2", {}), ("typical_4k", {}),
+                                       ("cfg2", {"FLUTL_QUEUE_ALWAYS": "1"}),
+                                       ("typical_4k", {"FLUTL_SYNC": "1"})],
+                         ids=["cfg2", "typical_4k", "cfg2-queued", "typical_4k-sync"])
+def test_element_at_full_size_is_the_reference_s(gpu, doc, knobs):
+    """The documents bench.py's end-to-end figures are measured on, through the real
+    pipeline at 3840x2160 (`filesrc ! ttmlrender ! caps ! fdsink`, frames read from the
+    pipe): SHA-256 of EVERY frame equals that of the frame the reference plugin rendered
+    from the same TTML (bench_data/<doc>.e2e_sha256.json, tools/make_e2e_sha.py) -- 241
+    frames of cfg2 (regions played back in other colours, delta read-back into pooled
+    frames) and 121 of typical_4k (an outline stroked on a worker thread per cue)."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_e2e_sha
+    meta = json.load(open(os.path.join(ROOT, "bench_data", doc + ".e2e_sha256.json")))
+    shas, rc, err = make_e2e_sha.stream_sha(
+        gstenv.HIP_PLUGIN_DIR, os.path.join(ROOT, "bench_data", doc + ".ttml"),
+        meta["width"], meta["height"], extra_env=knobs)
+    assert rc == 0, err[-1500:]
+    assert len(shas) == meta["frames"]
+    bad = [i for i, (a, b) in enumerate(zip(shas, meta["sha256"])) if a != b]
+    assert not bad, (doc, knobs, bad[:10])
