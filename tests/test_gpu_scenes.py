@@ -248,3 +248,21 @@ def test_element_at_full_size_is_the_reference_s(gpu, doc, knobs):
     assert len(shas) == meta["frames"]
     bad = [i for i, (a, b) in enumerate(zip(shas, meta["sha256"])) if a != b]
     assert not bad, (doc, knobs, bad[:10])
+
+
+@pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
+                    reason="fluttml-hip plugin / GStreamer runtime not present")
+def test_element_at_8k_is_the_reference_s(gpu):
+    """... and the first 24 buffers of cfg4.ttml at 7680x4320 (133 MB frames: 16 overlapping
+    regions, translucent groups parking pixels in the scratch frame, the pool bounded by
+    size) against the per-state hashes of the reference's frames (bench_data/cfg4.sha256.json)."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_e2e_sha
+    meta = json.load(open(os.path.join(ROOT, "bench_data", "cfg4.sha256.json")))
+    n = 24
+    shas, rc, err = make_e2e_sha.stream_sha(
+        gstenv.HIP_PLUGIN_DIR, os.path.join(ROOT, "bench_data", "cfg4.ttml"),
+        meta["width"], meta["height"], max_frames=n, stop_after=True)
+    assert rc == 0 and len(shas) == n, err[-1500:]
+    assert shas == meta["sha256"][:n], [i for i in range(n) if shas[i] != meta["sha256"][i]]

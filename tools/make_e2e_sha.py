@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import gstenv  # noqa: E402
 
 
-def stream_sha(plugin_dir, ttml, W, H, max_frames=None, extra_env=None):
+def stream_sha(plugin_dir, ttml, W, H, max_frames=None, extra_env=None, stop_after=False):
     """SHA-256 per frame of `filesrc ! ttmlrender ! caps ! fdsink`, read from the pipe"""
     cmd = [os.path.join(gstenv.CONDA, "bin", "gst-launch-1.0"), "-q", "filesrc",
            f"location={os.path.abspath(ttml)}", "!", "ttmlrender", "!",
@@ -31,6 +31,10 @@ def stream_sha(plugin_dir, ttml, W, H, max_frames=None, extra_env=None):
             break
         if max_frames is None or len(shas) < max_frames:
             shas.append(hashlib.sha256(buf).hexdigest())
+        if stop_after and max_frames is not None and len(shas) >= max_frames:
+            p.kill()            # (our own child; 8K documents are 64 GB of frames)
+            p.wait()
+            return shas, 0, ""
     err = p.stderr.read().decode(errors="replace")
     rc = p.wait()
     return shas, rc, err
