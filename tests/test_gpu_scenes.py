@@ -252,17 +252,19 @@ def test_element_at_full_size_is_the_reference_s(gpu, doc, knobs):
 
 @pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
                     reason="fluttml-hip plugin / GStreamer runtime not present")
-def test_element_at_8k_is_the_reference_s(gpu):
+@pytest.mark.parametrize("cfg,n", [("cfg0", None), ("cfg1", None), ("cfg4", 24)])
+def test_element_at_8k_is_the_reference_s(gpu, cfg, n):
     """... and the first 24 buffers of cfg4.ttml at 7680x4320 (133 MB frames: 16 overlapping
     regions, translucent groups parking pixels in the scratch frame, the pool bounded by
-    size) against the per-state hashes of the reference's frames (bench_data/cfg4.sha256.json)."""
+    size), all states of cfg0 (720p) and cfg1 (1080p), against the per-state hashes of the
+    reference's frames (bench_data/<cfg>.sha256.json)."""
     import json
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import make_e2e_sha
-    meta = json.load(open(os.path.join(ROOT, "bench_data", "cfg4.sha256.json")))
-    n = 24
+    meta = json.load(open(os.path.join(ROOT, "bench_data", cfg + ".sha256.json")))
+    n = n or meta["states"]
     shas, rc, err = make_e2e_sha.stream_sha(
-        gstenv.HIP_PLUGIN_DIR, os.path.join(ROOT, "bench_data", "cfg4.ttml"),
+        gstenv.HIP_PLUGIN_DIR, os.path.join(ROOT, "bench_data", cfg + ".ttml"),
         meta["width"], meta["height"], max_frames=n, stop_after=True)
     assert rc == 0 and len(shas) == n, err[-1500:]
     assert shas == meta["sha256"][:n], [i for i in range(n) if shas[i] != meta["sha256"][i]]
