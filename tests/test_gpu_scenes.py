@@ -268,3 +268,22 @@ def test_element_at_8k_is_the_reference_s(gpu, cfg, n):
         meta["width"], meta["height"], max_frames=n, stop_after=True)
     assert rc == 0 and len(shas) == n, err[-1500:]
     assert shas == meta["sha256"][:n], [i for i in range(n) if shas[i] != meta["sha256"][i]]
+
+
+@pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
+                    reason="fluttml-hip plugin / GStreamer runtime not present")
+def test_element_fused_over_video_at_full_size(gpu):
+    """The request pad at 3840x2160: 12 frames of videotestsrc (2 per second) with cfg2.ttml
+    composited into them by the fused kernel.  Expected, as SHA-256 per frame
+    (bench_data/cfg2.video_sha256.json, tools/make_e2e_sha.py video): the reference's overlay
+    frame of that time OVER the video frame with pixman's rule."""
+    import hashlib
+    import json
+    meta = json.load(open(os.path.join(ROOT, "bench_data", "cfg2.video_sha256.json")))
+    W, H, n = meta["width"], meta["height"], meta["frames"]
+    vraw, oraw = gstenv.render_over_video(os.path.join(ROOT, "bench_data", meta["document"]),
+                                          W, H, n, meta["fps"], pattern=meta["pattern"])
+    size = W * H * 4
+    assert len(oraw) == n * size and len(vraw) == n * size
+    got = [hashlib.sha256(oraw[k * size:(k + 1) * size]).hexdigest() for k in range(n)]
+    assert got == meta["sha256"], [k for k in range(n) if got[k] != meta["sha256"][k]]
