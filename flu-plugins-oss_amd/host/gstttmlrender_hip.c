@@ -2921,6 +2921,13 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
   if (priv->video_pad) {
     /* fused over-video: this interval is a cue for the video side; no buffer */
     video_cue_push (render, ts, duration, rg, n_rg, pr, n_pr);
+    /* No buffer for the base class to push: what it does after a push is done here.
+     * last_out_time is what clamps the intervals of events that come out of order (a
+     * <set> inside a span replays its span's timeline): left at 0, such events made
+     * cues that reached back in time over cues already made -- 296 instead of 18 for
+     * fuzz document 1510398, and a stale one was the first to cover t = 0.5 s
+     * (gstttmlbase.c:103-108, :190). */
+    base->last_out_time = ts + duration;
     return NULL;
   }
   if (priv->dump_only) {
