@@ -155,7 +155,13 @@ def gen(seed):
             body = ""
             for _ in range(r.randrange(1, 4)):
                 if r.random() < 0.5:
-                    body += f'<span {span_style(r)}>{color_sets(r)}{text(r, r.randrange(1, 4))}</span> '
+                    timing = ""
+                    if SETS and r.random() < 0.25:      # a span with an interval of its own
+                        b0 = r.choice([0.0, 0.25, 0.5])
+                        timing = f' begin="{b0:.2f}s" ' + r.choice(
+                            [f'end="{b0 + r.choice([0.25, 0.5, 1.0]):.2f}s"',
+                             f'dur="{r.choice([0.25, 0.5, 0.75]):.2f}s"', ""])
+                    body += f'<span{timing} {span_style(r)}>{color_sets(r)}{text(r, r.randrange(1, 4))}</span> '
                 else:
                     body += text(r, r.randrange(1, 4)) + " "
                 if r.random() < 0.2:
