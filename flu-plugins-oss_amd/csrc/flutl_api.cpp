@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -69,8 +70,10 @@ struct flutl_frame {
   void *host_dev;      // its device address
   void *twin;          // device
   hipEvent_t done;
-  bool pending;        // a submission has been queued since the last wait
-  int error;           // sticky: a submission failed, the content is undefined
+  // (atomics: flutl_frame_wait runs on whatever thread maps the buffer -- a tee or a
+  // shared sub-memory lets two threads wait for one frame at once)
+  std::atomic<bool> pending;   // a submission has been queued since the last wait
+  std::atomic<int> error;      // sticky: a submission failed, the content is undefined
   uint32_t ext[4];     // x0, y0, x1, y1: what the frame holds lies inside (empty: nothing)
 };
 
@@ -881,13 +884,14 @@ extern "C" int flutl_frame_wait (flutl_frame *f)
 {
   if (!f)
     return FLUTL_EINVAL;
-  if (f->pending) {
-    // (hipEventSynchronize does not depend on the calling thread's device)
+  if (f->pending.load (std::memory_order_acquire)) {
+    // (hipEventSynchronize does not depend on the calling thread's device, and
+    // several threads may wait for one event)
     if (!hip_ok (hipEventSynchronize (f->done)))
-      f->error = FLUTL_ENODEV;
-    f->pending = false;
+      f->error.store (FLUTL_ENODEV);
+    f->pending.store (false, std::memory_order_release);
   }
-  return f->error;
+  return f->error.load ();
 }
 
 extern "C" uint64_t flutl_ctx_delta_bytes (flutl_ctx *c)

@@ -83,7 +83,17 @@ enum
  * "flutl-hip-device-frame" on the memory (valid once the memory has been mapped).
  * FLUTL_FULL_D2H=1 restores synchronous whole-frame copies into writable memory. */
 #define MAX_IN_FLIGHT 16           /* buffers handed out but not yet queued on the device */
+#define VIDEO_CUES_AHEAD 64        /* fused over-video: cues the TTML side may be ahead of the video */
 #define POOL_MAX_FREE 24
+#define POOL_BUDGET_BYTES ((gsize) 640 << 20)   /* page-locked frames kept per element (+ twins in HBM) */
+
+/* Frames of `size` bytes that fit the budget run_ahead() also uses, plus the one
+ * being handed out: 20 at 4K (the caps below apply), 5 at 8K. */
+static inline guint
+pool_budget_frames (gsize size)
+{
+  return (guint) (POOL_BUDGET_BYTES / MAX (size, 1)) + 1;
+}
 
 typedef struct
 {
@@ -147,7 +157,9 @@ frame_block_release (gpointer data)
   FramePool *p = b->pool;
   g_mutex_lock (&p->lock);
   /* keep at most a few frames, and only of the current size */
-  if (b->size == p->block_size && p->free_slots->len < POOL_MAX_FREE && !b->slot->stale)
+  if (b->size == p->block_size &&
+      p->free_slots->len < MIN (POOL_MAX_FREE, pool_budget_frames (b->size)) &&
+      !b->slot->stale)
     g_ptr_array_add (p->free_slots, b->slot);
   else
     frame_slot_free (b->slot);
@@ -484,10 +496,11 @@ typedef struct
    * linked, gen_buffer records cues instead of rendering frames, and every video
    * buffer gets the cue of its time composited into it on the device */
   GstPad *video_pad;
-  GstPadEventFunction ttml_event;   /* the base class's handler of the TTML pad */
+  GstPadEventFunction ttml_event;   /* the base class's handlers of the TTML pad */
+  GstPadChainFunction ttml_chain;
   GMutex video_lock, ctx_lock;      /* ctx_lock: the device, between the two streaming threads */
   GCond video_cond;
-  gboolean video_have_caps, ttml_eos, video_flushing;
+  gboolean video_have_caps, ttml_eos, video_flushing, video_eos;
   gint video_width, video_height;
   GQueue cues;               /* VideoCue *, in time order */
   guint n_deferred;          /* buffers that went through the finisher */
@@ -1917,6 +1930,7 @@ walk_layout (GstTTMLRender *render, FlutlRecorder *rec, PangoLayout *layout,
 static gboolean flush_atlas (GstTTMLRender *render);
 static gboolean ensure_ctx (GstTTMLRender *render);
 static void pipeline_drain (GstTTMLRender *render);
+static gboolean video_cues_drained (GstTTMLRender *render);
 static void video_cue_push (GstTTMLRender *render, GstClockTime ts, GstClockTime duration,
     const flutl_region *rg, guint32 n_rg, const flutl_prim *pr, guint32 n_pr);
 
@@ -2755,7 +2769,7 @@ run_ahead (GstTTMLRenderPrivate *priv, gint width, gint height)
 {
   if (priv->max_ahead)
     return priv->max_ahead;
-  return (guint) CLAMP (((gsize) 640 << 20) / MAX ((gsize) width * height * 4, 1), 3,
+  return (guint) CLAMP (POOL_BUDGET_BYTES / MAX ((gsize) width * height * 4, 1), 3,
       MAX_IN_FLIGHT);
 }
 
@@ -2858,8 +2872,9 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
     flutl_recorder_lock (rec);
     (void) flutl_recorder_atlas (rec, &atlas_bytes);
     flutl_recorder_unlock (rec);
-    /* (a dump keeps one atlas; so do the cues queued for the video side) */
-    if (atlas_bytes > priv->atlas_limit && !priv->dump && !priv->video_pad) {
+    /* (a dump keeps one atlas; so do the cues queued for the video side: there the
+     * atlas starts over once the video has used up every cue made so far) */
+    if (atlas_bytes > priv->atlas_limit && !priv->dump && video_cues_drained (render)) {
       GST_INFO_OBJECT (render, "atlas at %" G_GSIZE_FORMAT " bytes: dropping the mask caches",
           atlas_bytes);
       caches_drop (render);
@@ -2968,8 +2983,13 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
       uint32_t n_def = 0;
       (void) flutl_recorder_patches (rec, &n_def);
       const guint ahead = run_ahead (priv, width, height);
+      /* (the default of 8 is a number for 4K: by bytes it is the run-ahead budget
+       * plus the frame being handed out -- 5 frames at 8K, not a gigabyte of
+       * page-locked memory and as much HBM at the first buffer) */
+      const guint first = priv->pool_prefill_set ? priv->pool_prefill
+          : MIN (priv->pool_prefill, pool_budget_frames (size));
       frame_pool_prefill (priv->pool, priv->ctx, width, height,
-          n_def && !priv->pool_prefill_set ? MAX (priv->pool_prefill, ahead) : priv->pool_prefill);
+          n_def && !priv->pool_prefill_set ? MAX (first, ahead) : first);
     }
     FrameSlot *slot = frame_pool_take (priv->pool, priv->ctx, width, height, async);
     int rc = FLUTL_OK;
@@ -3350,9 +3370,31 @@ video_cue_push (GstTTMLRender *render, GstClockTime ts, GstClockTime duration,
   c->regions = g_memdup (rg, n_rg * sizeof *rg);
   c->prims = g_memdup (pr, n_pr * sizeof *pr);
   g_mutex_lock (&priv->video_lock);
+  /* The parser runs through a whole document at once: without a bound a long or live
+   * stream queues cues (and pins the masks they name) without limit.  The TTML thread
+   * waits here while VIDEO_CUES_AHEAD cues are ahead of the video -- unless nothing
+   * will ever take them (video at EOS, flushing, shutting down). */
+  while (g_queue_get_length (&priv->cues) >= VIDEO_CUES_AHEAD && !priv->video_flushing &&
+      !priv->video_eos)
+    g_cond_wait (&priv->video_cond, &priv->video_lock);
   g_queue_push_tail (&priv->cues, c);
   g_cond_broadcast (&priv->video_cond);
   g_mutex_unlock (&priv->video_lock);
+}
+
+/* TRUE when no cue is waiting for its video frames (always, outside video mode):
+ * only then may the masks the cues name be dropped. */
+static gboolean
+video_cues_drained (GstTTMLRender *render)
+{
+  GstTTMLRenderPrivate *priv = get_priv (render);
+  gboolean drained;
+  if (!priv->video_pad)
+    return TRUE;
+  g_mutex_lock (&priv->video_lock);
+  drained = g_queue_is_empty (&priv->cues);
+  g_mutex_unlock (&priv->video_lock);
+  return drained;
 }
 
 static GstFlowReturn
@@ -3371,7 +3413,10 @@ video_chain (GstPad *pad, GstObject *parent, GstBuffer *buffer)
     VideoCue *c;
     while ((c = g_queue_peek_head (&priv->cues)) && GST_CLOCK_TIME_IS_VALID (c->end) &&
         GST_CLOCK_TIME_IS_VALID (t) && c->end <= t)
+    {
       video_cue_free (g_queue_pop_head (&priv->cues));      /* video time only moves on */
+      g_cond_broadcast (&priv->video_cond);                 /* (room for the TTML side) */
+    }
     c = g_queue_peek_head (&priv->cues);
     if (c && (!GST_CLOCK_TIME_IS_VALID (t) || c->start <= t)) {
       cue = c;
@@ -3444,13 +3489,21 @@ video_event (GstPad *pad, GstObject *parent, GstEvent *event)
        * when the frame size is already known while it parses -- fontSize="1c"
        * becomes a cell WIDTH then, gstttmlattribute.c:702-704 -- and the parser
        * runs on the other thread) */
-      g_mutex_lock (&priv->video_lock);
-      priv->video_width = w;
-      priv->video_height = h;
-      priv->video_have_caps = TRUE;
-      g_cond_broadcast (&priv->video_cond);
-      g_mutex_unlock (&priv->video_lock);
-      return gst_pad_push_event (base->srcpad, event);
+      /* The caps go downstream BEFORE the TTML side is let go (ttml_chain_in_video_mode
+       * waits for video_have_caps): the base class negotiates the src pad on the TTML
+       * thread right before gen_buffer when the pad has no caps yet
+       * (gstttmlbase.c:115, :922-975) -- with the overlay template fixated to the
+       * window size, which would land between the video's caps and its buffers. */
+      {
+        const gboolean ok = gst_pad_push_event (base->srcpad, event);
+        g_mutex_lock (&priv->video_lock);
+        priv->video_width = w;
+        priv->video_height = h;
+        priv->video_have_caps = ok;
+        g_cond_broadcast (&priv->video_cond);
+        g_mutex_unlock (&priv->video_lock);
+        return ok;
+      }
     }
     case GST_EVENT_FLUSH_START:
       g_mutex_lock (&priv->video_lock);
@@ -3461,6 +3514,13 @@ video_event (GstPad *pad, GstObject *parent, GstEvent *event)
     case GST_EVENT_FLUSH_STOP:
       g_mutex_lock (&priv->video_lock);
       priv->video_flushing = FALSE;
+      priv->video_eos = FALSE;
+      g_mutex_unlock (&priv->video_lock);
+      break;
+    case GST_EVENT_EOS:
+      g_mutex_lock (&priv->video_lock);
+      priv->video_eos = TRUE;             /* (nobody will take further cues) */
+      g_cond_broadcast (&priv->video_cond);
       g_mutex_unlock (&priv->video_lock);
       break;
     default:
@@ -3496,6 +3556,50 @@ ttml_event_in_video_mode (GstPad *pad, GstObject *parent, GstEvent *event)
     }
   }
   return priv->ttml_event (pad, parent, event);
+}
+
+/* The TTML pad's data in video mode: held back until the video's caps are on the src
+ * pad, so that the base class finds the pad negotiated and leaves it alone (see
+ * video_event). */
+static GstFlowReturn
+ttml_chain_in_video_mode (GstPad *pad, GstObject *parent, GstBuffer *buffer)
+{
+  GstTTMLRender *render = GST_TTMLRENDER (parent);
+  GstTTMLRenderPrivate *priv = get_priv (render);
+  if (priv->video_pad) {
+    gboolean flushing;
+    g_mutex_lock (&priv->video_lock);
+    while (!priv->video_have_caps && !priv->video_flushing && !priv->video_eos)
+      g_cond_wait (&priv->video_cond, &priv->video_lock);
+    flushing = priv->video_flushing || !priv->video_have_caps;
+    g_mutex_unlock (&priv->video_lock);
+    if (flushing) {
+      gst_buffer_unref (buffer);
+      return GST_FLOW_FLUSHING;
+    }
+  }
+  return priv->ttml_chain (pad, parent, buffer);
+}
+
+/* Going down: nothing may keep waiting for the other side (pad deactivation takes
+ * the streaming threads' locks). */
+static GstStateChangeReturn
+gst_ttmlrender_change_state (GstElement *element, GstStateChange transition)
+{
+  GstTTMLRenderPrivate *priv = get_priv (GST_TTMLRENDER (element));
+  if (transition == GST_STATE_CHANGE_PAUSED_TO_READY) {
+    g_mutex_lock (&priv->video_lock);
+    priv->video_flushing = TRUE;
+    g_cond_broadcast (&priv->video_cond);
+    g_mutex_unlock (&priv->video_lock);
+  } else if (transition == GST_STATE_CHANGE_READY_TO_PAUSED) {
+    g_mutex_lock (&priv->video_lock);
+    priv->video_flushing = FALSE;
+    priv->video_eos = priv->ttml_eos = FALSE;
+    priv->video_have_caps = FALSE;
+    g_mutex_unlock (&priv->video_lock);
+  }
+  return GST_ELEMENT_CLASS (gst_ttmlrender_parent_class)->change_state (element, transition);
 }
 
 static GstPad *
@@ -3584,6 +3688,7 @@ gst_ttmlrender_class_init (GstTTMLRenderClass *klass)
         gst_static_pad_template_get (&video_template));
     element_class->request_new_pad = gst_ttmlrender_request_new_pad;
     element_class->release_pad = gst_ttmlrender_release_pad;
+    element_class->change_state = gst_ttmlrender_change_state;
   }
 
   base_class->gen_buffer = gst_ttmlrender_gen_buffer;
@@ -3656,6 +3761,8 @@ gst_ttmlrender_init (GstTTMLRender *render)
   /* (the base class has installed its handler on the TTML pad by now) */
   priv->ttml_event = GST_PAD_EVENTFUNC (render->base.sinkpad);
   gst_pad_set_event_function (render->base.sinkpad, ttml_event_in_video_mode);
+  priv->ttml_chain = GST_PAD_CHAINFUNC (render->base.sinkpad);
+  gst_pad_set_chain_function (render->base.sinkpad, ttml_chain_in_video_mode);
   priv->sync_mode = g_getenv ("FLUTL_SYNC") != NULL;
   priv->queue_always = g_getenv ("FLUTL_QUEUE_ALWAYS") != NULL;
   priv->max_ahead = g_getenv ("FLUTL_MAX_AHEAD")

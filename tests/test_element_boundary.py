@@ -144,3 +144,49 @@ def test_video_mode_makes_the_cues_the_stand_alone_element_makes_buffers_of(tmp_
     assert len(packs[False]) == 18 and len(packs[True]) == 18, (len(packs[False]), len(packs[True]))
     for (Ra, Pa), (Rb, Pb) in zip(packs[False], packs[True]):
         assert np.array_equal(Ra, Rb) and np.array_equal(Pa, Pb)
+
+
+@pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
+                    reason="fluttml-hip plugin / GStreamer runtime not present")
+def test_video_mode_leaves_the_src_caps_to_the_video(tmp_path):
+    """In the fused mode the src pad carries the VIDEO's caps.  The base class
+    negotiates the src pad itself on the TTML thread when it finds it without caps
+    right before gen_buffer (gstttmlbase.c:115, :922-975: the overlay template, BGRA at
+    the window size), which would race with the video's stream-start and caps.  The TTML
+    side is held back until the video's caps are on the pad.  Downstream here converts
+    and constrains (videoconvert + capsfilter: wrong geometry or a second caps event
+    cannot pass unnoticed as it does into filesink), the video is NOT the window size
+    and the TTML thread is ready long before the video thread (delayed by a queue
+    behind a slow start): every run must deliver every frame, converted, in order."""
+    ttml = os.path.join(ROOT, "tests", "golden", "scenes", "k06_animation.ttml")
+    gst = os.path.join(gstenv.CONDA, "bin", "gst-launch-1.0")
+    W, H, N = 352, 200, 7        # (not the 720x576 window the overlay template fixates to)
+    vcaps = f"video/x-raw,format=BGRA,width={W},height={H},framerate=3/1"
+    plain = str(tmp_path / "plain.raw")
+    env = gstenv.env_for(gstenv.HIP_PLUGIN_DIR, {
+        "FLUTL_VIDEO_PAD": "1", "FLUTL_DUMP_ONLY": "1", "FLUTL_DUMP_PACK": os.devnull})
+    r = subprocess.run([gst, "-q", "videotestsrc", f"num-buffers={N}", "!", vcaps, "!",
+                        "videoconvert", "!", f"video/x-raw,format=RGB,width={W},height={H}", "!",
+                        "filesink", "location=" + plain],
+                       env=env, capture_output=True, text=True, cwd=str(tmp_path), timeout=120)
+    assert r.returncode == 0, r.stderr[-1000:]
+    want = open(plain, "rb").read()
+    assert len(want) == N * W * H * 3
+    for run in range(4):
+        out = str(tmp_path / f"subs{run}.raw")
+        cmd = [gst, "-v", "videotestsrc", f"num-buffers={N}", "!", vcaps, "!",
+               "queue", "!", "identity", "sleep-time=20000", "!", "r.video_sink",
+               "filesrc", "location=" + ttml, "!", "ttmlrender", "name=r", "!",
+               "videoconvert", "!", f"video/x-raw,format=RGB,width={W},height={H}", "!",
+               "filesink", "location=" + out]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=str(tmp_path),
+                           timeout=120)
+        assert r.returncode == 0, r.stderr[-1000:]
+        assert "not-negotiated" not in r.stderr and "CRITICAL" not in r.stderr, r.stderr[-1000:]
+        # the base class's own negotiation used to show as caps ahead of the video's
+        # stream-start ("Sticky event misordering") and as a second set of caps
+        assert "misordering" not in r.stderr, r.stderr[-1000:]
+        src_caps = [l for l in r.stdout.splitlines() if "GstTTMLRender:r.GstPad:src: caps" in l]
+        assert len(src_caps) == 1 and "framerate=(fraction)3/1" in src_caps[0], src_caps
+        # (record-only: cues are made, the frames pass through unchanged)
+        assert open(out, "rb").read() == want, f"run {run}"
