@@ -442,12 +442,8 @@ flutl_tor_polygon_box (const int32_t *edges, int n, int box[4])
       if (x >= x0 && x <= x1)
         continue;
       if (at != py && dy) {
-        /* _cairo_edge_compute_intersection_x_for_y: floored division */
-        const int64_t num = (int64_t) (at - e[1]) * ((int64_t) e[2] - e[0]);
-        int64_t q = num / dy, r = num % dy;
-        if (r && ((r < 0) != (dy < 0)))
-          q--;
-        x = e[0] + q;
+        /* _cairo_edge_compute_intersection_x_for_y (C's truncating division) */
+        x = e[0] + ((int64_t) (at - e[1]) * ((int64_t) e[2] - e[0])) / dy;
       }
       if (x < x0) x0 = x;
       if (x > x1) x1 = x;
