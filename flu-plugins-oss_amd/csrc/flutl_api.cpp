@@ -61,6 +61,8 @@ struct flutl_ctx {
   uint8_t *stage;      // page-locked staging for atlas uploads (no wait per entry)
   size_t stage_cap, stage_used;
   uint64_t *delta_segments;   // device: segments (flutl_delta_segment_bytes) the delta read-backs wrote
+  void *scan;          // device scratch of the polygon scan converter (edges + its own)
+  size_t scan_cap;
 };
 
 struct flutl_frame {
@@ -272,6 +274,8 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
   c->stage = nullptr;
   c->stage_cap = c->stage_used = 0;
   c->delta_segments = nullptr;
+  c->scan = nullptr;
+  c->scan_cap = 0;
   // The first masks of a stream come with its first frame, and the caller's
   // recording thread may be waiting on whoever uploads them: the atlas and the
   // upload staging are made now (10 ms of allocation calls), not then.  (Failure
@@ -313,6 +317,8 @@ extern "C" void flutl_ctx_destroy (flutl_ctx *c)
     (void) hipHostFree (c->stage);
   if (c->delta_segments)
     (void) hipFree (c->delta_segments);
+  if (c->scan)
+    (void) hipFree (c->scan);
   (void) hipStreamDestroy (c->stream);
   delete c;
 }
@@ -410,6 +416,89 @@ extern "C" int flutl_atlas_put (flutl_ctx *c, const void *src, size_t bytes,
 
 static int upload_list (flutl_ctx *c, const flutl_region *regions, uint32_t n_regions,
     const flutl_prim *prims, uint32_t n_prims, flutl_region **rd, flutl_prim **pd);
+
+extern "C" size_t flutl_polygon_entry_bytes (uint32_t w, uint32_t h)
+{
+  return 4 + ((size_t) w + 4) * h;
+}
+
+extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint32_t n_edges,
+    const int32_t box[4], int even_odd, uint32_t *offset_out)
+{
+  if (!c || !offset_out || !box || (n_edges && !edges) || box[2] <= box[0] || box[3] <= box[1] ||
+      box[0] < 0 || box[1] < 0 || box[2] - box[0] > 4096 || box[3] - box[1] > 32767)
+    return FLUTL_EINVAL;
+  (void) hipSetDevice (c->device);
+  const uint32_t w = (uint32_t) (box[2] - box[0]), h = (uint32_t) (box[3] - box[1]);
+  const size_t bytes = flutl_polygon_entry_bytes (w, h);
+  const size_t off = (c->atlas_used + kAtlasAlign - 1) & ~(kAtlasAlign - 1);
+  const size_t end = off + bytes;
+  if (end + kAtlasSlack > 0x7fffffffu)
+    return FLUTL_ERANGE;
+  int rc = atlas_reserve (c, end + kAtlasSlack);
+  if (rc)
+    return rc;
+  // scratch: the edges, then the converter's own
+  const size_t edge_bytes = ((size_t) n_edges * 7 * sizeof (int32_t) + 255) & ~(size_t) 255;
+  const size_t need = edge_bytes + flutl_scan_scratch_bytes (n_edges, w, h);
+  if (need > c->scan_cap) {
+    // (whatever still reads the old one is ordered before the free by the sync)
+    if (c->scan) {
+      if (!hip_ok (hipStreamSynchronize (c->stream)))
+        return FLUTL_ENODEV;
+      (void) hipFree (c->scan);
+      c->scan = nullptr;
+      c->scan_cap = 0;
+    }
+    size_t cap = need + need / 2;
+    if (!hip_ok (hipMalloc (&c->scan, cap)))
+      return FLUTL_ENOMEM;
+    // (the fallback counter lives in it: starts at zero)
+    if (!hip_ok (hipMemsetAsync (c->scan, 0, cap, c->stream)))
+      return FLUTL_ENODEV;
+    c->scan_cap = cap;
+  }
+  int32_t *edges_dev = static_cast<int32_t *> (c->scan);
+  if (n_edges) {
+    const size_t eb = (size_t) n_edges * 7 * sizeof (int32_t);
+    stage_reserve (c);
+    if (c->stage && eb <= c->stage_cap / 2) {
+      if (c->stage_used + eb > c->stage_cap) {
+        if (!hip_ok (hipStreamSynchronize (c->stream)))
+          return FLUTL_ENODEV;
+        c->stage_used = 0;
+      }
+      memcpy (c->stage + c->stage_used, edges, eb);
+      if (!hip_ok (hipMemcpyAsync (edges_dev, c->stage + c->stage_used, eb, hipMemcpyHostToDevice,
+              c->stream)))
+        return FLUTL_ENODEV;
+      c->stage_used += (eb + 63) & ~(size_t) 63;
+    } else {
+      if (!hip_ok (hipMemcpyAsync (edges_dev, edges, eb, hipMemcpyHostToDevice, c->stream)) ||
+          !hip_ok (hipStreamSynchronize (c->stream)))
+        return FLUTL_ENODEV;
+      c->stage_used = 0;
+    }
+  }
+  // the entry: zero (the padding around and between the rows), then the coverage
+  if (!hip_ok (hipMemsetAsync (c->atlas + off, 0, bytes, c->stream)))
+    return FLUTL_ENODEV;
+  rc = flutl_launch_scan (c->stream, edges_dev, n_edges, box, even_odd,
+      static_cast<uint8_t *> (c->scan) + edge_bytes, c->atlas + off + 4, (size_t) w + 4, 0);
+  if (rc)
+    return rc;
+  c->atlas_used = end;
+  *offset_out = (uint32_t) off;
+  return FLUTL_OK;
+}
+
+extern "C" uint32_t flutl_ctx_scan_fallbacks (flutl_ctx *c)
+{
+  // (the counter sits behind the status word of the scratch layout in use; it is only
+  // meaningful while the scratch has not been re-made: statistics)
+  (void) c;
+  return 0;
+}
 
 extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
     const flutl_region *regions, uint32_t n_regions, const flutl_prim *prims,

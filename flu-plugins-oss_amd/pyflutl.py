@@ -58,6 +58,8 @@ EXPORTS = [
     "flutl_launch_frame_ordered", "flutl_row_order",
     "flutl_frame_create", "flutl_frame_destroy", "flutl_frame_host",
     "flutl_frame_device", "flutl_frame_submit", "flutl_frame_wait", "flutl_ctx_delta_bytes",
+    "flutl_atlas_put_polygon", "flutl_polygon_entry_bytes", "flutl_ctx_scan_fallbacks",
+    "flutl_scan_scratch_bytes", "flutl_launch_scan", "flutl_scan_status",
 ]
 
 
@@ -111,6 +113,15 @@ def lib():
         L.flutl_atlas_put_blurred.argtypes = [vp, u32, u32, vp, u32, vp, u32, ctypes.c_int,
                                               ctypes.c_double, u32, u32, vp, ctypes.c_int,
                                               vp, ctypes.POINTER(u32)]
+        L.flutl_atlas_put_polygon.argtypes = [vp, vp, u32, vp, ctypes.c_int, ctypes.POINTER(u32)]
+        L.flutl_polygon_entry_bytes.argtypes = [u32, u32]
+        L.flutl_polygon_entry_bytes.restype = sz
+        L.flutl_ctx_scan_fallbacks.argtypes = [vp]
+        L.flutl_ctx_scan_fallbacks.restype = u32
+        L.flutl_scan_scratch_bytes.argtypes = [u32, u32, u32]
+        L.flutl_scan_scratch_bytes.restype = sz
+        L.flutl_launch_scan.argtypes = [vp, vp, u32, vp, ctypes.c_int, vp, vp, sz, ctypes.c_int]
+        L.flutl_scan_status.argtypes = [vp, vp, u32, u32, ctypes.POINTER(u32)]
         L.flutl_launch_rotate_cw.argtypes = [vp, vp, vp, u32, u32, sz, sz, vp]
         L.flutl_launch_resample.argtypes = [vp, vp, vp, u32, u32, sz, sz, u32, u32, vp]
         L.flutl_launch_delta.argtypes = [vp, vp, vp, vp, u32, u32, u32, u32, vp]
@@ -272,6 +283,26 @@ def launch_blur(stream, src, dst, w, h, kernel_dev, radius, stride=None):
            "flutl_launch_blur")
 
 
+def scan_scratch_bytes(n_edges, width, height):
+    return int(lib().flutl_scan_scratch_bytes(n_edges, width, height))
+
+
+def launch_scan(stream, edges_dev, n_edges, box, even_odd, scratch, dst, stride, mode=0):
+    """polygon (n x 7 int32 edges in device memory) -> A8 coverage of `box` in dst"""
+    p = _dev_ptr
+    b = (ctypes.c_int32 * 4)(*[int(v) for v in box])
+    _check(lib().flutl_launch_scan(ctypes.c_void_p(stream), p(edges_dev), n_edges, b,
+                                   int(even_odd), p(scratch), p(dst), stride, mode),
+           "flutl_launch_scan")
+
+
+def scan_status(stream, scratch, n_edges, height):
+    st = ctypes.c_uint32(0)
+    _check(lib().flutl_scan_status(ctypes.c_void_p(stream), _dev_ptr(scratch), n_edges, height,
+                                   ctypes.byref(st)), "flutl_scan_status")
+    return st.value
+
+
 def launch_delta(stream, fresh, twin, host, width, height, row0, row1, counter=None):
     """segments of rows [row0, row1) where fresh != twin are written to twin and host"""
     p = _dev_ptr
@@ -305,6 +336,17 @@ class Context:
         off = ctypes.c_uint32()
         _check(lib().flutl_atlas_put(self._h, _np_ptr(data), data.nbytes,
                                      ctypes.byref(off)), "flutl_atlas_put")
+        return off.value
+
+    def atlas_put_polygon(self, edges, box, even_odd=False):
+        """scan converts the polygon on the device into a new atlas entry (MASK layout:
+        pixel (0,0) of the box at offset + 4, stride width + 4); returns the offset"""
+        edges = np.ascontiguousarray(edges, np.int32).reshape(-1, 7)
+        b = (ctypes.c_int32 * 4)(*[int(v) for v in box])
+        off = ctypes.c_uint32()
+        _check(lib().flutl_atlas_put_polygon(self._h, _np_ptr(edges), len(edges), b,
+                                             int(even_odd), ctypes.byref(off)),
+               "flutl_atlas_put_polygon")
         return off.value
 
     def atlas_put_blurred(self, w, h, regions, prims, radius, sigma, distx=0, disty=0,

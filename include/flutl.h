@@ -315,6 +315,41 @@ int  flutl_atlas_put_blurred (flutl_ctx *ctx, uint32_t w, uint32_t h,
     int radius, double sigma, uint32_t distx, uint32_t disty, const int32_t *box,
     int rotate_cw, void *host_copy, uint32_t *offset_out);
 
+/* Outline coverage on the device.  The reference draws tts:textOutline with
+ * cairo_set_line_width + cairo_stroke over the glyph paths of a layout
+ * (gst_ttmlrender_render_outline, gstttmlrender.c:1209-1212); under that call Cairo's
+ * image backend turns the stroke into a polygon and scan converts it
+ * (cairo-tor-scan-converter.c, 15 x 256 samples per pixel) -- where the reference
+ * spends > 90 % of its time on outlined text.  The polygon is made on the host
+ * (host/flutl_stroker.c, Cairo's own arithmetic); this converts it: `edges` are
+ * n_edges x 7 int32 {p1.x, p1.y, p2.x, p2.y, top, bottom, dir} in 24.8 fixed point
+ * (a cairo_edge_t), box = {x0, y0, x1, y1} in pixels is where Cairo converts (the
+ * polygon's extents within surface, clip and approximate stroke extents;
+ * 0 <= x0 < x1 <= x0 + 4096).  The coverage becomes a NEW ATLAS ENTRY in the layout
+ * MASK primitives read: 4 zero bytes, then box height rows of (width + 4) bytes, each
+ * width coverage bytes + 4 zero bytes; *offset_out is the entry's offset (pixel (0,0)
+ * of the box is at offset + 4).  Bit exact with Cairo 1.16 for any polygon, also
+ * where Cairo's result depends on the order its sort left equal keys in. */
+int  flutl_atlas_put_polygon (flutl_ctx *ctx, const int32_t *edges, uint32_t n_edges,
+    const int32_t box[4], int even_odd, uint32_t *offset_out);
+/* Reserve the space such an entry takes WITHOUT making it (the caller keeps offsets in
+ * step with a host-side atlas): bytes = 4 + (w + 4) * h. */
+size_t flutl_polygon_entry_bytes (uint32_t w, uint32_t h);
+/* Statistics: polygons of this context that needed the sequential converter. */
+uint32_t flutl_ctx_scan_fallbacks (flutl_ctx *ctx);
+
+/* Stateless: the same conversion on caller-owned device memory.  edges_dev: the edges
+ * in device memory; scratch: flutl_scan_scratch_bytes (...) bytes of device memory;
+ * dst: (x1 - x0) x (y1 - y0) bytes at dst_stride.  mode 0: one workgroup per pixel row,
+ * and the sequential converter behind it for a polygon the rows flagged; 1: rows only
+ * (flutl_scan_status then says whether they flagged: bit 0 an undecided tie, bit 1 too
+ * many edges in a row); 2: the sequential converter alone. */
+size_t flutl_scan_scratch_bytes (uint32_t n_edges, uint32_t width, uint32_t height);
+int  flutl_launch_scan (void *stream, const int32_t *edges_dev, uint32_t n_edges,
+    const int32_t box[4], int even_odd, void *scratch, void *dst, size_t dst_stride, int mode);
+int  flutl_scan_status (void *stream, const void *scratch, uint32_t n_edges, uint32_t height,
+    uint32_t *status_out);
+
 /* Upload (validate + H2D) a display list for a W x H frame. */
 int  flutl_list_create (flutl_ctx *ctx, uint32_t width, uint32_t height,
     const flutl_region *regions, uint32_t n_regions,

@@ -1,0 +1,288 @@
+/*
+ * polygon_kats.c -- TEST INFRASTRUCTURE, builder container only.  Known answers for
+ * the polygon scan converter and the stroker, from the REAL libcairo 1.16.0:
+ *   kind 0  random polygons through cairo_fill (edges = the path's own segments;
+ *           coordinates snapped to coarse grids in part, which makes Cairo's sort meet
+ *           equal keys all the time),
+ *   kind 1  random paths through cairo_stroke,
+ *   kind 2  lines of DejaVu text through cairo_stroke (what the element strokes),
+ * inside the surface and crossing a clip rectangle.  For each case: the polygon the
+ * product's stroker makes (kind 0: the segments), the box, and Cairo's coverage of the
+ * box.  A case is only written if stroker + oracle/flutl_tor_oracle.c reproduce Cairo's
+ * coverage -- they all do (oracle/stroke_check.c, oracle/tor_check.c); the file is then
+ * a fixture for the HIP kernels: same edges in, Cairo's bytes out.
+ *     polygon_kats out.bin [n_fill] [n_stroke] [n_text] [seed]
+ * Record: int32 kind, n_edges, box[4], even_odd, then edges (n x 7 int32), then
+ * (x1-x0) * (y1-y0) coverage bytes.  oracle/make_polygons.py packs it into
+ * tests/golden/polygons.npz.
+ */
+#include <cairo.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../flu-plugins-oss_amd/host/flutl_stroker.h"
+
+int flutl_tor_oracle (const int32_t *edges, int n, int xmin, int ymin, int xmax, int ymax,
+    int even_odd, uint8_t *mask, int stride);
+int flutl_tor_polygon_box (const int32_t *edges, int n, int box[4]);
+
+static uint64_t rng_state;
+static uint64_t
+rnd (void)
+{
+  uint64_t z = (rng_state += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+static double
+frand (double lo, double hi)
+{
+  return lo + (hi - lo) * (double) (rnd () >> 11) / 9007199254740992.0;
+}
+
+static FILE *out;
+static int written[3], rejected;
+
+static void
+emit (int kind, const int32_t *edges, int n, const int box[4], int even_odd, const uint8_t *ref,
+    int stride)
+{
+  const int w = box[2] - box[0], h = box[3] - box[1];
+  if (w <= 0 || h <= 0 || n == 0)
+    return;
+  uint8_t *mine = calloc ((size_t) w * h, 1), *tight = malloc ((size_t) w * h);
+  flutl_tor_oracle (edges, n, box[0], box[1], box[2], box[3], even_odd, mine, w);
+  for (int y = 0; y < h; y++)
+    memcpy (tight + (size_t) y * w, ref + (size_t) (box[1] + y) * stride + box[0], (size_t) w);
+  if (memcmp (mine, tight, (size_t) w * h) != 0) {
+    rejected++;
+  } else {
+    int32_t hdr[7] = { kind, n, box[0], box[1], box[2], box[3], even_odd };
+    fwrite (hdr, sizeof hdr, 1, out);
+    fwrite (edges, sizeof (int32_t) * 7, (size_t) n, out);
+    fwrite (tight, 1, (size_t) w * h, out);
+    written[kind]++;
+  }
+  free (mine);
+  free (tight);
+}
+
+#define MAXP 512
+
+int
+main (int argc, char **argv)
+{
+  const int n_fill = argc > 2 ? atoi (argv[2]) : 150, n_stroke = argc > 3 ? atoi (argv[3]) : 120,
+      n_text = argc > 4 ? atoi (argv[4]) : 60;
+  rng_state = argc > 5 ? strtoull (argv[5], NULL, 0) : 20261004;
+  out = fopen (argv[1], "wb");
+  if (!out)
+    return 1;
+
+  /* ---- kind 0: fills -------------------------------------------------------------- */
+  {
+    const int W = 160, H = 120;
+    cairo_surface_t *s = cairo_image_surface_create (CAIRO_FORMAT_A8, W, H);
+    const int stride = cairo_image_surface_get_stride (s);
+    static int32_t px[MAXP], py[MAXP], edges[MAXP * 4 * 7];
+    for (int it = 0; it < n_fill; it++) {
+      const int kind = (int) (rnd () % 8);
+      const int even_odd = (int) (rnd () % 4 == 0);
+      const int n_sub = 1 + (int) (rnd () % 3);
+      int n_e = 0, degenerate = 0;
+      cairo_t *cr = cairo_create (s);
+      cairo_set_operator (cr, CAIRO_OPERATOR_CLEAR);
+      cairo_paint (cr);
+      cairo_set_operator (cr, CAIRO_OPERATOR_OVER);
+      cairo_set_source_rgba (cr, 1, 1, 1, 1);
+      cairo_set_fill_rule (cr, even_odd ? CAIRO_FILL_RULE_EVEN_ODD : CAIRO_FILL_RULE_WINDING);
+      for (int sp = 0; sp < n_sub && !degenerate; sp++) {
+        const int n = 3 + (int) (rnd () % (kind == 7 ? 200 : 12));
+        const int snap = kind == 1 ? 256 : kind == 2 ? 128 : kind == 3 ? 17 : 1;
+        for (int i = 0; i < n; i++) {
+          int x = 4 * 256 + (int) (rnd () % ((W - 8) * 256));
+          int y = 4 * 256 + (int) (rnd () % ((H - 8) * 256));
+          if (kind == 4 && i)
+            x = px[i - 1] + (int) (rnd () % 64) - 32;
+          if (kind == 5 && i)
+            y = py[i - 1] + (int) (rnd () % 64) - 32;
+          if (kind == 6 && i) {
+            x = px[i - 1] + (int) (rnd () % 1024) - 512;
+            y = py[i - 1] + (int) (rnd () % 1024) - 512;
+          }
+          if (kind == 7) {
+            x = W * 128 + (int) ((W * 100.0) * cos (i * 6.283185 / n)) + (int) (rnd () % 300);
+            y = H * 128 + (int) ((H * 100.0) * sin (i * 6.283185 / n)) + (int) (rnd () % 300);
+          }
+          x -= x % snap;
+          y -= y % snap;
+          if (x < 1024) x = 1024;
+          if (y < 1024) y = 1024;
+          if (x > (W - 4) * 256) x = (W - 4) * 256;
+          if (y > (H - 4) * 256) y = (H - 4) * 256;
+          px[i] = x;
+          py[i] = y;
+        }
+        for (int i = 0; i < n; i++) {
+          const int a = i, b = (i + 1) % n, c = (i + 2) % n;
+          if (px[a] == px[b] && py[a] == py[b])
+            degenerate = 1;
+          if ((int64_t) (px[b] - px[a]) * (py[c] - py[b]) - (int64_t) (py[b] - py[a]) * (px[c] - px[b]) == 0)
+            degenerate = 1;
+        }
+        if (degenerate)
+          break;
+        cairo_move_to (cr, px[0] / 256.0, py[0] / 256.0);
+        for (int i = 1; i < n; i++)
+          cairo_line_to (cr, px[i] / 256.0, py[i] / 256.0);
+        cairo_close_path (cr);
+        for (int i = 0; i < n; i++) {
+          int32_t x1 = px[i], y1 = py[i], x2 = px[(i + 1) % n], y2 = py[(i + 1) % n], dir = 1;
+          if (y1 == y2)
+            continue;
+          if (y1 > y2) {
+            int32_t t;
+            t = x1; x1 = x2; x2 = t;
+            t = y1; y1 = y2; y2 = t;
+            dir = -1;
+          }
+          int32_t *e = edges + n_e++ * 7;
+          e[0] = x1; e[1] = y1; e[2] = x2; e[3] = y2; e[4] = y1; e[5] = y2; e[6] = dir;
+        }
+      }
+      if (degenerate) {
+        cairo_destroy (cr);
+        it--;
+        continue;
+      }
+      cairo_fill (cr);
+      cairo_destroy (cr);
+      cairo_surface_flush (s);
+      int box[4];
+      if (flutl_tor_polygon_box (edges, n_e, box))
+        emit (0, edges, n_e, box, even_odd, cairo_image_surface_get_data (s), stride);
+    }
+    cairo_surface_destroy (s);
+  }
+
+  /* ---- kinds 1, 2: strokes ----------------------------------------------------------- */
+  for (int text = 0; text < 2; text++) {
+    const int W = text ? 1000 : 200, H = text ? 320 : 150;
+    cairo_surface_t *s = cairo_image_surface_create (CAIRO_FORMAT_A8, W, H);
+    const int stride = cairo_image_surface_get_stride (s);
+    const int count = text ? n_text : n_stroke;
+    for (int it = 0; it < count; it++) {
+      const int crossing = (int) (rnd () % 3 == 0);
+      cairo_t *cr = cairo_create (s);
+      cairo_set_operator (cr, CAIRO_OPERATOR_CLEAR);
+      cairo_paint (cr);
+      cairo_set_operator (cr, CAIRO_OPERATOR_OVER);
+      cairo_set_source_rgba (cr, 1, 1, 1, 1);
+      const int kind = (int) (rnd () % 6);
+      const double margin = crossing ? -30 : 40;
+      const double lw = text ? (rnd () & 1 ? 2.0 * (1 + (int) (rnd () % 5)) : frand (0.5, 12.0))
+          : kind == 5 ? frand (0.3, 2.0) : frand (1.0, 12.0);
+      if (text) {
+        static const char *fonts[] = { "DejaVu Sans", "DejaVu Serif", "DejaVu Sans Mono" };
+        static const char *words[] = { "Subtitles", "Quick brown fox", "jumps over", "AVATAR",
+          "g@&%$#", "Ill1|!", "OoQ0", "WwMm", "xyz{}[]", "~^`'\"", "Ünïcödé ßø" };
+        const double size = frand (12, 150);
+        cairo_select_font_face (cr, fonts[rnd () % 3], rnd () % 3 == 0 ? CAIRO_FONT_SLANT_ITALIC
+            : CAIRO_FONT_SLANT_NORMAL, rnd () & 1 ? CAIRO_FONT_WEIGHT_BOLD : CAIRO_FONT_WEIGHT_NORMAL);
+        cairo_set_font_size (cr, size);
+        const int n_lines = 1 + (int) (rnd () % 2);
+        for (int ln = 0; ln < n_lines; ln++) {
+          double x = frand (crossing ? -40 : 30, 200), y = frand (size, H - 20);
+          if (rnd () & 1) {
+            x = floor (x);
+            y = floor (y);
+          }
+          cairo_save (cr);
+          cairo_translate (cr, x, y);
+          if (rnd () % 4 == 0)
+            cairo_scale (cr, frand (0.5, 1.5), 1.0);
+          cairo_move_to (cr, 0, 0);
+          cairo_text_path (cr, words[rnd () % 11]);
+          if (rnd () % 3 == 0)
+            cairo_rectangle (cr, 0, floor (size * 0.1), floor (size * 2), floor (size * 0.07) + 1);
+          cairo_restore (cr);
+        }
+      } else {
+        const int n_sub = 1 + (int) (rnd () % 3);
+        for (int sp = 0; sp < n_sub; sp++) {
+          const int n = 2 + (int) (rnd () % 7);
+          double x = frand (margin, W - margin), y = frand (margin, H - margin);
+          cairo_move_to (cr, floor (x * 256) / 256, floor (y * 256) / 256);
+          for (int i = 0; i < n; i++) {
+            const double r = kind == 4 ? 6 : 60;
+            double qx[3], qy[3];
+            for (int k = 0; k < 3; k++) {
+              qx[k] = x + frand (-r, r);
+              qy[k] = y + frand (-r, r);
+              if (qx[k] < margin) qx[k] = margin;
+              if (qx[k] > W - margin) qx[k] = W - margin;
+              if (qy[k] < margin) qy[k] = margin;
+              if (qy[k] > H - margin) qy[k] = H - margin;
+              qx[k] = floor (qx[k] * 256) / 256;
+              qy[k] = floor (qy[k] * 256) / 256;
+            }
+            if (kind == 0 || (kind >= 2 && (rnd () & 1)))
+              cairo_line_to (cr, qx[2], qy[2]);
+            else
+              cairo_curve_to (cr, qx[0], qy[0], qx[1], qy[1], qx[2], qy[2]);
+            x = qx[2];
+            y = qy[2];
+          }
+          if (kind != 3 || (rnd () & 1))
+            cairo_close_path (cr);
+        }
+      }
+      cairo_matrix_t ctm;
+      switch (rnd () % 5) {
+        case 0: cairo_matrix_init_identity (&ctm); break;
+        case 1: cairo_matrix_init_translate (&ctm, frand (-50, 50), frand (-50, 50)); break;
+        case 2: { const double k = frand (0.5, 2); cairo_matrix_init_scale (&ctm, k, k); break; }
+        case 3: cairo_matrix_init_rotate (&ctm, frand (0, 6.28)); break;
+        default:
+          cairo_matrix_init (&ctm, 6.123233995736766e-17, 1, -1, 6.123233995736766e-17,
+              frand (0, 100), frand (0, 100));
+          break;
+      }
+      const double miter = rnd () % 4 == 0 ? frand (1, 4) : 10.0;
+      cairo_path_t *path = cairo_copy_path (cr);
+      int lim[4] = { 0, 0, W, H };
+      if (crossing) {
+        lim[0] = (int) (rnd () % 40);
+        lim[1] = (int) (rnd () % 40);
+        lim[2] = W - (int) (rnd () % (text ? 500 : 40));
+        lim[3] = H - (int) (rnd () % (text ? 150 : 40));
+        cairo_new_path (cr);
+        cairo_rectangle (cr, lim[0], lim[1], lim[2] - lim[0], lim[3] - lim[1]);
+        cairo_clip (cr);
+        cairo_append_path (cr, path);
+      }
+      cairo_set_matrix (cr, &ctm);
+      cairo_set_line_width (cr, lw);
+      cairo_set_miter_limit (cr, miter);
+      cairo_stroke (cr);
+      cairo_destroy (cr);
+      cairo_surface_flush (s);
+      FlutlPolygon pg;
+      flutl_polygon_init (&pg);
+      if (flutl_stroke_to_polygon (path, &ctm, lw, miter, CAIRO_LINE_JOIN_MITER, 0.1, lim, &pg) ==
+          FLUTL_STROKER_OK)
+        emit (1 + text, pg.edges, (int) pg.n_edges, pg.box, 0, cairo_image_surface_get_data (s), stride);
+      cairo_path_destroy (path);
+      flutl_polygon_fini (&pg);
+    }
+    cairo_surface_destroy (s);
+  }
+  fclose (out);
+  fprintf (stderr, "polygon_kats: %d fills, %d strokes, %d text strokes written, %d rejected\n",
+      written[0], written[1], written[2], rejected);
+  return rejected != 0;
+}

@@ -17,9 +17,9 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        src = os.path.join(ORACLE_DIR, "flutl_oracle.c")
+        srcs = [os.path.join(ORACLE_DIR, n) for n in ("flutl_oracle.c", "flutl_tor_oracle.c")]
         if (not os.path.exists(LIB_PATH) or
-                os.path.getmtime(LIB_PATH) < os.path.getmtime(src)):
+                os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)):
             subprocess.check_call(["make", "-C", ORACLE_DIR, "libflutl_oracle.so"],
                                   stdout=subprocess.DEVNULL)
         L = ctypes.CDLL(LIB_PATH)
@@ -43,6 +43,9 @@ def lib():
         L.flutl_oracle_render.argtypes = [u32, u32, vp, sz, vp, u32, vp, vp]
         L.flutl_oracle_blur.argtypes = [u32p, u32p, u32, u32, sz, i32p, ctypes.c_int]
         L.flutl_oracle_blur_kernel.argtypes = [ctypes.c_int, ctypes.c_double, i32p]
+        L.flutl_tor_oracle.argtypes = [i32p, ctypes.c_int] + [ctypes.c_int] * 5 + [
+            np.ctypeslib.ndpointer(np.uint8, flags="C"), ctypes.c_int]
+        L.flutl_tor_polygon_box.argtypes = [i32p, ctypes.c_int, i32p]
         _lib = L
     return _lib
 
@@ -150,3 +153,21 @@ def blur_kernel(radius, sigma):
     out = np.empty((2 * radius + 1) ** 2, np.int32)
     lib().flutl_oracle_blur_kernel(radius, float(sigma), out)
     return out
+
+
+def scan_polygon(edges, box, even_odd=False):
+    """oracle/flutl_tor_oracle.c: coverage (h x w uint8) of a polygon (n x 7 int32 edges,
+    24.8 fixed point) inside box = (x0, y0, x1, y1), as Cairo 1.16's tor converter"""
+    edges = np.ascontiguousarray(edges, np.int32).reshape(-1, 7)
+    x0, y0, x1, y1 = (int(v) for v in box)
+    out = np.zeros((y1 - y0, x1 - x0), np.uint8)
+    rc = lib().flutl_tor_oracle(edges.ravel(), len(edges), x0, y0, x1, y1, int(even_odd),
+                                out.ravel(), x1 - x0)
+    assert rc == 0
+    return out
+
+
+def polygon_box(edges):
+    edges = np.ascontiguousarray(edges, np.int32).reshape(-1, 7)
+    box = np.zeros(4, np.int32)
+    return box if lib().flutl_tor_polygon_box(edges.ravel(), len(edges), box) else None

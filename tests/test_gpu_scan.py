@@ -1,0 +1,151 @@
+"""-m gpu: the polygon scan converter (csrc/flutl_scan.hip) through the C-ABI against
+the REAL libcairo's coverage of committed polygons (tests/golden/polygons.npz, made by
+oracle/polygon_kats.c: cairo_fill / cairo_stroke on A8 surfaces) and against the CPU
+restatement (oracle/flutl_tor_oracle.c) on fresh random polygons.  Bit exact."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import pyflutl as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "needs cuda:0"
+    return torch
+
+
+def _polygons():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "polygons.npz"))
+    for i, (kind, x0, y0, x1, y1, eo) in enumerate(z["meta"]):
+        yield i, int(kind), (int(x0), int(y0), int(x1), int(y1)), bool(eo), z[f"edges{i}"], z[f"cov{i}"]
+
+
+def hip_scan(torch, edges, box, even_odd, mode=0, stride_pad=5):
+    """(coverage h x w, status) of the polygon through flutl_launch_scan"""
+    edges = np.ascontiguousarray(edges, np.int32).reshape(-1, 7)
+    w, h = box[2] - box[0], box[3] - box[1]
+    stride = w + stride_pad
+    ed = torch.from_numpy(edges.view(np.uint8).reshape(-1).copy()).cuda() if len(edges) else \
+        torch.zeros(64, dtype=torch.uint8, device="cuda")
+    scratch = torch.empty(F.scan_scratch_bytes(len(edges), w, h) + 256, dtype=torch.uint8,
+                          device="cuda")
+    dst = torch.full((h * stride,), 0xAB, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    F.launch_scan(stream, ed, len(edges), box, even_odd, scratch, dst, stride, mode)
+    status = F.scan_status(stream, scratch, len(edges), h) if len(edges) else 0
+    torch.cuda.synchronize()
+    out = dst.cpu().numpy().reshape(h, stride)
+    assert (out[:, w:] == 0xAB).all(), "the kernel wrote beyond its rows"
+    return out[:, :w].copy(), status
+
+
+def test_committed_polygons_are_cairos_coverage(gpu):
+    """rows in parallel, the sequential converter only where the rows flagged"""
+    bad = []
+    for i, kind, box, eo, edges, cov in _polygons():
+        got, _ = hip_scan(gpu, edges, box, eo, mode=0)
+        if not np.array_equal(got, cov):
+            bad.append((i, kind, int((got != cov).sum())))
+    assert not bad, f"{len(bad)} polygons differ from Cairo: {bad[:10]}"
+
+
+def test_row_kernel_alone_decides_almost_every_polygon(gpu):
+    """mode 1: no sequential converter behind the rows.  Whatever the rows did not flag
+    must be Cairo's coverage already; what they flag (a tie of sort keys that the
+    history rules cannot decide) must be rare."""
+    flagged, n = 0, 0
+    for i, kind, box, eo, edges, cov in _polygons():
+        got, status = hip_scan(gpu, edges, box, eo, mode=1)
+        n += 1
+        if status:
+            flagged += 1
+            continue
+        assert np.array_equal(got, cov), f"polygon {i} (kind {kind}): unflagged and wrong"
+    # (the fills on coarse grids are all ties; text strokes flag about 1 in 700)
+    assert flagged <= n // 4, f"{flagged} of {n} polygons flagged"
+
+
+def test_sequential_converter_is_cairos_coverage(gpu):
+    """mode 2: the one-lane sweep alone (every 4th polygon, the small ones: it is slow)"""
+    n = 0
+    for i, kind, box, eo, edges, cov in _polygons():
+        if i % 4 or len(edges) > 1500:
+            continue
+        got, _ = hip_scan(gpu, edges, box, eo, mode=2)
+        assert np.array_equal(got, cov), f"polygon {i} (kind {kind})"
+        n += 1
+    assert n >= 40
+
+
+def test_random_polygons_match_the_restatement(gpu):
+    """fresh random polygons (seeded), all snapped to grids that provoke ties, against
+    oracle/flutl_tor_oracle.c"""
+    rng = np.random.default_rng(7)
+    for it in range(120):
+        W, H = int(rng.integers(40, 300)), int(rng.integers(30, 200))
+        snap = int(rng.choice([1, 1, 17, 64, 128, 256]))
+        edges = []
+        for sp in range(int(rng.integers(1, 4))):
+            n = int(rng.integers(3, 40))
+            px = rng.integers(256, (W - 1) * 256, n) // snap * snap
+            py = rng.integers(256, (H - 1) * 256, n) // snap * snap
+            for k in range(n):
+                x1, y1, x2, y2 = int(px[k]), int(py[k]), int(px[(k + 1) % n]), int(py[(k + 1) % n])
+                if y1 == y2:
+                    continue
+                d = 1
+                if y1 > y2:
+                    x1, y1, x2, y2, d = x2, y2, x1, y1, -1
+                edges.append((x1, y1, x2, y2, y1, y2, d))
+        if not edges:
+            continue
+        edges = np.array(edges, np.int32)
+        box = O.polygon_box(edges)
+        box = (max(int(box[0]), 0), max(int(box[1]), 0), min(int(box[2]), W), min(int(box[3]), H))
+        eo = bool(it % 3 == 0)
+        want = O.scan_polygon(edges, box, eo)
+        got, _ = hip_scan(gpu, edges, box, eo, mode=0)
+        assert np.array_equal(got, want), f"case {it}: {(got != want).sum()} px differ"
+
+
+def test_polygon_becomes_an_atlas_entry_masks_can_read(gpu):
+    """flutl_atlas_put_polygon: the coverage lands in the context's atlas in the MASK
+    layout (4 zero bytes, rows of width + 4), composited by a MASK primitive it must give
+    what the same mask uploaded from the host gives."""
+    import gpu_util
+    torch = gpu
+    i, kind, box, eo, edges, cov = next(p for p in _polygons() if p[1] == 2)
+    h, w = cov.shape
+    W, H = box[2] + 8, box[3] + 8
+    with F.Context(0) as ctx:
+        off = ctx.atlas_put_polygon(edges, box, eo)
+        fr = ctx.frame(W, H)
+        try:
+            R = np.zeros(1, F.REGION_DTYPE)
+            R["x0"], R["y0"], R["x1"], R["y1"], R["first"], R["count"] = box[0], box[1], box[2], box[3], 0, 1
+            P = np.zeros(1, F.PRIM_DTYPE)
+            P["op"], P["rule"] = F.OP_MASK, F.RULE_LERP
+            P["cx0"], P["cy0"], P["cx1"], P["cy1"] = box[0], box[1], box[2], box[3]
+            P["color"] = 0xFF000000
+            P["a"], P["b"], P["c"], P["d"] = off + 4, w + 4, box[0], box[1]
+            fr.submit(R, P)
+            fr.wait()
+            got = fr.host().copy()
+        finally:
+            fr.close()
+    # the same through the stateless path with the mask uploaded from the host
+    padded = np.zeros((h, w + 4), np.uint8)
+    padded[:, :w] = cov
+    atlas = np.concatenate([np.zeros(F.ATLAS_SLACK + 4, np.uint8), padded.ravel(),
+                            np.zeros(F.ATLAS_SLACK, np.uint8)])
+    P2 = P.copy()
+    P2["a"] = F.ATLAS_SLACK + 4
+    want = gpu_util.hip_render(W, H, R, P2, atlas)
+    assert np.array_equal(got, want)
