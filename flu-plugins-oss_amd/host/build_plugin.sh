@@ -34,7 +34,7 @@ REF_SRCS="$T/gstfluttml.c $T/gstttmlbase.c $T/gstttmltype.c $T/gstttmlattribute.
  $REF/libs/fluc/flu-codec-sdk/fluc/threads/fluc_monitor.c
  $REF/libs/fluc/flu-codec-sdk/fluc/threads/fluc_mutex.c"
 OUR_SRCS="$HERE/gstttmlrender_hip.c $HERE/flutl_recorder.c $HERE/flutl_pack.c
- $HERE/flutl_state_fix.c"
+ $HERE/flutl_state_fix.c $HERE/flutl_stroker.c"
 INC="-I$HERE -I$PKG/../include -I$T -I$REF/libs/common -I$REF/libs/flu/downloader/lib
  -I$REF/libs/fluc/flu-codec-sdk -I$REF/libs/fluc/flu-codec-sdk/fluc
  -I$C/include/gstreamer-1.0 -I$C/include/glib-2.0 -I$C/lib/glib-2.0/include
@@ -55,7 +55,7 @@ mkdir -p "$PKG/build"
 gcc -c -fPIC -O2 -w $DEFS -Dgst_ttml_state_save_data=ref_unused_state_save_data $INC \
   "$T/gstttmlstate.c" -o "$PKG/build/gstttmlstate.o"
 # shellcheck disable=SC2086
-gcc -shared -fPIC -O2 -w $DEFS $INC $REF_SRCS "$PKG/build/gstttmlstate.o" -Wall -Wno-deprecated-declarations $OUR_SRCS \
+gcc -shared -fPIC -O2 -ffp-contract=off -w $DEFS $INC $REF_SRCS "$PKG/build/gstttmlstate.o" -Wall -Wno-deprecated-declarations $OUR_SRCS \
   -L"$PKG/lib" -lflutl -Wl,-rpath,'$ORIGIN/..' \
   -L$C/lib -Wl,-rpath,$C/lib -lgstreamer-1.0 -lgstbase-1.0 -lgstvideo-1.0 \
   -lgobject-2.0 -lglib-2.0 -lxml2 -lpangocairo-1.0 -lpango-1.0 -lcairo \

@@ -16,6 +16,7 @@
  *   - glyphs land at floor (device position + 0.5) and always go to pixman.
  */
 #include "flutl_recorder.h"
+#include "flutl_stroker.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -123,6 +124,8 @@ struct FlutlRecorder
   size_t atlas_size, atlas_cap;
   uint32_t *new_off, *new_size;
   uint32_t n_new, cap_new;
+  FlutlPolygonEntry **new_poly;      /* per new entry: NULL, or the polygon the DEVICE makes it of */
+  int device_strokes;                /* outlines leave the workers as polygons (see stroke_job_run) */
 
   GlyphEntry *glyphs;
   uint32_t glyph_cap, glyph_count;
@@ -216,6 +219,7 @@ flutl_recorder_unlock (FlutlRecorder *rec)
   g_rec_mutex_unlock (&root_of (rec)->lock);
 }
 
+#define MASK_PAD 4              /* zero bytes in front of a mask and after each of its rows */
 static uint32_t
 atlas_put_ex (FlutlRecorder *rec, const void *src, size_t bytes, int on_device);
 
@@ -261,11 +265,31 @@ atlas_put_locked (FlutlRecorder *rec, const void *src, size_t bytes, int on_devi
     rec->cap_new = rec->cap_new ? rec->cap_new * 2 : 64;
     rec->new_off = xrealloc (rec->new_off, rec->cap_new * sizeof (uint32_t));
     rec->new_size = xrealloc (rec->new_size, rec->cap_new * sizeof (uint32_t));
+    rec->new_poly = xrealloc (rec->new_poly, rec->cap_new * sizeof (FlutlPolygonEntry *));
   }
   rec->new_off[rec->n_new] = (uint32_t) off;
   rec->new_size[rec->n_new] = (uint32_t) bytes;
+  rec->new_poly[rec->n_new] = NULL;
   rec->n_new++;
   return (uint32_t) off;
+}
+
+/* An entry the DEVICE will make (flutl_atlas_put_polygon): its space is set aside
+ * here (zeros in the host copy), and it takes its place in the log of new entries,
+ * which whoever owns the device works off in order -- offsets are given out in the
+ * same order on both sides.  Takes the polygon over.  (with the root's lock) */
+static uint32_t
+atlas_reserve_polygon (FlutlRecorder *rec, FlutlPolygonEntry *pe)
+{
+  rec = root_of (rec);
+  const size_t bytes = MASK_PAD + ((size_t) pe->w + MASK_PAD) * pe->h;
+  uint8_t *zeros = calloc (bytes, 1);
+  if (!zeros)
+    abort ();
+  const uint32_t off = atlas_put_locked (rec, zeros, bytes, 0);
+  free (zeros);
+  rec->new_poly[rec->n_new - 1] = pe;
+  return off;
 }
 
 static uint64_t
@@ -323,7 +347,6 @@ atlas_put_dedup_hashed (FlutlRecorder *rec, const uint8_t *src, size_t bytes, ui
 /* Store a tight w x h A8 bitmap the way the kernel wants to read it: 4 zero
  * bytes in front of the first row, every row followed by 4 zero bytes (stride
  * w + 4).  Returns the atlas offset of mask pixel (0,0). */
-#define MASK_PAD 4
 static uint8_t *
 mask_padded (const uint8_t *tight, int w, int h, size_t *bytes_out)
 {
@@ -564,6 +587,8 @@ drop_caches (FlutlRecorder *rec)
   rec->atlas_size = ATLAS_SLACK;
   if (rec->atlas)
     memset (rec->atlas, 0, rec->atlas_cap);
+  for (uint32_t i = 0; i < rec->n_new; i++)
+    flutl_polygon_entry_free (rec->new_poly[i]);
   rec->n_new = 0;
 }
 
@@ -587,8 +612,11 @@ flutl_recorder_free (FlutlRecorder *rec)
   free (rec->prim_tags);
   free (rec->regions);
   free (rec->atlas);
+  for (uint32_t i = 0; i < rec->n_new; i++)
+    flutl_polygon_entry_free (rec->new_poly ? rec->new_poly[i] : NULL);
   free (rec->new_off);
   free (rec->new_size);
+  free (rec->new_poly);
   free (rec->images);
   free (rec->masks);
   path_ops_clear (rec);
@@ -2126,6 +2154,8 @@ typedef struct StrokeJob
   int exact_pending;             /* rb was made from bounds of the extents: the worker takes
                                   * the exact ones (rb becomes exact before the stroke) */
   gint64 t_pushed;
+  int to_polygon;                /* the device makes the mask: the result is the polygon */
+  FlutlPolygonEntry *poly;       /* result (to_polygon): the stroke's polygon, or NULL */
   uint8_t *tight;                /* result: w x h coverage at (x, y), or NULL */
   uint8_t *padded;               /* ... in the atlas's layout, and its hash: made here so */
   size_t padded_bytes;           /* that the thread that resolves frames only copies it  */
@@ -2160,6 +2190,7 @@ stroke_job_unref (StrokeJob *j)
     return;
   if (j->path)
     cairo_path_destroy (j->path);
+  flutl_polygon_entry_free (j->poly);
   free (j->tight);
   free (j->padded);
   g_mutex_clear (&j->lock);
@@ -2177,6 +2208,13 @@ stroke_job_wait (StrokeJob *j)
 }
 
 static gint64 stroke_jobs_done, stroke_jobs_us, stroke_jobs_queue_us;   /* statistics */
+static gint64 stroke_jobs_polygons;     /* ... of which left as polygons for the device */
+
+uint64_t
+flutl_recorder_polygon_jobs (void)
+{
+  return (uint64_t) __atomic_load_n (&stroke_jobs_polygons, __ATOMIC_RELAXED);
+}
 static gint64 stroke_jobs_extents_us, stroke_jobs_draw_us, stroke_jobs_crop_us;
 static gint64 resolve_wait_us;  /* time flutl_recorder_resolve spent waiting for workers */
 
@@ -2194,11 +2232,68 @@ flutl_recorder_stroke_stats (uint64_t *jobs, uint64_t *busy_us, uint64_t *queued
   *queued_us = (uint64_t) __atomic_load_n (&stroke_jobs_queue_us, __ATOMIC_RELAXED);
 }
 
+/* The stroke as the polygon Cairo makes of it (flutl_stroker.c); the device scan
+ * converts it (flutl_atlas_put_polygon) and the mask never exists in host memory.
+ * 0: not a stroke the stroker takes (Cairo draws it, below). */
+static int
+stroke_job_polygon (StrokeJob *j)
+{
+  FlutlPolygon pg;
+  /* what bounds the stroke in the reference: its surface and the region's clip
+   * (current_limits), within the surface paths are rasterised on here */
+  const int target[4] = { imax (j->rb.lim[0], 0), imax (j->rb.lim[1], 0),
+    imin (j->rb.lim[2], j->sw), imin (j->rb.lim[3], j->sh) };
+  flutl_polygon_init (&pg);
+  if (flutl_stroke_to_polygon (j->path, &j->ctm, j->line_width, j->miter_limit,
+          CAIRO_LINE_JOIN_MITER, 0.1, target, &pg) != FLUTL_STROKER_OK) {
+    flutl_polygon_fini (&pg);
+    return 0;
+  }
+  /* the stroke's extents as cairo_stroke_extents gives them: those of its polygon
+   * before anything is cut to limits */
+  if (pg.uext[2] >= pg.uext[0]) {
+    raster_box_from_extents (&j->rb, pg.uext[0] / 256.0, pg.uext[1] / 256.0, pg.uext[2] / 256.0,
+        pg.uext[3] / 256.0, j->sw, j->sh);
+  } else {
+    raster_box_from_extents (&j->rb, 0, 0, 0, 0, j->sw, j->sh);
+  }
+  if (pg.box[2] > pg.box[0] && pg.box[3] > pg.box[1] && pg.n_edges) {
+    FlutlPolygonEntry *pe = calloc (1, sizeof *pe);
+    if (!pe)
+      abort ();
+    pe->edges = pg.edges;
+    pe->n_edges = pg.n_edges;
+    memcpy (pe->box, pg.box, sizeof pe->box);
+    pe->w = pg.box[2] - pg.box[0];
+    pe->h = pg.box[3] - pg.box[1];
+    pg.edges = NULL;
+    j->poly = pe;
+    j->x = pg.box[0];
+    j->y = pg.box[1];
+    j->w = pe->w;
+    j->h = pe->h;
+  }
+  flutl_polygon_fini (&pg);
+  return 1;
+}
+
 static void
 stroke_job_run (gpointer data, gpointer user_data)
 {
   StrokeJob *j = data;
   const gint64 t_run = g_get_monotonic_time ();
+  if (j->to_polygon && stroke_job_polygon (j)) {
+    __atomic_fetch_add (&stroke_jobs_polygons, 1, __ATOMIC_RELAXED);
+    __atomic_fetch_add (&stroke_jobs_done, 1, __ATOMIC_RELAXED);
+    __atomic_fetch_add (&stroke_jobs_us, g_get_monotonic_time () - t_run, __ATOMIC_RELAXED);
+    __atomic_fetch_add (&stroke_jobs_queue_us, t_run - j->t_pushed, __ATOMIC_RELAXED);
+    g_mutex_lock (&j->lock);
+    j->done = 1;
+    g_cond_broadcast (&j->cond);
+    g_mutex_unlock (&j->lock);
+    stroke_job_unref (j);
+    return;
+  }
   WorkerSurface *ws = g_private_get (&worker_surface_key);
   if (!ws) {
     ws = calloc (1, sizeof *ws);
@@ -2383,6 +2478,7 @@ stroke_defer_prepare (FlutlRecorder *rec, RasterBox *rb, int *exact)
   j->exact_pending = !*exact;
   j->sw = rec->sw;
   j->sh = rec->sh;
+  j->to_polygon = root_of (rec)->device_strokes;
   return j;
 }
 
@@ -2476,7 +2572,15 @@ flutl_recorder_resolve (FlutlRecorder *rec, flutl_region *regions, uint32_t n_re
       /* (the worker's extents are the exact ones) */
       memcpy (e->ext, j->rb.ext, sizeof e->ext);
       e->translatable = j->rb.inside;
-      if (j->tight) {
+      if (j->poly) {
+        /* the device makes the mask, of the polygon, when the entry's turn comes */
+        e->x = j->x;
+        e->y = j->y;
+        e->w = j->w;
+        e->h = j->h;
+        e->offset = atlas_reserve_polygon (rec, j->poly) + MASK_PAD;
+        j->poly = NULL;
+      } else if (j->tight) {
         e->offset = atlas_put_dedup_hashed (rec, j->padded, j->padded_bytes, j->padded_hash) +
             MASK_PAD;
         e->x = j->x;
@@ -3028,13 +3132,29 @@ flutl_recorder_atlas (FlutlRecorder *rec, size_t *size)
 
 uint32_t
 flutl_recorder_new_atlas_entries (FlutlRecorder *rec, const uint32_t **offsets,
-    const uint32_t **sizes)
+    const uint32_t **sizes, FlutlPolygonEntry *const **polygons)
 {
   uint32_t n = rec->n_new;
   *offsets = rec->new_off;
   *sizes = rec->new_size;
-  rec->n_new = 0;
+  *polygons = rec->new_poly;
+  rec->n_new = 0;               /* (the polygons are the caller's now) */
   return n;
+}
+
+void
+flutl_polygon_entry_free (FlutlPolygonEntry *pe)
+{
+  if (!pe)
+    return;
+  free (pe->edges);
+  free (pe);
+}
+
+void
+flutl_recorder_set_device_strokes (FlutlRecorder *rec, int on)
+{
+  rec->device_strokes = on && !rec->parent;
 }
 
 uint32_t

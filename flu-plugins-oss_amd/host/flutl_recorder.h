@@ -116,10 +116,29 @@ const flutl_region *flutl_recorder_regions (FlutlRecorder *rec, uint32_t *n);
 const flutl_prim *flutl_recorder_prims (FlutlRecorder *rec, uint32_t *n);
 /* host copy of the atlas: bytes [0, size), incl. the 16-byte leading slack */
 const uint8_t *flutl_recorder_atlas (FlutlRecorder *rec, size_t *size);
+/* An atlas entry the device makes of a polygon (flutl_atlas_put_polygon): the
+ * outline of a text as the worker's stroker left it.  edges: n_edges x 7 int32 (24.8
+ * fixed point cairo_edge_t), box: where Cairo converts it (raster pixels), w x h its
+ * size; the entry has the MASK layout (4 + (w + 4) * h bytes, zero padded). */
+typedef struct
+{
+  int32_t *edges;
+  uint32_t n_edges;
+  int32_t box[4];
+  int w, h;
+} FlutlPolygonEntry;
+void flutl_polygon_entry_free (FlutlPolygonEntry *pe);
+/* Outlines without a mask leave the worker threads as polygons for the device instead
+ * of as coverage rasterised by Cairo (only where strokes are deferred, set_defer). */
+void flutl_recorder_set_device_strokes (FlutlRecorder *rec, int on);
+uint64_t flutl_recorder_polygon_jobs (void);
+
 /* atlas entries appended since the last call (for incremental upload);
- * returns the number of entries; entry i spans [offsets[i], offsets[i]+sizes[i]) */
+ * returns the number of entries; entry i spans [offsets[i], offsets[i]+sizes[i]);
+ * polygons[i] != NULL: the device makes that entry (the caller owns the polygon now:
+ * flutl_polygon_entry_free), else its bytes are in the host copy */
 uint32_t flutl_recorder_new_atlas_entries (FlutlRecorder *rec,
-    const uint32_t **offsets, const uint32_t **sizes);
+    const uint32_t **offsets, const uint32_t **sizes, FlutlPolygonEntry *const **polygons);
 /* number of primitives dropped because a feature is not implemented yet */
 uint32_t flutl_recorder_unsupported (FlutlRecorder *rec);
 

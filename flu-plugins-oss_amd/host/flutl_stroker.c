@@ -307,9 +307,17 @@ add_clipped_edge (Stroker *st, const Pt *p1, const Pt *p2, const int top, const 
 static void
 polygon_add_edge (Stroker *st, const Pt *p1, const Pt *p2, int dir)
 {
-  const FlutlPolygon *pg = st->polygon;
+  FlutlPolygon *pg = st->polygon;
   if (p1->y == p2->y)           /* horizontal edges do not count */
     return;
+  /* (the polygon's extents had it no limits: what cairo_stroke_extents reports) */
+  for (int k = 0; k < 2; k++) {
+    const Pt *q = k ? p2 : p1;
+    if (q->x < pg->uext[0]) pg->uext[0] = q->x;
+    if (q->y < pg->uext[1]) pg->uext[1] = q->y;
+    if (q->x > pg->uext[2]) pg->uext[2] = q->x;
+    if (q->y > pg->uext[3]) pg->uext[3] = q->y;
+  }
   if (p1->y > p2->y) {
     const Pt *t = p1;
     p1 = p2;
@@ -1368,6 +1376,8 @@ flutl_polygon_init (FlutlPolygon *pg)
   memset (pg, 0, sizeof *pg);
   pg->extents[0] = pg->extents[1] = INT32_MAX;
   pg->extents[2] = pg->extents[3] = INT32_MIN;
+  pg->uext[0] = pg->uext[1] = INT32_MAX;
+  pg->uext[2] = pg->uext[3] = INT32_MIN;
 }
 
 void

@@ -23,6 +23,7 @@ typedef struct
   int32_t *edges;
   uint32_t n_edges, cap;
   int32_t extents[4];           /* x0, y0, x1, y1 of the edges' end points (cut at top / bottom) */
+  int32_t uext[4];              /* ... before anything was cut to limits */
   int has_limits;
   int32_t limits[4];            /* the box edges were cut to (cairo_polygon_t.limits) */
   int box[4];                   /* pixels: the box Cairo scan converts the polygon in (all 0: nothing) */

@@ -504,6 +504,9 @@ typedef struct
   gint video_width, video_height;
   GQueue cues;               /* VideoCue *, in time order */
   guint n_deferred;          /* buffers that went through the finisher */
+  guint n_polygons;          /* outlines scan converted on the device (statistics) */
+  guint64 polygon_edges;
+  gboolean host_strokes;     /* FLUTL_HOST_STROKES=1: outlines rasterised by Cairo on the workers */
   guint64 delta_reported;
 } GstTTMLRenderPrivate;
 
@@ -2609,6 +2612,8 @@ flush_atlas (GstTTMLRender *render)
 {
   GstTTMLRenderPrivate *priv = get_priv (render);
   const uint32_t *off_, *size_;
+  FlutlPolygonEntry *const *poly_;
+  FlutlPolygonEntry **poly;
   uint32_t *off, *size;
   uint32_t i, n;
   gboolean ok = TRUE;
@@ -2621,18 +2626,28 @@ flush_atlas (GstTTMLRender *render)
    * recorder too.  Calls do not overlap: the finisher makes them, or the
    * streaming thread when the finisher has nothing in flight.) */
   flutl_recorder_lock (priv->rec);
-  n = flutl_recorder_new_atlas_entries (priv->rec, &off_, &size_);
+  n = flutl_recorder_new_atlas_entries (priv->rec, &off_, &size_, &poly_);
   off = g_memdup (off_, n * sizeof *off);
   size = g_memdup (size_, n * sizeof *size);
+  poly = g_memdup (poly_, n * sizeof *poly);
   flutl_recorder_unlock (priv->rec);
   for (i = 0; i < n && ok; i++) {
     uint32_t dev_off = 0;
     size_t atlas_size;
     int rc;
-    flutl_recorder_lock (priv->rec);
-    rc = flutl_atlas_put (priv->ctx, flutl_recorder_atlas (priv->rec, &atlas_size) + off[i],
-        size[i], &dev_off);
-    flutl_recorder_unlock (priv->rec);
+    if (poly[i]) {
+      /* an outline as the polygon a worker's stroker made of it: the device scan
+       * converts it straight into the entry (no coverage in host memory, no upload) */
+      rc = flutl_atlas_put_polygon (priv->ctx, poly[i]->edges, poly[i]->n_edges, poly[i]->box,
+          0, &dev_off);
+      priv->n_polygons++;
+      priv->polygon_edges += poly[i]->n_edges;
+    } else {
+      flutl_recorder_lock (priv->rec);
+      rc = flutl_atlas_put (priv->ctx, flutl_recorder_atlas (priv->rec, &atlas_size) + off[i],
+          size[i], &dev_off);
+      flutl_recorder_unlock (priv->rec);
+    }
     if (rc != FLUTL_OK || dev_off != off[i]) {
       GST_ELEMENT_ERROR (render, LIBRARY, FAILED, ("ttmlrender: atlas upload failed"),
           ("flutl_atlas_put: %s (offset %u vs %u)", flutl_strerror (rc), dev_off, off[i]));
@@ -2646,6 +2661,9 @@ flush_atlas (GstTTMLRender *render)
     g_printerr ("ttmlrender-hip atlas flush: %u entries, %" G_GUINT64_FORMAT " bytes, %" G_GINT64_FORMAT
         " us\n", n, bytes, g_get_monotonic_time () - t_flush0);
   }
+  for (i = 0; i < n; i++)
+    flutl_polygon_entry_free (poly[i]);
+  g_free (poly);
   g_free (off);
   g_free (size);
   return ok;
@@ -2884,6 +2902,9 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
    * by the finisher, unless the frame is needed complete right here */
   flutl_recorder_set_defer (rec, !priv->sync_mode && !priv->full_d2h && !priv->video_pad &&
       (!priv->dump || priv->dump_defer));
+  /* ... as polygons for the device to scan convert (not when the frame is dumped: a
+   * scene pack holds the masks' bytes) */
+  flutl_recorder_set_device_strokes (rec, !priv->dump && !priv->host_strokes);
   flutl_recorder_begin_frame (rec, width, height);
   if (base->state.saved_region_attr_stacks) {
     gpointer ctx[2] = { render, &regions };
@@ -3773,6 +3794,7 @@ gst_ttmlrender_init (GstTTMLRender *render)
   priv->jobs = g_async_queue_new ();
   g_mutex_init (&priv->flight_lock);
   g_cond_init (&priv->flight_cond);
+  priv->host_strokes = g_getenv ("FLUTL_HOST_STROKES") != NULL;
   priv->no_layout_cache = g_getenv ("FLUTL_NO_LAYOUT_CACHE") != NULL;
   priv->no_region_cache = g_getenv ("FLUTL_NO_REGION_CACHE") != NULL;
   priv->no_recolour = g_getenv ("FLUTL_NO_RECOLOUR") != NULL;
