@@ -42,9 +42,10 @@
 namespace {
 
 constexpr int kGridY = 15;
-constexpr int kThreads = 256;
+constexpr int kThreads = 1024;
 constexpr int kMaxActive = 2048;        // edges crossing one pixel row
 constexpr int kMaxWidth = 4096;         // box width (accumulators live in LDS)
+constexpr int kBins = 2048;             // bins a row's pixels are cut into (sample-row path)
 constexpr int kMaxBucket = 32;          // edges starting on one sample row with one cell history
 
 // status bits (device word)
@@ -114,7 +115,8 @@ __device__ inline void normalise (int32_t &q, int64_t &r, int64_t D)
 
 // ---- edges: cairo_edge_t -> ScanEdge (glitter_scan_converter_add_edge) ----------------
 __global__ void scan_prepare_kernel (const int32_t *__restrict__ edges, uint32_t n,
-    int ymin, int ymax, ScanEdge *__restrict__ out, uint8_t *__restrict__ row_flags)
+    int ymin, int ymax, ScanEdge *__restrict__ out, uint8_t *__restrict__ row_flags,
+    int2 *__restrict__ spans)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n)
@@ -136,6 +138,7 @@ __global__ void scan_prepare_kernel (const int32_t *__restrict__ edges, uint32_t
     e.xr0 = e.dr = e.D = 0;
     e.dq = 0;
     out[i] = e;
+    spans[i] = make_int2 (INT_MAX, INT_MIN);
     return;
   }
   int32_t p1x = in[0], p1y = in[1], p2x = in[2], p2y = in[3];
@@ -168,6 +171,7 @@ __global__ void scan_prepare_kernel (const int32_t *__restrict__ edges, uint32_t
     e.D = Dy;
   }
   out[i] = e;
+  spans[i] = make_int2 (ytop, ybot);    // (what the rows look through for their edges)
   // rows that are converted by sample rows whatever the order of their edges: an edge
   // starts or ends inside them
   if (ytop % kGridY)
@@ -206,16 +210,40 @@ __device__ inline int key_cell (uint64_t k)
   return (int) ((uint32_t) (k >> 32) ^ 0x80000000u);
 }
 
+// The workgroup's LDS (dynamic: sized by the box width), as every thread sees it.
 struct RowShared {
-  int cov[kMaxWidth + 2];       // covered_height per pixel; [0]: everything left of xmin
-  int unc[kMaxWidth + 2];       // uncovered_area per pixel
-  uint64_t key[kMaxActive];
-  uint32_t idx[kMaxActive];     // slot -> edge index
-  int8_t dir[kMaxActive];       // slot -> winding direction
-  int part[kThreads];
-  int n, live, flag, result;
-  int tmp[4];
+  int *cov;             // [(width + 3) / 2] covered_height per pixel, two to a word (cov_add);
+                        // pixel 0: everything left of xmin
+  int *unc;             // [width + 2] uncovered_area per pixel
+  uint32_t *idx;        // [kMaxActive] slot -> edge index
+  int8_t *dir;          // [kMaxActive] slot -> winding direction
+  int *part;            // [kThreads]
+  int *sc;              // scalars: 0 n, 1 flag, 2 result, 4.. scratch of the tie rules
+  uint64_t *key;        // sort keys of the row-start order (cell, edge index): [npad]
+  uint32_t *key32;      // the same memory as sample-row keys (cell << 11 | slot): [rows][npad]
+  int key_bytes;        // what is there for keys
 };
+
+__host__ __device__ inline size_t row_shared_fixed_bytes (int width)
+{
+  return (size_t) (width + 2) * sizeof (int) + (size_t) ((width + 3) / 2) * sizeof (int) +
+      kMaxActive * sizeof (uint32_t) + kMaxActive + kThreads * sizeof (int) + 16 * sizeof (int);
+}
+
+// covered heights are small (|sum| <= 15 * kMaxActive < 2^15): two to a 32-bit word, added to
+// with 32-bit LDS atomics.  The word is lo + 65536 * hi as one exact integer -- a negative
+// lo borrows from hi -- and is taken apart accordingly (cov_get).
+__device__ inline void cov_add (int *cov, int k, int v)
+{
+  atomicAdd (&cov[k >> 1], (k & 1) ? v * 65536 : v);
+}
+
+__device__ inline int cov_get (const int *cov, int k)
+{
+  const int w = cov[k >> 1];
+  const int lo = (int) (int16_t) (w & 0xffff);
+  return (k & 1) ? (w - lo) >> 16 : lo;
+}
 
 // inclusive prefix sums of part[0..255] in place (all threads call)
 __device__ inline void block_scan_256 (int *part, int tid)
@@ -263,7 +291,7 @@ __device__ void render_edge (RowShared &S, const ScanEdge &e, int s0, int sign, 
   const int ix1 = x1q >> 8, ix2 = x2q >> 8;
   if (ix1 == ix2) {
     const int k = pixel_index (ix1, xmin, width);
-    atomicAdd (&S.cov[k], sign * kGridY);
+    cov_add (S.cov, k, sign * kGridY);
     atomicAdd (&S.unc[k], sign * kGridY * (fx1 + fx2));
     return;
   }
@@ -282,7 +310,7 @@ __device__ void render_edge (RowShared &S, const ScanEdge &e, int s0, int sign, 
   {
     const int k = pixel_index (ixlo, xmin, width);
     const int h = (int) yq * sign;
-    atomicAdd (&S.cov[k], h);
+    cov_add (S.cov, k, h);
     atomicAdd (&S.unc[k], (fxlo + 256) * h);
   }
   int y = (int) yq;
@@ -298,7 +326,7 @@ __device__ void render_edge (RowShared &S, const ScanEdge &e, int s0, int sign, 
       const int k = pixel_index (ix, xmin, width);
       const int h = (y2 - y) * sign;
       if (h) {
-        atomicAdd (&S.cov[k], h);
+        cov_add (S.cov, k, h);
         atomicAdd (&S.unc[k], h * 256);
       }
       y = y2;
@@ -308,7 +336,7 @@ __device__ void render_edge (RowShared &S, const ScanEdge &e, int s0, int sign, 
   {
     const int k = pixel_index (ixhi, xmin, width);
     const int h = sign * (kGridY - y);
-    atomicAdd (&S.cov[k], h);
+    cov_add (S.cov, k, h);
     atomicAdd (&S.unc[k], fxhi * h);
   }
 }
@@ -325,8 +353,8 @@ __device__ int merge_rule (RowShared &S, const ScanEdge *edges, uint32_t n, int 
 {
   // packed: (cell biased << 2) | (seen among the new ones << 1) | (seen among the old ones)
   if (tid == 0) {
-    S.tmp[0] = INT_MIN;         // best cell
-    S.tmp[1] = 0;               // bit 0: an old edge has it, bit 1: a new one
+    S.sc[4] = INT_MIN;         // best cell
+    S.sc[5] = 0;               // bit 0: an old edge has it, bit 1: a new one
   }
   __syncthreads ();
   int best = INT_MIN, who = 0;
@@ -346,12 +374,12 @@ __device__ int merge_rule (RowShared &S, const ScanEdge *edges, uint32_t n, int 
     }
   }
   if (best != INT_MIN)
-    atomicMax (&S.tmp[0], best);
+    atomicMax (&S.sc[4], best);
   __syncthreads ();
-  if (best != INT_MIN && best == S.tmp[0])
-    atomicOr (&S.tmp[1], who);
+  if (best != INT_MIN && best == S.sc[4])
+    atomicOr (&S.sc[5], who);
   __syncthreads ();
-  const int b = S.tmp[0], w = S.tmp[1];
+  const int b = S.sc[4], w = S.sc[5];
   __syncthreads ();
   if (b == INT_MIN)
     return -1;                  // nothing before: the active list's group first
@@ -475,10 +503,10 @@ __device__ int bucket_rule (RowShared &S, const ScanEdge *edges, uint32_t n, int
           if (e == pb) { r = 1; break; }
         }
       }
-      S.tmp[2] = r;
+      S.sc[6] = r;
     }
     __syncthreads ();
-    result = S.tmp[2];
+    result = S.sc[6];
   }
   __syncthreads ();
   return result;
@@ -529,38 +557,128 @@ __device__ inline bool same_line (const ScanEdge &a, const ScanEdge &b, int s)
 }
 
 // ---- one pixel row per workgroup ---------------------------------------------------------------
-__global__ void __launch_bounds__ (kThreads)
-scan_rows_kernel (const ScanEdge *__restrict__ edges, uint32_t n_edges,
-    const uint8_t *__restrict__ row_flags, int xmin, int ymin, int xmax, int ymax, int even_odd,
-    uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ status)
+// ---- wave-level helpers (the four waves of a workgroup convert different sample rows) ----
+__device__ inline void wave_fence ()
 {
-  __shared__ RowShared S;
+  // LDS traffic of one wave is processed in order; this only keeps the compiler from
+  // moving accesses across
+  __builtin_amdgcn_fence (__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier ();
+}
+
+// bitonic sort of npad (a power of two >= 64) 32-bit keys in LDS by one wave
+__device__ inline void wave_bitonic_sort (uint32_t *key, int npad, int lane)
+{
+  for (int k = 2; k <= npad; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = lane; t < npad / 2; t += 64) {
+        // the t-th pair of this stage: i has bit j clear
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int ixj = i | j;
+        const uint32_t a = key[i], b = key[ixj];
+        const bool up = (i & k) == 0;
+        if ((a > b) == up) {
+          key[i] = b;
+          key[ixj] = a;
+        }
+      }
+      wave_fence ();
+    }
+}
+
+__device__ inline int wave_inclusive_scan (int v, int lane)
+{
+  for (int off = 1; off < 64; off <<= 1) {
+    const int u = __shfl_up (v, off, 64);
+    if (lane >= off)
+      v += u;
+  }
+  return v;
+}
+
+// exclusive prefix sum of v over the workgroup's 256 threads (part: 4 words of LDS)
+__device__ inline int block_exclusive_scan (int v, int tid, int *part)
+{
+  const int lane = tid & 63, wave = tid >> 6;
+  const int incl = wave_inclusive_scan (v, lane);
+  if (lane == 63)
+    part[wave] = incl;
+  __syncthreads ();
+  int base = 0;
+  for (int w = 0; w < wave; w++)
+    base += part[w];
+  __syncthreads ();
+  return base + incl - v;
+}
+
+constexpr uint32_t kKeyNone = 0xffffffffu;
+constexpr int kSlotBits = 11;           // kMaxActive = 2048 slots
+
+__global__ void __launch_bounds__ (kThreads)
+scan_rows_kernel (const ScanEdge *__restrict__ edges, const int2 *__restrict__ spans,
+    uint32_t n_edges, const uint8_t *__restrict__ row_flags, int xmin, int ymin, int xmax, int ymax, int even_odd,
+    uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ status, int lds_bytes,
+    uint32_t *__restrict__ debug)
+{
+  extern __shared__ __align__ (16) uint8_t lds[];
   const int tid = threadIdx.x;
   const int row = blockIdx.x;
+  const uint64_t t_begin = debug ? wall_clock64 () : 0;
+  int dbg_mode = 0;
+  uint32_t dbg_ph[5] = { 0, 0, 0, 0, 0 };
+  uint64_t dbg_t = 0;
+#define DBG_PHASE(k) do { if (debug) { const uint64_t now_ = wall_clock64 (); dbg_ph[k] += (uint32_t) (now_ - dbg_t); dbg_t = now_; } } while (0)
   const int width = xmax - xmin;
   const int s0 = (ymin + row) * kGridY, s1 = s0 + kGridY;
   const unsigned mask = even_odd ? 1u : ~0u;
+  RowShared S;
+  {
+    uint8_t *p = lds;
+    S.key = reinterpret_cast<uint64_t *> (p);           // (first: 16-byte aligned)
+    S.key32 = reinterpret_cast<uint32_t *> (p);
+    S.key_bytes = lds_bytes - (int) row_shared_fixed_bytes (width);
+    p += S.key_bytes;
+    S.cov = reinterpret_cast<int *> (p);
+    p += (size_t) ((width + 3) / 2) * sizeof (int);
+    S.unc = reinterpret_cast<int *> (p);
+    p += (size_t) (width + 2) * sizeof (int);
+    S.idx = reinterpret_cast<uint32_t *> (p);
+    p += kMaxActive * sizeof (uint32_t);
+    S.part = reinterpret_cast<int *> (p);
+    p += kThreads * sizeof (int);
+    S.sc = reinterpret_cast<int *> (p);
+    p += 16 * sizeof (int);
+    S.dir = reinterpret_cast<int8_t *> (p);
+  }
 
   for (int i = tid; i < width + 2; i += kThreads) {
-    S.cov[i] = 0;
+    if (i < (width + 3) / 2)
+      S.cov[i] = 0;
     S.unc[i] = 0;
   }
   if (tid == 0) {
-    S.n = 0;
-    S.flag = 0;
+    S.sc[0] = 0;
+    S.sc[1] = 0;
   }
   __syncthreads ();
   // the edges that cross this row
-  for (uint32_t i = tid; i < n_edges; i += kThreads) {
-    const int2 tb = *reinterpret_cast<const int2 *> (&edges[i]);
-    if (tb.x < s1 && tb.y > s0) {
-      const int k = atomicAdd (&S.n, 1);
-      if (k < kMaxActive)
-        S.idx[k] = i;
+  for (uint32_t base = 0; base < n_edges; base += kThreads * 8) {
+    int2 tb[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const uint32_t i = base + u * kThreads + tid;
+      tb[u] = i < n_edges ? spans[i] : make_int2 (INT_MAX, INT_MIN);
     }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (tb[u].x < s1 && tb[u].y > s0) {
+        const int k = atomicAdd (&S.sc[0], 1);
+        if (k < kMaxActive)
+          S.idx[k] = base + u * kThreads + tid;
+      }
   }
   __syncthreads ();
-  const int n = S.n;
+  const int n = S.sc[0];
   uint8_t *out = dst + (size_t) row * dst_stride;
   if (n > kMaxActive) {
     if (tid == 0)
@@ -582,6 +700,7 @@ scan_rows_kernel (const ScanEdge *__restrict__ edges, uint32_t n_edges,
 
   bool full_row = false;
   if (!row_flags[row]) {
+    dbg_mode |= 1;
     // every edge spans the whole row: analytic, if their order holds to its end
     for (int i = tid; i < npad; i += kThreads)
       S.key[i] = i < n ? make_key (edge_cell_at (edges[S.idx[i]], s0), S.idx[i]) : ~0ull;
@@ -591,9 +710,10 @@ scan_rows_kernel (const ScanEdge *__restrict__ edges, uint32_t n_edges,
     for (int p = tid; p + 1 < n; p += kThreads)
       if ((S.key[p] >> 32) == (S.key[p + 1] >> 32) &&
           !same_line (edges[(uint32_t) S.key[p]], edges[(uint32_t) S.key[p + 1]], s0))
-        S.flag = 1;
+        S.sc[1] = 1;
     __syncthreads ();
-    if (S.flag) {
+    if (S.sc[1]) {
+      dbg_mode |= 4;
       bool undecided = false;
       for (int g0 = 0; g0 + 1 < n && !undecided;) {
         int g1 = g0;
@@ -637,20 +757,22 @@ scan_rows_kernel (const ScanEdge *__restrict__ edges, uint32_t n_edges,
     }
     // can_do_full_row: the cells at the end of the row, in this order, do not decrease
     if (tid == 0)
-      S.result = 1;
+      S.sc[2] = 1;
     __syncthreads ();
     for (int p = tid; p + 1 < n; p += kThreads) {
       const int ca = edge_cell_at (edges[(uint32_t) S.key[p]], s1);
       const int cb = edge_cell_at (edges[(uint32_t) S.key[p + 1]], s1);
       if (cb < ca)
-        S.result = 0;
+        S.sc[2] = 0;
     }
     __syncthreads ();
-    full_row = S.result != 0;
+    full_row = S.sc[2] != 0;
     __syncthreads ();
   }
 
+  const uint64_t t_mid = debug ? wall_clock64 () : 0;
   if (full_row) {
+    dbg_mode |= 2;
     // winding over the sorted edges; a span starts on the first edge and after every end,
     // and ends where the winding returns to zero and the next cell differs
     const int per = (n + kThreads - 1) / kThreads;
@@ -660,10 +782,7 @@ scan_rows_kernel (const ScanEdge *__restrict__ edges, uint32_t n_edges,
       // (slot of an edge index: the keys carry edge indices here, directions by lookup)
       sum += edges[(uint32_t) S.key[p]].dir;
     }
-    S.part[tid] = sum;
-    __syncthreads ();
-    block_scan_256 (S.part, tid);
-    int w = S.part[tid] - sum;
+    int w = block_exclusive_scan (sum, tid, S.part);
     for (int p = p0; p < p1; p++) {
       const ScanEdge e = edges[(uint32_t) S.key[p]];
       const int w_before = w;
@@ -680,47 +799,188 @@ scan_rows_kernel (const ScanEdge *__restrict__ edges, uint32_t n_edges,
     }
     __syncthreads ();
   } else {
-    for (int sub = 0; sub < kGridY; sub++) {
-      const int s = s0 + sub;
-      for (int i = tid; i < npad; i += kThreads) {
-        uint64_t k = ~0ull;
+    // By sample rows, without sorting.  What Cairo's sorted walk yields depends on the
+    // order of cells only through the winding before and after each group of equal cells.
+    // The row's pixels are cut into up to 2048 bins (one pixel each where they suffice).
+    // Per sample row: every edge counts itself and its direction into its bin (one LDS
+    // atomic, which also tells it its place there); one prefix sum over the bins gives
+    // every bin the winding before it and where its edges go; the edges are laid out bin by
+    // bin; and every edge reads the few edges of its own bin -- side by side, not a list to
+    // chase: at the tips of glyphs a pen fan puts two dozen edges into one pixel -- for the
+    // winding before and after its cell.  Cells beyond the box's sides: left, only whether
+    // the winding enters the box non-zero matters (one covered sample row in the catch-all
+    // pixel); right, nothing.
+    int *bin_a = reinterpret_cast<int *> (S.key);       // [kBins] edges | winding << 16
+    int *bin_b = bin_a + kBins;                         // [kBins] first place | winding before << 12
+    uint32_t *seg = reinterpret_cast<uint32_t *> (bin_b + kBins);       // [kMaxActive] by bin:
+                                                        //   cell in the bin << 12 | up << 11 | slot
+    constexpr int kPer = kBins / kThreads;
+    const int lo_cell = (xmin - 1) * 256, hi_cell = (xmax + 1) * 256 - 1;
+    constexpr int kSlots = kMaxActive / kThreads;
+    // this thread's edges: x at their first sample row in this pixel row, then Cairo's steps
+    int32_t eq[kSlots], edq[kSlots];
+    int64_t er[kSlots], edr[kSlots], eD[kSlots];
+    int esa[kSlots], esb[kSlots];
+    if (tid == 0) {
+      S.sc[8] = INT_MAX;        // the pixels the row's edges stay within
+      S.sc[9] = INT_MIN;
+      S.sc[10] = 0;             // winding of the edges left of the box, this sample row
+    }
+    __syncthreads ();
+    {
+      int pmin = INT_MAX, pmax = INT_MIN;
+#pragma unroll
+      for (int j = 0; j < kSlots; j++) {
+        const int i = tid + j * kThreads;
+        esa[j] = esb[j] = 0;
+        eq[j] = edq[j] = 0;
+        er[j] = edr[j] = eD[j] = 0;
         if (i < n) {
           const ScanEdge e = edges[S.idx[i]];
-          if (e.ytop <= s && e.ybot > s)
-            k = make_key (edge_cell_at (e, s), (uint32_t) i);
+          esa[j] = e.ytop > s0 ? e.ytop : s0;
+          esb[j] = e.ybot < s1 ? e.ybot : s1;
+          edge_x_at (e, esa[j], eq[j], er[j]);
+          edq[j] = e.dq;
+          edr[j] = e.dr;
+          eD[j] = e.D;
+          // (an edge is a straight line: every step advances it by dq plus a fraction
+          // within (-1, 1))
+          const int ca = cell_of (eq[j], er[j], eD[j]);
+          const int steps = esb[j] - esa[j] - 1;
+          const int far = ca + steps * e.dq;
+          const int c0 = (ca < far - steps ? ca : far - steps) - 2;
+          const int c1 = (ca > far + steps ? ca : far + steps) + 2;
+          const int k0 = ((c0 < lo_cell ? lo_cell : (c0 > hi_cell ? hi_cell : c0)) - lo_cell) >> 8;
+          const int k1 = ((c1 < lo_cell ? lo_cell : (c1 > hi_cell ? hi_cell : c1)) - lo_cell) >> 8;
+          pmin = k0 < pmin ? k0 : pmin;
+          pmax = k1 > pmax ? k1 : pmax;
         }
-        S.key[i] = k;
+      }
+      if (pmin <= pmax) {
+        atomicMin (&S.sc[8], pmin);
+        atomicMax (&S.sc[9], pmax);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; k++)
+      bin_a[tid * kPer + k] = 0;
+    __syncthreads ();
+    // bins of 1 << shift pixels over [range0, range1)
+    const int range0 = S.sc[8] < 1 ? 1 : S.sc[8];
+    const int range1 = S.sc[9] + 1;
+    int shift = 0;
+    while (((range1 - range0 + (1 << shift) - 1) >> shift) > kBins)
+      shift++;
+    if (debug)
+      dbg_t = wall_clock64 ();
+    dbg_ph[4] = (uint32_t) (dbg_t - t_mid);
+    for (int s = s0; s < s1; s++) {
+      int cellj[kSlots], posj[kSlots];
+#pragma unroll
+      for (int j = 0; j < kSlots; j++) {
+        cellj[j] = INT_MIN;
+        posj[j] = 0;
+        if (s >= esa[j] && s < esb[j]) {
+          int cell = cell_of (eq[j], er[j], eD[j]);
+          cell = cell < lo_cell ? lo_cell : (cell > hi_cell ? hi_cell : cell);
+          cell -= lo_cell;
+          const int px = cell >> 8;
+          const int slot = tid + j * kThreads;
+          if (px == 0) {
+            atomicAdd (&S.sc[10], (int) S.dir[slot]);
+          } else if (px <= width) {
+            cellj[j] = cell;
+            const int old = atomicAdd (&bin_a[(px - range0) >> shift], (int) S.dir[slot] * 65536 + 1);
+            posj[j] = (int) (int16_t) (old & 0xffff);
+          }
+          if (eD[j]) {
+            eq[j] += edq[j];
+            er[j] += edr[j];
+            normalise (eq[j], er[j], eD[j]);
+          }
+        }
       }
       __syncthreads ();
-      bitonic_sort (S.key, npad, tid);
-      const int per = npad / kThreads > 0 ? npad / kThreads : 1;
-      const int p0 = tid * per, p1 = p0 + per < npad ? p0 + per : npad;
-      int sum = 0;
-      for (int p = p0; p < p1; p++)
-        if (S.key[p] != ~0ull)
-          sum += S.dir[(uint32_t) S.key[p]];
-      S.part[tid] = sum;
-      __syncthreads ();
-      block_scan_256 (S.part, tid);
-      int w = S.part[tid] - sum;
-      for (int p = p0; p < p1; p++) {
-        const uint64_t k = S.key[p];
-        if (k == ~0ull)
-          break;
-        const int w_before = w;
-        w += S.dir[(uint32_t) k];
-        const int cell = key_cell (k);
-        bool start = p == 0;
-        if (p > 0)
-          start = (w_before & mask) == 0 && key_cell (S.key[p - 1]) != cell;
-        const uint64_t kn = p + 1 < npad ? S.key[p + 1] : ~0ull;
-        const bool end = (w & mask) == 0 && (kn == ~0ull || key_cell (kn) != cell);
-        if (start != end) {
-          const int ix = cell >> 8, fx = cell & 0xff;
-          const int px = pixel_index (ix, xmin, width);
-          atomicAdd (&S.unc[px], start ? 2 * fx : -2 * fx);
-          atomicAdd (&S.cov[px], start ? 1 : -1);
+      DBG_PHASE (0);
+      // every bin: where its edges go, and the winding before it
+      const int left_w = S.sc[10];
+      {
+        int v[kPer], sum = 0;
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+          v[k] = bin_a[tid * kPer + k];         // (edges + 65536 * winding: one exact integer)
+          sum += v[k];
         }
+        int before = block_exclusive_scan (sum, tid, S.part);
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+          if (v[k]) {
+            const int place = (int) (int16_t) (before & 0xffff);
+            const int wind = (before - place) >> 16;
+            bin_b[tid * kPer + k] = (wind + left_w) * 4096 + place;
+          }
+          before += v[k];
+        }
+      }
+      __syncthreads ();
+      DBG_PHASE (1);
+#pragma unroll
+      for (int j = 0; j < kSlots; j++) {
+        if (cellj[j] == INT_MIN)
+          continue;
+        const int b = ((cellj[j] >> 8) - range0) >> shift;
+        const int in_bin = cellj[j] - ((range0 + (b << shift)) << 8);     // (< 16 pixels * 256)
+        const uint32_t slot = (uint32_t) (tid + j * kThreads);
+        seg[(bin_b[b] & 0xfff) + posj[j]] = ((uint32_t) in_bin << 12) |
+            (S.dir[slot] > 0 ? 0x800u : 0u) | slot;
+      }
+      __syncthreads ();
+      DBG_PHASE (2);
+#pragma unroll
+      for (int j = 0; j < kSlots; j++) {
+        if (cellj[j] == INT_MIN)
+          continue;
+        const int px = cellj[j] >> 8, fx = cellj[j] & 0xff;
+        const int b = (px - range0) >> shift;
+        const uint32_t slot = (uint32_t) (tid + j * kThreads);
+        const uint32_t mine = (uint32_t) (cellj[j] - ((range0 + (b << shift)) << 8));
+        const int word = bin_b[b];
+        const int place = word & 0xfff, count = (int) (int16_t) (bin_a[b] & 0xffff);
+        int wb = word >> 12, wa = wb;   // (place < 4096: exact)
+        uint32_t first = slot;          // the lowest slot among the edges of my cell speaks
+        for (int k = 0; k < count; k++) {
+          const uint32_t o = seg[place + k];
+          const uint32_t oc = o >> 12;
+          const int od = (o & 0x800u) ? 1 : -1;
+          if (oc < mine) {
+            wb += od;
+            wa += od;
+          } else if (oc == mine) {
+            wa += od;
+            if ((o & 0x7ff) < first)
+              first = o & 0x7ff;
+          }
+        }
+        if (first == slot) {
+          const bool start = (wb & mask) == 0, end = (wa & mask) == 0;
+          if (start != end) {
+            atomicAdd (&S.unc[px], start ? 2 * fx : -2 * fx);
+            cov_add (S.cov, px, start ? 1 : -1);
+          }
+        }
+      }
+      __syncthreads ();
+      DBG_PHASE (3);
+      // leave the bins clear for the next sample row
+#pragma unroll
+      for (int j = 0; j < kSlots; j++)
+        if (cellj[j] != INT_MIN)
+          bin_a[((cellj[j] >> 8) - range0) >> shift] = 0;
+      if (tid == 0) {
+        // a span that is open at the box's left side: one sample row in the catch-all
+        if ((left_w & mask) != 0)
+          cov_add (S.cov, 0, 1);
+        S.sc[10] = 0;
       }
       __syncthreads ();
     }
@@ -733,13 +993,10 @@ scan_rows_kernel (const ScanEdge *__restrict__ edges, uint32_t n_edges,
     const int p0 = tid * per, p1 = p0 + per < width + 2 ? p0 + per : width + 2;
     int sum = 0;
     for (int p = p0; p < p1; p++)
-      sum += S.cov[p];
-    S.part[tid] = sum;
-    __syncthreads ();
-    block_scan_256 (S.part, tid);
-    int c = S.part[tid] - sum;
+      sum += cov_get (S.cov, p);
+    int c = block_exclusive_scan (sum, tid, S.part);
     for (int p = p0; p < p1; p++) {
-      c += S.cov[p];
+      c += cov_get (S.cov, p);
       if (p >= 1 && p <= width) {
         const int16_t cover = (int16_t) (c * 512);
         const int16_t area = (int16_t) (cover - (int16_t) S.unc[p]);
@@ -747,6 +1004,15 @@ scan_rows_kernel (const ScanEdge *__restrict__ edges, uint32_t n_edges,
         out[p - 1] = (uint8_t) ((v + (v << 4) + 256) >> 9);
       }
     }
+  }
+  if (debug && tid == 0) {
+    // (tools/scan_rows_debug.py: where a row's time goes)
+    debug[row * 16 + 0] = (uint32_t) (wall_clock64 () - t_begin);
+    debug[row * 16 + 1] = (uint32_t) n;
+    debug[row * 16 + 2] = (uint32_t) dbg_mode;
+    debug[row * 16 + 3] = (uint32_t) (t_mid - t_begin);
+    for (int k = 0; k < 5; k++)
+      debug[row * 16 + 4 + k] = dbg_ph[k];
   }
 }
 
@@ -1195,10 +1461,21 @@ __global__ void scan_sequential_kernel (const int32_t *__restrict__ in_edges, ui
 
 }  // namespace
 
+static uint32_t *g_scan_debug = nullptr;
+
+// development aid (tools/scan_rows_debug.py): 4 words per row -- ticks of the 100 MHz
+// wall clock, edges in the row, mode bits (1 eligible, 2 analytic, 4 ties), ticks before
+// the conversion proper
+extern "C" void flutl_scan_set_debug (void *dev)
+{
+  g_scan_debug = static_cast<uint32_t *> (dev);
+}
+
 extern "C" size_t flutl_scan_scratch_bytes (uint32_t n_edges, uint32_t width, uint32_t height)
 {
   size_t b = 0;
   b += ((size_t) n_edges * sizeof (ScanEdge) + 255) & ~(size_t) 255;
+  b += ((size_t) n_edges * sizeof (int2) + 255) & ~(size_t) 255;
   b += ((size_t) height + 255) & ~(size_t) 255;
   b += 256;                                           // status
   b += ((size_t) (n_edges + 2) * sizeof (SeqEdge) + 255) & ~(size_t) 255;
@@ -1227,6 +1504,8 @@ extern "C" int flutl_launch_scan (void *stream_, const int32_t *edges_dev, uint3
   uint8_t *p = static_cast<uint8_t *> (scratch);
   ScanEdge *prepared = reinterpret_cast<ScanEdge *> (p);
   p += ((size_t) n_edges * sizeof (ScanEdge) + 255) & ~(size_t) 255;
+  int2 *spans = reinterpret_cast<int2 *> (p);
+  p += ((size_t) n_edges * sizeof (int2) + 255) & ~(size_t) 255;
   uint8_t *row_flags = p;
   p += ((size_t) height + 255) & ~(size_t) 255;
   uint32_t *status = reinterpret_cast<uint32_t *> (p);
@@ -1242,9 +1521,19 @@ extern "C" int flutl_launch_scan (void *stream_, const int32_t *edges_dev, uint3
     return FLUTL_ENODEV;
   if (mode != 2) {
     scan_prepare_kernel<<<(n_edges + 255) / 256, 256, 0, stream>>> (edges_dev, n_edges, ymin, ymax,
-        prepared, row_flags);
-    scan_rows_kernel<<<height, kThreads, 0, stream>>> (prepared, n_edges, row_flags, xmin, ymin,
-        xmax, ymax, even_odd, static_cast<uint8_t *> (dst), dst_stride, status);
+        prepared, row_flags, spans);
+    // LDS: the accumulators by the box width; a region that holds the sort keys of an
+    // eligible row's order and then the pixel histogram of the sample rows
+    const size_t fixed = row_shared_fixed_bytes ((int) width);
+    size_t keys = (size_t) kMaxActive * sizeof (uint32_t) + 2 * kBins * sizeof (int);
+    if (keys < (size_t) kMaxActive * sizeof (uint64_t))
+      keys = (size_t) kMaxActive * sizeof (uint64_t);
+    const size_t lds = fixed + keys;
+    if (lds > 65536)
+      return FLUTL_ERANGE;
+    scan_rows_kernel<<<height, kThreads, lds, stream>>> (prepared, spans, n_edges, row_flags, xmin, ymin,
+        xmax, ymax, even_odd, static_cast<uint8_t *> (dst), dst_stride, status, (int) lds,
+        g_scan_debug);
   }
   if (mode != 1)
     scan_sequential_kernel<<<1, 64, 0, stream>>> (edges_dev, n_edges, xmin, ymin, xmax, ymax,
@@ -1259,6 +1548,7 @@ extern "C" int flutl_scan_status (void *stream_, const void *scratch, uint32_t n
   hipStream_t stream = static_cast<hipStream_t> (stream_);
   const uint8_t *p = static_cast<const uint8_t *> (scratch);
   p += ((size_t) n_edges * sizeof (ScanEdge) + 255) & ~(size_t) 255;
+  p += ((size_t) n_edges * sizeof (int2) + 255) & ~(size_t) 255;
   p += ((size_t) height + 255) & ~(size_t) 255;
   if (hipMemcpyAsync (status_out, p, sizeof (uint32_t), hipMemcpyDeviceToHost, stream) != hipSuccess ||
       hipStreamSynchronize (stream) != hipSuccess)
