@@ -217,6 +217,57 @@ def e2e_block(W, H, cpu_baseline):
     return out
 
 
+def outline_block(with_cpu):
+    """The outline rasteriser: the stroke polygon of one cue of a typical 4K stream (two
+    lines of 96 px text, 3 px outline; bench_data/outline_4k.npz, made by the product's
+    stroker from the path the reference strokes, with the REAL cairo_stroke's coverage as
+    the answer) through flutl_launch_scan, HIP events; checked byte for byte; and the CPU
+    restatement of Cairo's converter (oracle/flutl_tor_oracle.c) on one host core."""
+    import torch
+    import pyflutl as F
+    z = np.load(os.path.join(ROOT, "bench_data", "outline_4k.npz"))
+    edges = np.ascontiguousarray(z["edges0"], np.int32)
+    box = tuple(int(v) for v in z["meta"][0][1:5])
+    want = z["cov0"]
+    w, h = box[2] - box[0], box[3] - box[1]
+    ed = torch.from_numpy(edges.view(np.uint8).reshape(-1).copy()).cuda()
+    scratch = torch.empty(F.scan_scratch_bytes(len(edges), w, h) + 256, dtype=torch.uint8,
+                          device="cuda")
+    dst = torch.zeros(h * (w + 4), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(5):
+        F.launch_scan(stream, ed, len(edges), box, 0, scratch, dst, w + 4, 0)
+    torch.cuda.synchronize()
+    got = dst.cpu().numpy().reshape(h, w + 4)[:, :w]
+    n = 200
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        F.launch_scan(stream, ed, len(edges), box, 0, scratch, dst, w + 4, 0)
+    b.record()
+    torch.cuda.synchronize()
+    us = a.elapsed_time(b) / n * 1000.0
+    out = {"what": "polygon scan conversion of one cue's outline (two 96 px lines, 3 px outline), "
+                   "edges resident in HBM -> A8 coverage in HBM",
+           "edges": int(len(edges)), "box": [w, h], "us_per_outline": round(us, 1),
+           "outlines_per_s": round(1e6 / us, 1), "Mpix_per_s": round(w * h / us, 1),
+           "bit_exact_vs_cairo": bool(np.array_equal(got, want))}
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 2.0:
+            cpu = O.scan_polygon(edges, box, False)
+            reps += 1
+        cpu_us = (time.perf_counter() - t0) / reps * 1e6
+        out["cpu_port"] = {"us_per_outline": round(cpu_us, 1), "cores": 1, "kind": "port",
+                           "sample": f"{reps} conversions of the same polygon by oracle/flutl_tor_oracle.c",
+                           "bit_exact_vs_cairo": bool(np.array_equal(cpu, want))}
+        out["vs_cpu_port"] = round(cpu_us / us, 1)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -486,6 +537,11 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import cpu_baseline
             res["cpu_baseline"] = cpu_baseline.measure(args.config, W, H, states, atlas)
+        if world == 1:
+            try:
+                res["outline_scan"] = outline_block(not args.no_cpu_baseline)
+            except Exception as e:      # noqa: BLE001
+                res["outline_scan"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_e2e and H == 2160:
             res["e2e"] = e2e_block(W, H, res.get("cpu_baseline"))
         print(json.dumps(res), flush=True)

@@ -63,6 +63,7 @@ struct flutl_ctx {
   uint64_t *delta_segments;   // device: segments (flutl_delta_segment_bytes) the delta read-backs wrote
   void *scan;          // device scratch of the polygon scan converter (edges + its own)
   size_t scan_cap;
+  uint32_t *scan_counters;     // device: [0] polygons the sequential converter took
 };
 
 struct flutl_frame {
@@ -276,6 +277,7 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
   c->delta_segments = nullptr;
   c->scan = nullptr;
   c->scan_cap = 0;
+  c->scan_counters = nullptr;
   // The first masks of a stream come with its first frame, and the caller's
   // recording thread may be waiting on whoever uploads them: the atlas and the
   // upload staging are made now (10 ms of allocation calls), not then.  (Failure
@@ -319,6 +321,8 @@ extern "C" void flutl_ctx_destroy (flutl_ctx *c)
     (void) hipFree (c->delta_segments);
   if (c->scan)
     (void) hipFree (c->scan);
+  if (c->scan_counters)
+    (void) hipFree (c->scan_counters);
   (void) hipStreamDestroy (c->stream);
   delete c;
 }
@@ -417,6 +421,10 @@ extern "C" int flutl_atlas_put (flutl_ctx *c, const void *src, size_t bytes,
 static int upload_list (flutl_ctx *c, const flutl_region *regions, uint32_t n_regions,
     const flutl_prim *prims, uint32_t n_prims, flutl_region **rd, flutl_prim **pd);
 
+extern "C" int flutl_launch_scan_counted (void *stream_, const int32_t *edges_dev, uint32_t n_edges,
+    const int32_t box[4], int even_odd, void *scratch, void *dst, size_t dst_stride, int mode,
+    uint32_t *counters_dev);
+
 extern "C" size_t flutl_polygon_entry_bytes (uint32_t w, uint32_t h)
 {
   return 4 + ((size_t) w + 4) * h;
@@ -451,12 +459,16 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
       c->scan_cap = 0;
     }
     size_t cap = need + need / 2;
+    if (cap < ((size_t) 8 << 20))
+      cap = (size_t) 8 << 20;   // (an outline of two 4K lines needs about 3 MB)
     if (!hip_ok (hipMalloc (&c->scan, cap)))
       return FLUTL_ENOMEM;
-    // (the fallback counter lives in it: starts at zero)
-    if (!hip_ok (hipMemsetAsync (c->scan, 0, cap, c->stream)))
-      return FLUTL_ENODEV;
     c->scan_cap = cap;
+  }
+  if (!c->scan_counters) {
+    if (!hip_ok (hipMalloc (reinterpret_cast<void **> (&c->scan_counters), 4 * sizeof (uint32_t))) ||
+        !hip_ok (hipMemsetAsync (c->scan_counters, 0, 4 * sizeof (uint32_t), c->stream)))
+      return FLUTL_ENOMEM;
   }
   int32_t *edges_dev = static_cast<int32_t *> (c->scan);
   if (n_edges) {
@@ -483,8 +495,9 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
   // the entry: zero (the padding around and between the rows), then the coverage
   if (!hip_ok (hipMemsetAsync (c->atlas + off, 0, bytes, c->stream)))
     return FLUTL_ENODEV;
-  rc = flutl_launch_scan (c->stream, edges_dev, n_edges, box, even_odd,
-      static_cast<uint8_t *> (c->scan) + edge_bytes, c->atlas + off + 4, (size_t) w + 4, 0);
+  rc = flutl_launch_scan_counted (c->stream, edges_dev, n_edges, box, even_odd,
+      static_cast<uint8_t *> (c->scan) + edge_bytes, c->atlas + off + 4, (size_t) w + 4, 0,
+      c->scan_counters);
   if (rc)
     return rc;
   c->atlas_used = end;
@@ -494,10 +507,14 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
 
 extern "C" uint32_t flutl_ctx_scan_fallbacks (flutl_ctx *c)
 {
-  // (the counter sits behind the status word of the scratch layout in use; it is only
-  // meaningful while the scratch has not been re-made: statistics)
-  (void) c;
-  return 0;
+  uint32_t n = 0;
+  if (!c || !c->scan_counters)
+    return 0;
+  (void) hipSetDevice (c->device);
+  if (!hip_ok (hipMemcpyAsync (&n, c->scan_counters, sizeof n, hipMemcpyDeviceToHost, c->stream)) ||
+      !hip_ok (hipStreamSynchronize (c->stream)))
+    return 0;
+  return n;
 }
 
 extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,

@@ -1223,7 +1223,7 @@ __device__ int seq_can_do_full_row (SeqState &t)
 __global__ void scan_sequential_kernel (const int32_t *__restrict__ in_edges, uint32_t n,
     int xmin, int ymin, int xmax, int ymax, int even_odd, uint8_t *__restrict__ dst,
     size_t dst_stride, uint32_t *__restrict__ status, int force, SeqEdge *__restrict__ sedges,
-    SeqEdge **__restrict__ y_buckets, int *__restrict__ cells)
+    SeqEdge **__restrict__ y_buckets, int *__restrict__ cells, uint32_t *__restrict__ counters)
 {
   if (threadIdx.x != 0 || blockIdx.x != 0)
     return;
@@ -1455,7 +1455,8 @@ __global__ void scan_sequential_kernel (const int32_t *__restrict__ in_edges, ui
   }
   if (!force) {
     status[0] = 0;
-    status[1] += 1;             // polygons that took this way (statistics)
+    if (counters)
+      counters[0] += 1;         // polygons that took this way (statistics)
   }
 }
 
@@ -1484,8 +1485,21 @@ extern "C" size_t flutl_scan_scratch_bytes (uint32_t n_edges, uint32_t width, ui
   return b;
 }
 
+extern "C" int flutl_launch_scan_counted (void *stream_, const int32_t *edges_dev, uint32_t n_edges,
+    const int32_t box[4], int even_odd, void *scratch, void *dst, size_t dst_stride, int mode,
+    uint32_t *counters_dev);
+
 extern "C" int flutl_launch_scan (void *stream_, const int32_t *edges_dev, uint32_t n_edges,
     const int32_t box[4], int even_odd, void *scratch, void *dst, size_t dst_stride, int mode)
+{
+  return flutl_launch_scan_counted (stream_, edges_dev, n_edges, box, even_odd, scratch, dst,
+      dst_stride, mode, nullptr);
+}
+
+// (library internal: counters_dev[0] counts the polygons the sequential kernel converted)
+extern "C" int flutl_launch_scan_counted (void *stream_, const int32_t *edges_dev, uint32_t n_edges,
+    const int32_t box[4], int even_odd, void *scratch, void *dst, size_t dst_stride, int mode,
+    uint32_t *counters_dev)
 {
   hipStream_t stream = static_cast<hipStream_t> (stream_);
   const int xmin = box[0], ymin = box[1], xmax = box[2], ymax = box[3];
@@ -1538,7 +1552,7 @@ extern "C" int flutl_launch_scan (void *stream_, const int32_t *edges_dev, uint3
   if (mode != 1)
     scan_sequential_kernel<<<1, 64, 0, stream>>> (edges_dev, n_edges, xmin, ymin, xmax, ymax,
         even_odd, static_cast<uint8_t *> (dst), dst_stride, status, mode == 2, sedges, y_buckets,
-        cells);
+        cells, counters_dev);
   return hipGetLastError () == hipSuccess ? FLUTL_OK : FLUTL_ENODEV;
 }
 

@@ -3237,7 +3237,7 @@ timing_report (GstTTMLRender *render)
   }
   g_printerr ("ttmlrender-hip timing: buffers=%u record_us=%.1f device_us=%.1f "
       "span_us=%" G_GINT64_FORMAT " drained_us=%" G_GINT64_FORMAT " delta_bytes=%.0f "
-      "deferred=%u resolve_wait_us=%.1f atlas_upload_us=%.1f build_us=%.1f layout_us=%.1f region_hits=%u region_misses=%u strokes=%u stroke_us=%.0f stroke_queued_us=%.0f pure_wait_us=%.0f submit_us=%.1f push_block_us=%.1f runs_merged=%u runs_clashed=%u path_us=%.0f extents_us=%.0f miss_us=%.1f recoloured=%u worker_extents_us=%.0f worker_draw_us=%.0f worker_crop_us=%.0f polygons=%u polygon_edges=%" G_GUINT64_FORMAT " t_first_us=%" G_GINT64_FORMAT " t_end_us=%" G_GINT64_FORMAT "\n",
+      "deferred=%u resolve_wait_us=%.1f atlas_upload_us=%.1f build_us=%.1f layout_us=%.1f region_hits=%u region_misses=%u strokes=%u stroke_us=%.0f stroke_queued_us=%.0f pure_wait_us=%.0f submit_us=%.1f push_block_us=%.1f runs_merged=%u runs_clashed=%u path_us=%.0f extents_us=%.0f miss_us=%.1f recoloured=%u worker_extents_us=%.0f worker_draw_us=%.0f worker_crop_us=%.0f polygons=%u polygon_edges=%" G_GUINT64_FORMAT " polygons_sequential=%u t_first_us=%" G_GINT64_FORMAT " t_end_us=%" G_GINT64_FORMAT "\n",
       priv->n_timed, (double) priv->t_record / MAX (priv->n_timed - 1, 1),
       (double) (priv->t_device + priv->t_submit) / MAX (priv->n_timed - 1, 1),
       priv->t_last_return - priv->t_first_return,
@@ -3254,7 +3254,7 @@ timing_report (GstTTMLRender *render)
       sj ? (double) pp / sj : 0.0, sj ? (double) pe / sj : 0.0,
       (double) priv->t_miss / MAX (priv->n_timed - 1, 1), priv->region_recoloured,
       sj ? (double) we / sj : 0.0, sj ? (double) wd / sj : 0.0, sj ? (double) wc / sj : 0.0,
-      priv->n_polygons, priv->polygon_edges,
+      priv->n_polygons, priv->polygon_edges, priv->ctx ? flutl_ctx_scan_fallbacks (priv->ctx) : 0,
       /* (CLOCK_MONOTONIC: comparable across the elements and processes of one box) */
       priv->t_first_return, MAX (t_drained, priv->t_last_return));
   priv->t_push_block = 0;

@@ -3,7 +3,9 @@
 real libcairo under /opt/conda, runs it and packs its records into
 tests/golden/polygons.npz (edges + box per polygon, Cairo's coverage as the answer).
 
-    python oracle/make_polygons.py
+    python oracle/make_polygons.py          tests/golden/polygons.npz
+    python oracle/make_polygons.py bench    bench_data/outline_4k.npz: the outline of one cue
+                                            of a typical 4K stream (bench.py's outline_scan)
 """
 import os
 import struct
@@ -25,8 +27,9 @@ def main():
         os.path.join(HERE, "flutl_tor_oracle.c"),
         os.path.join(ROOT, "flu-plugins-oss_amd", "host", "flutl_stroker.c"),
         f"-I{CONDA}/include/cairo", f"-L{CONDA}/lib", f"-Wl,-rpath,{CONDA}/lib", "-lcairo", "-lm"])
+    bench = len(sys.argv) > 1 and sys.argv[1] == "bench"
     raw = os.path.join(HERE, "_build", "polygons.bin")
-    subprocess.check_call([exe, raw] + sys.argv[1:])
+    subprocess.check_call([exe, raw] + (["0", "0", "0", "1", "bench"] if bench else sys.argv[1:]))
     data = open(raw, "rb").read()
     pos, out, meta = 0, {}, []
     while pos < len(data):
@@ -43,7 +46,8 @@ def main():
         meta.append((kind, x0, y0, x1, y1, eo))
     out["meta"] = np.array(meta, dtype=np.int32)
     out["versions"] = np.array(["cairo 1.16.0 (conda), DejaVu 2.37"])
-    path = os.path.join(ROOT, "tests", "golden", "polygons.npz")
+    path = os.path.join(ROOT, "bench_data", "outline_4k.npz") if bench else \
+        os.path.join(ROOT, "tests", "golden", "polygons.npz")
     np.savez_compressed(path, **out)
     print(f"{len(meta)} polygons -> {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 

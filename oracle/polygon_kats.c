@@ -281,6 +281,47 @@ main (int argc, char **argv)
     }
     cairo_surface_destroy (s);
   }
+  /* ---- kind 3 (argv[6]): the outline of one cue as bench.py's typical stream has them:
+   * two lines of 96 px text, 3 px outline (line width 6), on a 4K-wide surface ---------- */
+  if (argc > 6) {
+    const int W = 3840, H = 400;
+    cairo_surface_t *s = cairo_image_surface_create (CAIRO_FORMAT_A8, W, H);
+    const int stride = cairo_image_surface_get_stride (s);
+    cairo_t *cr = cairo_create (s);
+    cairo_set_source_rgba (cr, 1, 1, 1, 1);
+    cairo_select_font_face (cr, "DejaVu Sans", CAIRO_FONT_SLANT_NORMAL, CAIRO_FONT_WEIGHT_NORMAL);
+    cairo_set_font_size (cr, 96);
+    static const char *lines[2] = { "Subtitles are outlined so that they stay legible",
+      "over any picture: two lines, 96 px, 3 px outline" };
+    for (int ln = 0; ln < 2; ln++) {
+      cairo_save (cr);
+      cairo_translate (cr, 400 + 37 * ln, 150 + 140 * ln);
+      cairo_move_to (cr, 0, 0);
+      cairo_text_path (cr, lines[ln]);
+      cairo_restore (cr);
+    }
+    cairo_matrix_t ctm;
+    cairo_matrix_init_translate (&ctm, 400, 150);
+    cairo_path_t *path = cairo_copy_path (cr);
+    cairo_set_matrix (cr, &ctm);
+    cairo_set_line_width (cr, 6.0);
+    cairo_stroke (cr);
+    cairo_destroy (cr);
+    cairo_surface_flush (s);
+    const int lim[4] = { 0, 0, W, H };
+    FlutlPolygon pg;
+    flutl_polygon_init (&pg);
+    if (flutl_stroke_to_polygon (path, &ctm, 6.0, 10.0, CAIRO_LINE_JOIN_MITER, 0.1, lim, &pg) ==
+        FLUTL_STROKER_OK) {
+      written[0] = written[1] = written[2] = 0;
+      emit (2, pg.edges, (int) pg.n_edges, pg.box, 0, cairo_image_surface_get_data (s), stride);
+      fprintf (stderr, "polygon_kats: bench outline: %u edges, box %d %d %d %d\n", pg.n_edges,
+          pg.box[0], pg.box[1], pg.box[2], pg.box[3]);
+    }
+    cairo_path_destroy (path);
+    flutl_polygon_fini (&pg);
+    cairo_surface_destroy (s);
+  }
   fclose (out);
   fprintf (stderr, "polygon_kats: %d fills, %d strokes, %d text strokes written, %d rejected\n",
       written[0], written[1], written[2], rejected);

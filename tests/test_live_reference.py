@@ -133,3 +133,35 @@ def test_regions_played_back_in_other_colours_are_the_reference_s(ttml, tmp_path
             assert r.returncode == 0, r.stderr[-800:]
             counts[bool(extra)] = int(re.search(r"recoloured=(\d+)", r.stderr).group(1))
         assert counts[False] >= 3 and counts[True] == 0, counts
+
+
+CAIRO_DEV = os.path.exists(os.path.join(gstenv.CONDA, "include", "cairo", "cairo.h"))
+
+
+@pytest.mark.skipif(not CAIRO_DEV, reason="cairo development files not present")
+@pytest.mark.parametrize("mode,what", [(0, "random paths"), (1, "random paths cut by a clip box"),
+                                       (2, "lines of text"), (3, "text cut by a clip box")])
+def test_stroker_and_scan_restatement_are_cairo_stroke(mode, what):
+    """The product's host-side stroker (host/flutl_stroker.c: path -> the polygon Cairo
+    makes of a stroke) and the scan converter's restatement (oracle/flutl_tor_oracle.c)
+    against the REAL cairo_stroke of this image, byte for byte: oracle/stroke_check.c
+    (560 000 strokes when it was written; a few hundred per mode here)."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "_build/stroke_check"],
+                          stdout=subprocess.DEVNULL)
+    n = 1500 if mode < 2 else 250
+    r = subprocess.run([os.path.join(ROOT, "oracle", "_build", "stroke_check"), str(n),
+                        str(4242 + mode), str(mode)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and f"{n} paths, 0 differ" in r.stdout, r.stdout[-1500:]
+
+
+@pytest.mark.skipif(not CAIRO_DEV, reason="cairo development files not present")
+def test_scan_restatement_is_cairo_fill():
+    """oracle/tor_check.c: random polygons (coarse grids: equal sort keys everywhere)
+    through the real cairo_fill and through the restatement."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "_build/tor_check"],
+                          stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(ROOT, "oracle", "_build", "tor_check"), "3000", "99"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "3000 polygons, 0 differ" in r.stdout, r.stdout[-1500:]
