@@ -291,6 +291,18 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
     (void) hipMemcpyAsync (c->atlas, c->stage, (size_t) 1 << 20, hipMemcpyHostToDevice, c->stream);
     (void) hipStreamSynchronize (c->stream);
   }
+  // (... and so is the scan converter's scratch: the first cue of a stream brings the
+  // outlines of all its regions)
+  if (hip_ok (hipMalloc (&c->scan, (size_t) 8 << 20)) &&
+      hip_ok (hipMemsetAsync (c->scan, 0, 256, c->stream)))    // (the converter's status words)
+    c->scan_cap = (size_t) 8 << 20;
+  else
+    c->scan = nullptr;
+  if (hip_ok (hipMalloc (reinterpret_cast<void **> (&c->scan_counters), 4 * sizeof (uint32_t))))
+    (void) hipMemsetAsync (c->scan_counters, 0, 4 * sizeof (uint32_t), c->stream);
+  else
+    c->scan_counters = nullptr;
+  (void) hipStreamSynchronize (c->stream);
   *out = c;
   return FLUTL_OK;
 }
@@ -446,9 +458,11 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
   int rc = atlas_reserve (c, end + kAtlasSlack);
   if (rc)
     return rc;
-  // scratch: the edges, then the converter's own
+  // scratch: the converter's own (its status words first: they are zero between calls),
+  // then the edges
   const size_t edge_bytes = ((size_t) n_edges * 7 * sizeof (int32_t) + 255) & ~(size_t) 255;
-  const size_t need = edge_bytes + flutl_scan_scratch_bytes (n_edges, w, h);
+  const size_t own_bytes = flutl_scan_scratch_bytes (n_edges, w, h);
+  const size_t need = edge_bytes + own_bytes;
   if (need > c->scan_cap) {
     // (whatever still reads the old one is ordered before the free by the sync)
     if (c->scan) {
@@ -463,6 +477,8 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
       cap = (size_t) 8 << 20;   // (an outline of two 4K lines needs about 3 MB)
     if (!hip_ok (hipMalloc (&c->scan, cap)))
       return FLUTL_ENOMEM;
+    if (!hip_ok (hipMemsetAsync (c->scan, 0, 256, c->stream)))
+      return FLUTL_ENODEV;
     c->scan_cap = cap;
   }
   if (!c->scan_counters) {
@@ -470,7 +486,7 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
         !hip_ok (hipMemsetAsync (c->scan_counters, 0, 4 * sizeof (uint32_t), c->stream)))
       return FLUTL_ENOMEM;
   }
-  int32_t *edges_dev = static_cast<int32_t *> (c->scan);
+  int32_t *edges_dev = reinterpret_cast<int32_t *> (static_cast<uint8_t *> (c->scan) + own_bytes);
   if (n_edges) {
     const size_t eb = (size_t) n_edges * 7 * sizeof (int32_t);
     stage_reserve (c);
@@ -492,12 +508,15 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
       c->stage_used = 0;
     }
   }
-  // the entry: zero (the padding around and between the rows), then the coverage
-  if (!hip_ok (hipMemsetAsync (c->atlas + off, 0, bytes, c->stream)))
-    return FLUTL_ENODEV;
-  rc = flutl_launch_scan_counted (c->stream, edges_dev, n_edges, box, even_odd,
-      static_cast<uint8_t *> (c->scan) + edge_bytes, c->atlas + off + 4, (size_t) w + 4, 0,
-      c->scan_counters);
+  // the entry: the coverage, and the zero bytes around and between its rows (mode 8); the
+  // converter's status words are the first of its scratch and stay zero between calls (16)
+  if (n_edges == 0) {
+    if (!hip_ok (hipMemsetAsync (c->atlas + off, 0, bytes, c->stream)))
+      return FLUTL_ENODEV;
+  } else {
+    rc = flutl_launch_scan_counted (c->stream, edges_dev, n_edges, box, even_odd,
+        c->scan, c->atlas + off + 4, (size_t) w + 4, 0 | 8 | 16, c->scan_counters);
+  }
   if (rc)
     return rc;
   c->atlas_used = end;

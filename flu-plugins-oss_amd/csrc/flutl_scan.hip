@@ -115,10 +115,12 @@ __device__ inline void normalise (int32_t &q, int64_t &r, int64_t D)
 
 // ---- edges: cairo_edge_t -> ScanEdge (glitter_scan_converter_add_edge) ----------------
 __global__ void scan_prepare_kernel (const int32_t *__restrict__ edges, uint32_t n,
-    int ymin, int ymax, ScanEdge *__restrict__ out, uint8_t *__restrict__ row_flags,
-    int2 *__restrict__ spans)
+    int ymin, int ymax, ScanEdge *__restrict__ out, int2 *__restrict__ spans,
+    uint32_t *__restrict__ status)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0)
+    status[0] = 0;              // (the rows run behind this kernel in stream order)
   if (i >= n)
     return;
   const int32_t *in = edges + (size_t) i * 7;
@@ -172,12 +174,6 @@ __global__ void scan_prepare_kernel (const int32_t *__restrict__ edges, uint32_t
   }
   out[i] = e;
   spans[i] = make_int2 (ytop, ybot);    // (what the rows look through for their edges)
-  // rows that are converted by sample rows whatever the order of their edges: an edge
-  // starts or ends inside them
-  if (ytop % kGridY)
-    row_flags[ytop / kGridY - ymin] = 1;
-  if (ybot % kGridY)
-    row_flags[ybot / kGridY - ymin] = 1;
 }
 
 // ---- workgroup helpers ------------------------------------------------------------------
@@ -219,8 +215,8 @@ struct RowShared {
   int8_t *dir;          // [kMaxActive] slot -> winding direction
   int *part;            // [kThreads]
   int *sc;              // scalars: 0 n, 1 flag, 2 result, 4.. scratch of the tie rules
-  uint64_t *key;        // sort keys of the row-start order (cell, edge index): [npad]
-  uint32_t *key32;      // the same memory as sample-row keys (cell << 11 | slot): [rows][npad]
+  uint64_t *key;        // sort keys of the row-start order (cell, edge index): [npad]; then
+                        // the bins of the sample rows (the same memory)
   int key_bytes;        // what is there for keys
 };
 
@@ -243,17 +239,6 @@ __device__ inline int cov_get (const int *cov, int k)
   const int w = cov[k >> 1];
   const int lo = (int) (int16_t) (w & 0xffff);
   return (k & 1) ? (w - lo) >> 16 : lo;
-}
-
-// inclusive prefix sums of part[0..255] in place (all threads call)
-__device__ inline void block_scan_256 (int *part, int tid)
-{
-  for (int off = 1; off < kThreads; off <<= 1) {
-    const int v = tid >= off ? part[tid - off] : 0;
-    __syncthreads ();
-    part[tid] += v;
-    __syncthreads ();
-  }
 }
 
 __device__ inline int pixel_index (int ix, int xmin, int width)
@@ -512,8 +497,20 @@ __device__ int bucket_rule (RowShared &S, const ScanEdge *edges, uint32_t n, int
   return result;
 }
 
-__device__ int tie_order (RowShared &S, const ScanEdge *edges, uint32_t n, const uint8_t *row_flags,
-    int ymin, uint32_t ia, uint32_t ib, int s, int tid)
+// A row that is converted by sample rows whatever the order of its edges: an edge starts
+// or ends inside it.  (All threads call; rare: only a tie asks.)
+__device__ bool row_is_sub_certain (const int2 *spans, uint32_t n, int r, int tid)
+{
+  bool hit = false;
+  for (uint32_t i = tid; i < n && !hit; i += kThreads) {
+    const int2 tb = spans[i];
+    hit = (tb.x > r && tb.x < r + kGridY) || (tb.y > r && tb.y < r + kGridY);
+  }
+  return __syncthreads_or (hit) != 0;
+}
+
+__device__ int tie_order (RowShared &S, const ScanEdge *edges, uint32_t n, const int2 *spans,
+    uint32_t ia, uint32_t ib, int s, int tid)
 {
   const ScanEdge a = edges[ia], b = edges[ib];
   const int t0 = a.ytop > b.ytop ? a.ytop : b.ytop;
@@ -530,7 +527,7 @@ __device__ int tie_order (RowShared &S, const ScanEdge *edges, uint32_t n, const
     const int ra = edge_cell_at (a, r), rb = edge_cell_at (b, r);
     if (ra != rb && (ra < rb ? -1 : 1) == sign)
       return sign;
-    if (row_flags[r / kGridY - ymin])
+    if (row_is_sub_certain (spans, n, r, tid))
       return sign;
     return 2;
   }
@@ -556,36 +553,460 @@ __device__ inline bool same_line (const ScanEdge &a, const ScanEdge &b, int s)
   return qa == qb && ra == rb;
 }
 
-// ---- one pixel row per workgroup ---------------------------------------------------------------
-// ---- wave-level helpers (the four waves of a workgroup convert different sample rows) ----
-__device__ inline void wave_fence ()
+// ---- the sequential sweep (exact by construction; one lane) ----------------------------------
+// A port of Cairo's sweep as it stands (see oracle/flutl_tor_oracle.c for the same
+// statement on the CPU, which the tests hold this kernel to as well).
+struct SeqEdge {
+  SeqEdge *next, *prev;
+  int ytop, height_left, dir, cell;
+  int32_t xq;
+  int64_t xr;
+  int32_t dq;
+  int64_t dr;
+  int32_t fq;
+  int64_t fr;
+  int64_t dy;
+};
+
+struct SeqState {
+  SeqEdge &head, &tail;         // (in device memory like the edges: they are linked to)
+  int min_height, is_vertical;
+  int *cov, *unc;               // width + 2 each
+  int xmin, width;
+};
+
+__device__ inline void seq_step_full (SeqEdge *e)
 {
-  // LDS traffic of one wave is processed in order; this only keeps the compiler from
-  // moving accesses across
-  __builtin_amdgcn_fence (__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier ();
+  if (!e->dy)
+    return;
+  e->xq += e->fq;
+  e->xr += e->fr;
+  normalise (e->xq, e->xr, e->dy);
+  e->cell = e->xq + (e->dy / 2 <= e->xr);
 }
 
-// bitonic sort of npad (a power of two >= 64) 32-bit keys in LDS by one wave
-__device__ inline void wave_bitonic_sort (uint32_t *key, int npad, int lane)
+__device__ SeqEdge *seq_merge (SeqEdge *head_a, SeqEdge *head_b)
 {
-  for (int k = 2; k <= npad; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = lane; t < npad / 2; t += 64) {
-        // the t-th pair of this stage: i has bit j clear
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int ixj = i | j;
-        const uint32_t a = key[i], b = key[ixj];
-        const bool up = (i & k) == 0;
-        if ((a > b) == up) {
-          key[i] = b;
-          key[ixj] = a;
+  SeqEdge *head, **next, *prev;
+  int x;
+  prev = head_a->prev;
+  next = &head;
+  if (head_a->cell <= head_b->cell) {
+    head = head_a;
+  } else {
+    head = head_b;
+    head_b->prev = prev;
+    goto start_with_b;
+  }
+  for (;;) {
+    x = head_b->cell;
+    while (head_a != nullptr && head_a->cell <= x) {
+      prev = head_a;
+      next = &head_a->next;
+      head_a = head_a->next;
+    }
+    head_b->prev = prev;
+    *next = head_b;
+    if (head_a == nullptr)
+      return head;
+  start_with_b:
+    x = head_a->cell;
+    while (head_b != nullptr && head_b->cell <= x) {
+      prev = head_b;
+      next = &head_b->next;
+      head_b = head_b->next;
+    }
+    head_a->prev = prev;
+    *next = head_a;
+    if (head_b == nullptr)
+      return head;
+  }
+}
+
+__device__ SeqEdge *seq_sort (SeqEdge *list, unsigned level, SeqEdge **head_out)
+{
+  SeqEdge *head_other = list->next, *remaining;
+  if (head_other == nullptr) {
+    *head_out = list;
+    return nullptr;
+  }
+  remaining = head_other->next;
+  if (list->cell <= head_other->cell) {
+    *head_out = list;
+    head_other->next = nullptr;
+  } else {
+    *head_out = head_other;
+    head_other->prev = list->prev;
+    head_other->next = list;
+    list->prev = head_other;
+    list->next = nullptr;
+  }
+  for (unsigned i = 0; i < level && remaining; i++) {
+    remaining = seq_sort (remaining, i, &head_other);
+    *head_out = seq_merge (*head_out, head_other);
+  }
+  return remaining;
+}
+
+__device__ inline void seq_cell_add (SeqState &t, int ix, int dcov, int dunc)
+{
+  const int k = pixel_index (ix, t.xmin, t.width);
+  t.cov[k] += dcov;
+  t.unc[k] += dunc;
+}
+
+__device__ void seq_render_edge (SeqState &t, SeqEdge *e, int sign)
+{
+  int32_t x1q = e->xq, x2q;
+  int64_t x1r = e->xr, x2r;
+  if (e->dy == 0) {
+    x2q = x1q;
+    x2r = x1r;
+  } else {
+    seq_step_full (e);
+    const int32_t hq = e->dq / 2;
+    const int64_t hr = e->dr / 2;
+    x1q -= hq;
+    x1r -= hr;
+    normalise (x1q, x1r, e->dy);
+    x2q = e->xq - hq;
+    x2r = e->xr - hr;
+    normalise (x2q, x2r, e->dy);
+  }
+  const int fx1 = x1q & 0xff, fx2 = x2q & 0xff;
+  const int ix1 = x1q >> 8, ix2 = x2q >> 8;
+  if (ix1 == ix2) {
+    seq_cell_add (t, ix1, sign * kGridY, sign * kGridY * (fx1 + fx2));
+    return;
+  }
+  int32_t loq = x2q, hiq = x1q;
+  int64_t lor = x2r, hir = x1r;
+  int ixlo = ix2, ixhi = ix1, fxlo = fx2, fxhi = fx1;
+  if (ix1 < ix2) {
+    loq = x1q; hiq = x2q; lor = x1r; hir = x2r;
+    ixlo = ix1; ixhi = ix2; fxlo = fx1; fxhi = fx2;
+  }
+  const int64_t D = e->dy;
+  const int64_t tx = (hir - lor) + (int64_t) (hiq - loq) * D;
+  int ix = ixlo + 1;
+  const int64_t a = (int64_t) (int32_t) ((uint32_t) ix << 8) * D - ((int64_t) loq * D + lor);
+  int64_t yq = (a * kGridY) / tx, yr = (a * kGridY) % tx;
+  {
+    const int h = (int) yq * sign;
+    seq_cell_add (t, ixlo, h, (fxlo + 256) * h);
+  }
+  int y = (int) yq;
+  if (ix < ixhi) {
+    const int64_t sq = (D * kGridY * 256) / tx, sr = (D * kGridY * 256) % tx;
+    do {
+      int y2 = (int) sq + y;
+      yr += sr;
+      if (yr >= tx) {
+        y2++;
+        yr -= tx;
+      }
+      const int h = (y2 - y) * sign;
+      seq_cell_add (t, ix, h, h * 256);
+      y = y2;
+      ix++;
+    } while (ix != ixhi);
+  }
+  {
+    const int h = sign * (kGridY - y);
+    seq_cell_add (t, ixhi, h, fxhi * h);
+  }
+}
+
+__device__ inline void seq_dec (SeqState &t, SeqEdge *e, int h)
+{
+  e->height_left -= h;
+  if (e->height_left == 0) {
+    e->prev->next = e->next;
+    e->next->prev = e->prev;
+    t.min_height = -1;
+  }
+}
+
+__device__ int seq_can_do_full_row (SeqState &t)
+{
+  if (t.min_height <= 0) {
+    int min_height = INT_MAX, is_vertical = 1;
+    for (SeqEdge *e = t.head.next; e != nullptr; e = e->next) {
+      if (e->height_left < min_height)
+        min_height = e->height_left;
+      is_vertical &= e->dy == 0;
+    }
+    t.is_vertical = is_vertical;
+    t.min_height = min_height;
+  }
+  if (t.min_height < kGridY)
+    return 0;
+  int prev_x = INT_MIN;
+  for (SeqEdge *e = t.head.next; e != &t.tail; e = e->next) {
+    int cell = e->cell;
+    if (e->dy) {
+      int32_t q = e->xq + e->fq;
+      int64_t r = e->xr + e->fr;
+      normalise (q, r, e->dy);
+      cell = q + (e->dy / 2 <= r);
+    }
+    if (cell < prev_x)
+      return 0;
+    prev_x = cell;
+  }
+  return 1;
+}
+
+struct SeqArgs {
+  const int32_t *in_edges;      // the polygon as it came (cairo_edge_t)
+  SeqEdge *sedges;              // [n + 2]
+  SeqEdge **y_buckets;          // [height]
+  int *cells;                   // [2 * (width + 2)]
+  uint32_t *counters;           // [0]: polygons converted this way (statistics), or null
+};
+
+__device__ __noinline__ void sequential_sweep (const int32_t *__restrict__ in_edges, uint32_t n,
+    int xmin, int ymin, int xmax, int ymax, int even_odd, uint8_t *__restrict__ dst,
+    size_t dst_stride, SeqEdge *__restrict__ sedges, SeqEdge **__restrict__ y_buckets,
+    int *__restrict__ cells)
+{
+  const int h = ymax - ymin, width = xmax - xmin;
+  SeqState t = { sedges[n], sedges[n + 1], 0, 1, nullptr, nullptr, 0, 0 };
+  t.cov = cells;
+  t.unc = cells + (width + 2);
+  t.xmin = xmin;
+  t.width = width;
+  t.head.cell = INT_MIN;
+  t.head.height_left = INT_MAX;
+  t.head.next = &t.tail;
+  t.head.prev = nullptr;
+  t.head.dy = 0;
+  t.tail.prev = &t.head;
+  t.tail.next = nullptr;
+  t.tail.cell = INT_MAX;
+  t.tail.height_left = INT_MAX;
+  t.tail.dy = 0;
+  t.min_height = 0;
+  t.is_vertical = 1;
+  for (int i = 0; i < h; i++)
+    y_buckets[i] = nullptr;
+  for (uint32_t i = 0; i < n; i++) {
+    const int32_t *in = in_edges + (size_t) i * 7;
+    int ytop = (int) (((int64_t) in[4] * kGridY + 128) >> 8);
+    int ybot = (int) (((int64_t) in[5] * kGridY + 128) >> 8);
+    if (ytop < ymin * kGridY)
+      ytop = ymin * kGridY;
+    if (ybot > ymax * kGridY)
+      ybot = ymax * kGridY;
+    if (ybot <= ytop)
+      continue;
+    SeqEdge *e = &sedges[i];
+    e->ytop = ytop;
+    e->height_left = ybot - ytop;
+    int32_t p1x = in[0], p1y = in[1], p2x = in[2], p2y = in[3];
+    e->dir = in[6];
+    if (!(p2y > p1y)) {
+      int32_t s = p1x; p1x = p2x; p2x = s;
+      s = p1y; p1y = p2y; p2y = s;
+      e->dir = -e->dir;
+    }
+    if (p2x == p1x) {
+      e->cell = p2x;
+      e->xq = p1x;
+      e->xr = 0;
+      e->dq = 0; e->dr = 0; e->fq = 0; e->fr = 0;
+      e->dy = 0;
+    } else {
+      const int64_t dx = (int64_t) p2x - p1x;
+      const int64_t Dy = ((int64_t) p2y - p1y) * kGridY * 512;
+      const int64_t Ex = dx * 256;
+      e->dq = (int32_t) ((dx * 131072) / Dy);
+      e->dr = (dx * 131072) % Dy;
+      const int64_t num = ((int64_t) (2 * ytop + 1) * 256 - 2 * (int64_t) kGridY * p1y) * Ex;
+      e->xq = (int32_t) (num / Dy) + p1x;
+      e->xr = num % Dy;
+      normalise (e->xq, e->xr, Dy);
+      if (e->height_left >= kGridY) {
+        e->fq = (int32_t) ((Ex * kGridY * 512) / Dy);
+        e->fr = (Ex * kGridY * 512) % Dy;
+      } else {
+        e->fq = 0;
+        e->fr = 0;
+      }
+      e->dy = Dy;
+      e->cell = e->xq + (Dy / 2 <= e->xr);
+    }
+    SeqEdge **b = &y_buckets[(ytop - ymin * kGridY) / kGridY];
+    e->next = *b;
+    *b = e;
+  }
+
+  const unsigned mask = even_odd ? 1u : ~0u;
+  SeqEdge *buckets[kGridY];
+  for (int i = 0; i < kGridY; i++)
+    buckets[i] = nullptr;
+  int j;
+  for (int i = 0; i < h; i = j) {
+    int do_full_row = 0;
+    j = i + 1;
+    if (y_buckets[i]) {
+      int max_suby = 0;
+      const int row_top = (i + ymin) * kGridY;
+      for (SeqEdge *e = y_buckets[i], *nx; e; e = nx) {
+        nx = e->next;
+        const int suby = e->ytop - row_top;
+        if (buckets[suby])
+          buckets[suby]->prev = e;
+        e->next = buckets[suby];
+        e->prev = nullptr;
+        buckets[suby] = e;
+        if (e->height_left < t.min_height)
+          t.min_height = e->height_left;
+        t.is_vertical &= e->dy == 0;
+        if (suby > max_suby)
+          max_suby = suby;
+      }
+      if (max_suby == 0) {
+        if (buckets[0]) {
+          SeqEdge *sorted;
+          seq_sort (buckets[0], UINT_MAX, &sorted);
+          t.head.next = seq_merge (t.head.next, sorted);
+          buckets[0] = nullptr;
+        }
+        do_full_row = seq_can_do_full_row (t);
+      }
+    } else {
+      if (t.head.next == &t.tail) {
+        t.min_height = INT_MAX;
+        t.is_vertical = 1;
+        for (; j < h && !y_buckets[j]; j++)
+          ;
+        for (int r = i; r < j; r++)
+          for (int x = 0; x < width; x++)
+            dst[(size_t) r * dst_stride + x] = 0;
+        continue;
+      }
+      do_full_row = seq_can_do_full_row (t);
+    }
+    for (int k = 0; k < 2 * (width + 2); k++)
+      cells[k] = 0;
+    if (do_full_row) {
+      SeqEdge *left = t.head.next;
+      while (left != &t.tail) {
+        SeqEdge *right;
+        int winding;
+        seq_dec (t, left, kGridY);
+        winding = left->dir;
+        right = left->next;
+        for (;;) {
+          seq_dec (t, right, kGridY);
+          winding += right->dir;
+          if ((winding & mask) == 0 && right->next->cell != right->cell)
+            break;
+          seq_step_full (right);
+          right = right->next;
+        }
+        seq_render_edge (t, left, +1);
+        seq_render_edge (t, right, -1);
+        left = right->next;
+      }
+      if (t.is_vertical) {
+        while (j < h && y_buckets[j] == nullptr && t.min_height >= 2 * kGridY) {
+          t.min_height -= kGridY;
+          j++;
+        }
+        if (j != i + 1) {
+          const int count = (j - (i + 1)) * kGridY;
+          for (SeqEdge *e = t.head.next, *nx; e != &t.tail; e = nx) {
+            nx = e->next;
+            seq_dec (t, e, count);
+          }
         }
       }
-      wave_fence ();
+    } else {
+      for (int sub = 0; sub < kGridY; sub++) {
+        if (buckets[sub]) {
+          SeqEdge *sorted;
+          seq_sort (buckets[sub], UINT_MAX, &sorted);
+          t.head.next = seq_merge (t.head.next, sorted);
+          buckets[sub] = nullptr;
+        }
+        SeqEdge *e = t.head.next;
+        int xstart = INT_MIN, prev_x = INT_MIN, winding = 0;
+        while (e != &t.tail) {
+          SeqEdge *next = e->next;
+          const int xend = e->cell;
+          if (--e->height_left) {
+            if (e->dy) {
+              e->xq += e->dq;
+              e->xr += e->dr;
+              normalise (e->xq, e->xr, e->dy);
+              e->cell = e->xq + (e->dy / 2 <= e->xr);
+            }
+            if (e->cell < prev_x) {
+              SeqEdge *pos = e->prev;
+              pos->next = next;
+              next->prev = pos;
+              do
+                pos = pos->prev;
+              while (e->cell < pos->cell);
+              pos->next->prev = e;
+              e->next = pos->next;
+              e->prev = pos;
+              pos->next = e;
+            } else {
+              prev_x = e->cell;
+            }
+            t.min_height = -1;
+          } else {
+            e->prev->next = next;
+            next->prev = e->prev;
+          }
+          winding += e->dir;
+          if ((winding & mask) == 0) {
+            if (next->cell != xend) {
+              if (xend != xstart) {
+                seq_cell_add (t, xstart >> 8, 1, 2 * (xstart & 0xff));
+                seq_cell_add (t, xend >> 8, -1, -2 * (xend & 0xff));
+              }
+              xstart = INT_MIN;
+            }
+          } else if (xstart == INT_MIN) {
+            xstart = xend;
+          }
+          e = next;
+        }
+      }
     }
+    {
+      int c = t.cov[0];
+      uint8_t *row = dst + (size_t) i * dst_stride;
+      for (int x = 0; x < width; x++) {
+        c += t.cov[x + 1];
+        const int16_t cover = (int16_t) (c * 512);
+        const int16_t area = (int16_t) (cover - (int16_t) t.unc[x + 1]);
+        const int v = (int) area;
+        row[x] = (uint8_t) ((v + (v << 4) + 256) >> 9);
+      }
+      for (int r = i + 1; r < j; r++)
+        for (int x = 0; x < width; x++)
+          dst[(size_t) r * dst_stride + x] = row[x];
+    }
+    t.min_height -= kGridY;
+  }
 }
 
+__global__ void scan_sequential_kernel (const int32_t *__restrict__ in_edges, uint32_t n,
+    int xmin, int ymin, int xmax, int ymax, int even_odd, uint8_t *__restrict__ dst,
+    size_t dst_stride, SeqEdge *__restrict__ sedges, SeqEdge **__restrict__ y_buckets,
+    int *__restrict__ cells)
+{
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    sequential_sweep (in_edges, n, xmin, ymin, xmax, ymax, even_odd, dst, dst_stride, sedges,
+        y_buckets, cells);
+}
+
+// ---- wave-level helpers ------------------------------------------------------------------------
 __device__ inline int wave_inclusive_scan (int v, int lane)
 {
   for (int off = 1; off < 64; off <<= 1) {
@@ -611,12 +1032,11 @@ __device__ inline int block_exclusive_scan (int v, int tid, int *part)
   return base + incl - v;
 }
 
-constexpr uint32_t kKeyNone = 0xffffffffu;
-constexpr int kSlotBits = 11;           // kMaxActive = 2048 slots
 
-__global__ void __launch_bounds__ (kThreads)
-scan_rows_kernel (const ScanEdge *__restrict__ edges, const int2 *__restrict__ spans,
-    uint32_t n_edges, const uint8_t *__restrict__ row_flags, int xmin, int ymin, int xmax, int ymax, int even_odd,
+// ---- one pixel row per workgroup ---------------------------------------------------------------
+__device__ __forceinline__ void
+scan_row (const ScanEdge *__restrict__ edges, const int2 *__restrict__ spans,
+    uint32_t n_edges, int xmin, int ymin, int xmax, int ymax, int even_odd,
     uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ status, int lds_bytes,
     uint32_t *__restrict__ debug)
 {
@@ -635,7 +1055,6 @@ scan_rows_kernel (const ScanEdge *__restrict__ edges, const int2 *__restrict__ s
   {
     uint8_t *p = lds;
     S.key = reinterpret_cast<uint64_t *> (p);           // (first: 16-byte aligned)
-    S.key32 = reinterpret_cast<uint32_t *> (p);
     S.key_bytes = lds_bytes - (int) row_shared_fixed_bytes (width);
     p += S.key_bytes;
     S.cov = reinterpret_cast<int *> (p);
@@ -659,9 +1078,12 @@ scan_rows_kernel (const ScanEdge *__restrict__ edges, const int2 *__restrict__ s
   if (tid == 0) {
     S.sc[0] = 0;
     S.sc[1] = 0;
+    S.sc[13] = 0;
   }
   __syncthreads ();
-  // the edges that cross this row
+  // the edges that cross this row; and whether one of them starts or ends inside it (the
+  // row is then converted by sample rows whatever the order of its edges)
+  bool inside = false;
   for (uint32_t base = 0; base < n_edges; base += kThreads * 8) {
     int2 tb[8];
 #pragma unroll
@@ -675,8 +1097,11 @@ scan_rows_kernel (const ScanEdge *__restrict__ edges, const int2 *__restrict__ s
         const int k = atomicAdd (&S.sc[0], 1);
         if (k < kMaxActive)
           S.idx[k] = base + u * kThreads + tid;
+        inside |= tb[u].x > s0 || tb[u].y < s1;
       }
   }
+  if (inside)
+    S.sc[13] = 1;
   __syncthreads ();
   const int n = S.sc[0];
   uint8_t *out = dst + (size_t) row * dst_stride;
@@ -699,7 +1124,7 @@ scan_rows_kernel (const ScanEdge *__restrict__ edges, const int2 *__restrict__ s
     S.dir[i] = (int8_t) edges[S.idx[i]].dir;
 
   bool full_row = false;
-  if (!row_flags[row]) {
+  if (!S.sc[13]) {
     dbg_mode |= 1;
     // every edge spans the whole row: analytic, if their order holds to its end
     for (int i = tid; i < npad; i += kThreads)
@@ -727,7 +1152,7 @@ scan_rows_kernel (const ScanEdge *__restrict__ edges, const int2 *__restrict__ s
               const uint32_t ea = (uint32_t) S.key[j - 1], eb = (uint32_t) S.key[j];
               int o = -1;
               if (!same_line (edges[ea], edges[eb], s0))
-                o = tie_order (S, edges, n_edges, row_flags, ymin, ea, eb, s0, tid);
+                o = tie_order (S, edges, n_edges, spans, ea, eb, s0, tid);
               if (o == 2) {
                 undecided = true;
                 break;
@@ -1016,447 +1441,44 @@ scan_rows_kernel (const ScanEdge *__restrict__ edges, const int2 *__restrict__ s
   }
 }
 
-// ---- the sequential sweep (exact by construction; one lane) ----------------------------------
-// A port of Cairo's sweep as it stands (see oracle/flutl_tor_oracle.c for the same
-// statement on the CPU, which the tests hold this kernel to as well).
-struct SeqEdge {
-  SeqEdge *next, *prev;
-  int ytop, height_left, dir, cell;
-  int32_t xq;
-  int64_t xr;
-  int32_t dq;
-  int64_t dr;
-  int32_t fq;
-  int64_t fr;
-  int64_t dy;
-};
-
-struct SeqState {
-  SeqEdge &head, &tail;         // (in device memory like the edges: they are linked to)
-  int min_height, is_vertical;
-  int *cov, *unc;               // width + 2 each
-  int xmin, width;
-};
-
-__device__ inline void seq_step_full (SeqEdge *e)
+__global__ void __launch_bounds__ (kThreads)
+scan_rows_kernel (const ScanEdge *__restrict__ edges, const int2 *__restrict__ spans,
+    uint32_t n_edges, int xmin, int ymin, int xmax, int ymax, int even_odd,
+    uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ status, int lds_bytes,
+    uint32_t *__restrict__ debug, int pad_zero, int with_sequential, SeqArgs seq)
 {
-  if (!e->dy)
+  scan_row (edges, spans, n_edges, xmin, ymin, xmax, ymax, even_odd, dst, dst_stride, status,
+      lds_bytes, debug);
+  const int tid = threadIdx.x, width = xmax - xmin;
+  if (pad_zero && tid < 4) {
+    // the MASK layout's zero bytes: 4 after every row, 4 in front of the first
+    dst[(size_t) blockIdx.x * dst_stride + width + tid] = 0;
+    if (blockIdx.x == 0)
+      *(dst - 4 + tid) = 0;
+  }
+  if (!with_sequential)
     return;
-  e->xq += e->fq;
-  e->xr += e->fr;
-  normalise (e->xq, e->xr, e->dy);
-  e->cell = e->xq + (e->dy / 2 <= e->xr);
-}
-
-__device__ SeqEdge *seq_merge (SeqEdge *head_a, SeqEdge *head_b)
-{
-  SeqEdge *head, **next, *prev;
-  int x;
-  prev = head_a->prev;
-  next = &head;
-  if (head_a->cell <= head_b->cell) {
-    head = head_a;
-  } else {
-    head = head_b;
-    head_b->prev = prev;
-    goto start_with_b;
+  // The workgroup that finishes last looks whether any row raised a flag, and if so
+  // converts the polygon again by the sequential sweep (one lane; exact by construction).
+  __shared__ int s_last;
+  __syncthreads ();
+  if (tid == 0) {
+    __threadfence ();
+    s_last = atomicAdd (&status[2], 1u) == gridDim.x - 1;
   }
-  for (;;) {
-    x = head_b->cell;
-    while (head_a != nullptr && head_a->cell <= x) {
-      prev = head_a;
-      next = &head_a->next;
-      head_a = head_a->next;
-    }
-    head_b->prev = prev;
-    *next = head_b;
-    if (head_a == nullptr)
-      return head;
-  start_with_b:
-    x = head_a->cell;
-    while (head_b != nullptr && head_b->cell <= x) {
-      prev = head_b;
-      next = &head_b->next;
-      head_b = head_b->next;
-    }
-    head_a->prev = prev;
-    *next = head_a;
-    if (head_b == nullptr)
-      return head;
-  }
-}
-
-__device__ SeqEdge *seq_sort (SeqEdge *list, unsigned level, SeqEdge **head_out)
-{
-  SeqEdge *head_other = list->next, *remaining;
-  if (head_other == nullptr) {
-    *head_out = list;
-    return nullptr;
-  }
-  remaining = head_other->next;
-  if (list->cell <= head_other->cell) {
-    *head_out = list;
-    head_other->next = nullptr;
-  } else {
-    *head_out = head_other;
-    head_other->prev = list->prev;
-    head_other->next = list;
-    list->prev = head_other;
-    list->next = nullptr;
-  }
-  for (unsigned i = 0; i < level && remaining; i++) {
-    remaining = seq_sort (remaining, i, &head_other);
-    *head_out = seq_merge (*head_out, head_other);
-  }
-  return remaining;
-}
-
-__device__ inline void seq_cell_add (SeqState &t, int ix, int dcov, int dunc)
-{
-  const int k = pixel_index (ix, t.xmin, t.width);
-  t.cov[k] += dcov;
-  t.unc[k] += dunc;
-}
-
-__device__ void seq_render_edge (SeqState &t, SeqEdge *e, int sign)
-{
-  int32_t x1q = e->xq, x2q;
-  int64_t x1r = e->xr, x2r;
-  if (e->dy == 0) {
-    x2q = x1q;
-    x2r = x1r;
-  } else {
-    seq_step_full (e);
-    const int32_t hq = e->dq / 2;
-    const int64_t hr = e->dr / 2;
-    x1q -= hq;
-    x1r -= hr;
-    normalise (x1q, x1r, e->dy);
-    x2q = e->xq - hq;
-    x2r = e->xr - hr;
-    normalise (x2q, x2r, e->dy);
-  }
-  const int fx1 = x1q & 0xff, fx2 = x2q & 0xff;
-  const int ix1 = x1q >> 8, ix2 = x2q >> 8;
-  if (ix1 == ix2) {
-    seq_cell_add (t, ix1, sign * kGridY, sign * kGridY * (fx1 + fx2));
+  __syncthreads ();
+  if (!s_last)
     return;
-  }
-  int32_t loq = x2q, hiq = x1q;
-  int64_t lor = x2r, hir = x1r;
-  int ixlo = ix2, ixhi = ix1, fxlo = fx2, fxhi = fx1;
-  if (ix1 < ix2) {
-    loq = x1q; hiq = x2q; lor = x1r; hir = x2r;
-    ixlo = ix1; ixhi = ix2; fxlo = fx1; fxhi = fx2;
-  }
-  const int64_t D = e->dy;
-  const int64_t tx = (hir - lor) + (int64_t) (hiq - loq) * D;
-  int ix = ixlo + 1;
-  const int64_t a = (int64_t) (int32_t) ((uint32_t) ix << 8) * D - ((int64_t) loq * D + lor);
-  int64_t yq = (a * kGridY) / tx, yr = (a * kGridY) % tx;
-  {
-    const int h = (int) yq * sign;
-    seq_cell_add (t, ixlo, h, (fxlo + 256) * h);
-  }
-  int y = (int) yq;
-  if (ix < ixhi) {
-    const int64_t sq = (D * kGridY * 256) / tx, sr = (D * kGridY * 256) % tx;
-    do {
-      int y2 = (int) sq + y;
-      yr += sr;
-      if (yr >= tx) {
-        y2++;
-        yr -= tx;
-      }
-      const int h = (y2 - y) * sign;
-      seq_cell_add (t, ix, h, h * 256);
-      y = y2;
-      ix++;
-    } while (ix != ixhi);
-  }
-  {
-    const int h = sign * (kGridY - y);
-    seq_cell_add (t, ixhi, h, fxhi * h);
-  }
-}
-
-__device__ inline void seq_dec (SeqState &t, SeqEdge *e, int h)
-{
-  e->height_left -= h;
-  if (e->height_left == 0) {
-    e->prev->next = e->next;
-    e->next->prev = e->prev;
-    t.min_height = -1;
-  }
-}
-
-__device__ int seq_can_do_full_row (SeqState &t)
-{
-  if (t.min_height <= 0) {
-    int min_height = INT_MAX, is_vertical = 1;
-    for (SeqEdge *e = t.head.next; e != nullptr; e = e->next) {
-      if (e->height_left < min_height)
-        min_height = e->height_left;
-      is_vertical &= e->dy == 0;
+  if (tid == 0) {
+    __threadfence ();
+    status[2] = 0;
+    if (atomicOr (&status[0], 0u) & (kStatusTie | kStatusOverflow)) {
+      sequential_sweep (seq.in_edges, n_edges, xmin, ymin, xmax, ymax, even_odd, dst, dst_stride,
+          seq.sedges, seq.y_buckets, seq.cells);
+      status[0] = 0;
+      if (seq.counters)
+        seq.counters[0] += 1;
     }
-    t.is_vertical = is_vertical;
-    t.min_height = min_height;
-  }
-  if (t.min_height < kGridY)
-    return 0;
-  int prev_x = INT_MIN;
-  for (SeqEdge *e = t.head.next; e != &t.tail; e = e->next) {
-    int cell = e->cell;
-    if (e->dy) {
-      int32_t q = e->xq + e->fq;
-      int64_t r = e->xr + e->fr;
-      normalise (q, r, e->dy);
-      cell = q + (e->dy / 2 <= r);
-    }
-    if (cell < prev_x)
-      return 0;
-    prev_x = cell;
-  }
-  return 1;
-}
-
-__global__ void scan_sequential_kernel (const int32_t *__restrict__ in_edges, uint32_t n,
-    int xmin, int ymin, int xmax, int ymax, int even_odd, uint8_t *__restrict__ dst,
-    size_t dst_stride, uint32_t *__restrict__ status, int force, SeqEdge *__restrict__ sedges,
-    SeqEdge **__restrict__ y_buckets, int *__restrict__ cells, uint32_t *__restrict__ counters)
-{
-  if (threadIdx.x != 0 || blockIdx.x != 0)
-    return;
-  if (!force && (*status & (kStatusTie | kStatusOverflow)) == 0)
-    return;
-  const int h = ymax - ymin, width = xmax - xmin;
-  SeqState t = { sedges[n], sedges[n + 1], 0, 1, nullptr, nullptr, 0, 0 };
-  t.cov = cells;
-  t.unc = cells + (width + 2);
-  t.xmin = xmin;
-  t.width = width;
-  t.head.cell = INT_MIN;
-  t.head.height_left = INT_MAX;
-  t.head.next = &t.tail;
-  t.head.prev = nullptr;
-  t.head.dy = 0;
-  t.tail.prev = &t.head;
-  t.tail.next = nullptr;
-  t.tail.cell = INT_MAX;
-  t.tail.height_left = INT_MAX;
-  t.tail.dy = 0;
-  t.min_height = 0;
-  t.is_vertical = 1;
-  for (int i = 0; i < h; i++)
-    y_buckets[i] = nullptr;
-  for (uint32_t i = 0; i < n; i++) {
-    const int32_t *in = in_edges + (size_t) i * 7;
-    int ytop = (int) (((int64_t) in[4] * kGridY + 128) >> 8);
-    int ybot = (int) (((int64_t) in[5] * kGridY + 128) >> 8);
-    if (ytop < ymin * kGridY)
-      ytop = ymin * kGridY;
-    if (ybot > ymax * kGridY)
-      ybot = ymax * kGridY;
-    if (ybot <= ytop)
-      continue;
-    SeqEdge *e = &sedges[i];
-    e->ytop = ytop;
-    e->height_left = ybot - ytop;
-    int32_t p1x = in[0], p1y = in[1], p2x = in[2], p2y = in[3];
-    e->dir = in[6];
-    if (!(p2y > p1y)) {
-      int32_t s = p1x; p1x = p2x; p2x = s;
-      s = p1y; p1y = p2y; p2y = s;
-      e->dir = -e->dir;
-    }
-    if (p2x == p1x) {
-      e->cell = p2x;
-      e->xq = p1x;
-      e->xr = 0;
-      e->dq = 0; e->dr = 0; e->fq = 0; e->fr = 0;
-      e->dy = 0;
-    } else {
-      const int64_t dx = (int64_t) p2x - p1x;
-      const int64_t Dy = ((int64_t) p2y - p1y) * kGridY * 512;
-      const int64_t Ex = dx * 256;
-      e->dq = (int32_t) ((dx * 131072) / Dy);
-      e->dr = (dx * 131072) % Dy;
-      const int64_t num = ((int64_t) (2 * ytop + 1) * 256 - 2 * (int64_t) kGridY * p1y) * Ex;
-      e->xq = (int32_t) (num / Dy) + p1x;
-      e->xr = num % Dy;
-      normalise (e->xq, e->xr, Dy);
-      if (e->height_left >= kGridY) {
-        e->fq = (int32_t) ((Ex * kGridY * 512) / Dy);
-        e->fr = (Ex * kGridY * 512) % Dy;
-      } else {
-        e->fq = 0;
-        e->fr = 0;
-      }
-      e->dy = Dy;
-      e->cell = e->xq + (Dy / 2 <= e->xr);
-    }
-    SeqEdge **b = &y_buckets[(ytop - ymin * kGridY) / kGridY];
-    e->next = *b;
-    *b = e;
-  }
-
-  const unsigned mask = even_odd ? 1u : ~0u;
-  SeqEdge *buckets[kGridY];
-  for (int i = 0; i < kGridY; i++)
-    buckets[i] = nullptr;
-  int j;
-  for (int i = 0; i < h; i = j) {
-    int do_full_row = 0;
-    j = i + 1;
-    if (y_buckets[i]) {
-      int max_suby = 0;
-      const int row_top = (i + ymin) * kGridY;
-      for (SeqEdge *e = y_buckets[i], *nx; e; e = nx) {
-        nx = e->next;
-        const int suby = e->ytop - row_top;
-        if (buckets[suby])
-          buckets[suby]->prev = e;
-        e->next = buckets[suby];
-        e->prev = nullptr;
-        buckets[suby] = e;
-        if (e->height_left < t.min_height)
-          t.min_height = e->height_left;
-        t.is_vertical &= e->dy == 0;
-        if (suby > max_suby)
-          max_suby = suby;
-      }
-      if (max_suby == 0) {
-        if (buckets[0]) {
-          SeqEdge *sorted;
-          seq_sort (buckets[0], UINT_MAX, &sorted);
-          t.head.next = seq_merge (t.head.next, sorted);
-          buckets[0] = nullptr;
-        }
-        do_full_row = seq_can_do_full_row (t);
-      }
-    } else {
-      if (t.head.next == &t.tail) {
-        t.min_height = INT_MAX;
-        t.is_vertical = 1;
-        for (; j < h && !y_buckets[j]; j++)
-          ;
-        for (int r = i; r < j; r++)
-          for (int x = 0; x < width; x++)
-            dst[(size_t) r * dst_stride + x] = 0;
-        continue;
-      }
-      do_full_row = seq_can_do_full_row (t);
-    }
-    for (int k = 0; k < 2 * (width + 2); k++)
-      cells[k] = 0;
-    if (do_full_row) {
-      SeqEdge *left = t.head.next;
-      while (left != &t.tail) {
-        SeqEdge *right;
-        int winding;
-        seq_dec (t, left, kGridY);
-        winding = left->dir;
-        right = left->next;
-        for (;;) {
-          seq_dec (t, right, kGridY);
-          winding += right->dir;
-          if ((winding & mask) == 0 && right->next->cell != right->cell)
-            break;
-          seq_step_full (right);
-          right = right->next;
-        }
-        seq_render_edge (t, left, +1);
-        seq_render_edge (t, right, -1);
-        left = right->next;
-      }
-      if (t.is_vertical) {
-        while (j < h && y_buckets[j] == nullptr && t.min_height >= 2 * kGridY) {
-          t.min_height -= kGridY;
-          j++;
-        }
-        if (j != i + 1) {
-          const int count = (j - (i + 1)) * kGridY;
-          for (SeqEdge *e = t.head.next, *nx; e != &t.tail; e = nx) {
-            nx = e->next;
-            seq_dec (t, e, count);
-          }
-        }
-      }
-    } else {
-      for (int sub = 0; sub < kGridY; sub++) {
-        if (buckets[sub]) {
-          SeqEdge *sorted;
-          seq_sort (buckets[sub], UINT_MAX, &sorted);
-          t.head.next = seq_merge (t.head.next, sorted);
-          buckets[sub] = nullptr;
-        }
-        SeqEdge *e = t.head.next;
-        int xstart = INT_MIN, prev_x = INT_MIN, winding = 0;
-        while (e != &t.tail) {
-          SeqEdge *next = e->next;
-          const int xend = e->cell;
-          if (--e->height_left) {
-            if (e->dy) {
-              e->xq += e->dq;
-              e->xr += e->dr;
-              normalise (e->xq, e->xr, e->dy);
-              e->cell = e->xq + (e->dy / 2 <= e->xr);
-            }
-            if (e->cell < prev_x) {
-              SeqEdge *pos = e->prev;
-              pos->next = next;
-              next->prev = pos;
-              do
-                pos = pos->prev;
-              while (e->cell < pos->cell);
-              pos->next->prev = e;
-              e->next = pos->next;
-              e->prev = pos;
-              pos->next = e;
-            } else {
-              prev_x = e->cell;
-            }
-            t.min_height = -1;
-          } else {
-            e->prev->next = next;
-            next->prev = e->prev;
-          }
-          winding += e->dir;
-          if ((winding & mask) == 0) {
-            if (next->cell != xend) {
-              if (xend != xstart) {
-                seq_cell_add (t, xstart >> 8, 1, 2 * (xstart & 0xff));
-                seq_cell_add (t, xend >> 8, -1, -2 * (xend & 0xff));
-              }
-              xstart = INT_MIN;
-            }
-          } else if (xstart == INT_MIN) {
-            xstart = xend;
-          }
-          e = next;
-        }
-      }
-    }
-    {
-      int c = t.cov[0];
-      uint8_t *row = dst + (size_t) i * dst_stride;
-      for (int x = 0; x < width; x++) {
-        c += t.cov[x + 1];
-        const int16_t cover = (int16_t) (c * 512);
-        const int16_t area = (int16_t) (cover - (int16_t) t.unc[x + 1]);
-        const int v = (int) area;
-        row[x] = (uint8_t) ((v + (v << 4) + 256) >> 9);
-      }
-      for (int r = i + 1; r < j; r++)
-        for (int x = 0; x < width; x++)
-          dst[(size_t) r * dst_stride + x] = row[x];
-    }
-    t.min_height -= kGridY;
-  }
-  if (!force) {
-    status[0] = 0;
-    if (counters)
-      counters[0] += 1;         // polygons that took this way (statistics)
   }
 }
 
@@ -1474,11 +1496,9 @@ extern "C" void flutl_scan_set_debug (void *dev)
 
 extern "C" size_t flutl_scan_scratch_bytes (uint32_t n_edges, uint32_t width, uint32_t height)
 {
-  size_t b = 0;
+  size_t b = 256;                                     // status
   b += ((size_t) n_edges * sizeof (ScanEdge) + 255) & ~(size_t) 255;
   b += ((size_t) n_edges * sizeof (int2) + 255) & ~(size_t) 255;
-  b += ((size_t) height + 255) & ~(size_t) 255;
-  b += 256;                                           // status
   b += ((size_t) (n_edges + 2) * sizeof (SeqEdge) + 255) & ~(size_t) 255;
   b += ((size_t) height * sizeof (SeqEdge *) + 255) & ~(size_t) 255;
   b += ((size_t) 2 * (width + 2) * sizeof (int) + 255) & ~(size_t) 255;
@@ -1505,7 +1525,7 @@ extern "C" int flutl_launch_scan_counted (void *stream_, const int32_t *edges_de
   const int xmin = box[0], ymin = box[1], xmax = box[2], ymax = box[3];
   if (!dst || xmax <= xmin || ymax <= ymin || xmin < 0 || xmax > (1 << 22) || ymin < 0 ||
       ymax > (1 << 22) || (n_edges && (!edges_dev || !scratch)) ||
-      dst_stride < (size_t) (xmax - xmin) || mode < 0 || mode > 2)
+      dst_stride < (size_t) (xmax - xmin) || mode < 0 || (mode & 7) > 2 || mode > 31)
     return FLUTL_EINVAL;
   const uint32_t width = (uint32_t) (xmax - xmin), height = (uint32_t) (ymax - ymin);
   if (width > (uint32_t) kMaxWidth || height > 65535u || n_edges > (1u << 24))
@@ -1516,28 +1536,33 @@ extern "C" int flutl_launch_scan_counted (void *stream_, const int32_t *edges_de
     return FLUTL_OK;
   }
   uint8_t *p = static_cast<uint8_t *> (scratch);
+  uint32_t *status = reinterpret_cast<uint32_t *> (p);  // 0 flags, 2 rows done (last one resets)
+  p += 256;
   ScanEdge *prepared = reinterpret_cast<ScanEdge *> (p);
   p += ((size_t) n_edges * sizeof (ScanEdge) + 255) & ~(size_t) 255;
   int2 *spans = reinterpret_cast<int2 *> (p);
   p += ((size_t) n_edges * sizeof (int2) + 255) & ~(size_t) 255;
-  uint8_t *row_flags = p;
-  p += ((size_t) height + 255) & ~(size_t) 255;
-  uint32_t *status = reinterpret_cast<uint32_t *> (p);
-  p += 256;
-  SeqEdge *sedges = reinterpret_cast<SeqEdge *> (p);
+  SeqArgs seq;
+  seq.in_edges = edges_dev;
+  seq.sedges = reinterpret_cast<SeqEdge *> (p);
   p += ((size_t) (n_edges + 2) * sizeof (SeqEdge) + 255) & ~(size_t) 255;
-  SeqEdge **y_buckets = reinterpret_cast<SeqEdge **> (p);
+  seq.y_buckets = reinterpret_cast<SeqEdge **> (p);
   p += ((size_t) height * sizeof (SeqEdge *) + 255) & ~(size_t) 255;
-  int *cells = reinterpret_cast<int *> (p);
-  // row flags and the status word, cleared in stream order
-  if (hipMemsetAsync (row_flags, 0, (size_t) (reinterpret_cast<uint8_t *> (status) + 4 - row_flags),
-          stream) != hipSuccess)
-    return FLUTL_ENODEV;
+  seq.cells = reinterpret_cast<int *> (p);
+  seq.counters = counters_dev;
+  // (library internal, flutl_atlas_put_polygon: 8 = the MASK layout's zero bytes are the
+  // rows' to write, 16 = the scratch's first 16 bytes are zero -- made so once, and left so
+  // by every conversion)
+  const int pad_zero = mode & 8 ? 1 : 0, clean = mode & 16 ? 1 : 0;
+  mode &= 7;
   if (mode != 2) {
+    // (the "rows done" counter must start at zero: a scratch buffer of unknown content)
+    if (!clean && hipMemsetAsync (status, 0, 16, stream) != hipSuccess)
+      return FLUTL_ENODEV;
     scan_prepare_kernel<<<(n_edges + 255) / 256, 256, 0, stream>>> (edges_dev, n_edges, ymin, ymax,
-        prepared, row_flags, spans);
+        prepared, spans, status);
     // LDS: the accumulators by the box width; a region that holds the sort keys of an
-    // eligible row's order and then the pixel histogram of the sample rows
+    // eligible row's order and then the bins of the sample rows
     const size_t fixed = row_shared_fixed_bytes ((int) width);
     size_t keys = (size_t) kMaxActive * sizeof (uint32_t) + 2 * kBins * sizeof (int);
     if (keys < (size_t) kMaxActive * sizeof (uint64_t))
@@ -1545,14 +1570,13 @@ extern "C" int flutl_launch_scan_counted (void *stream_, const int32_t *edges_de
     const size_t lds = fixed + keys;
     if (lds > 65536)
       return FLUTL_ERANGE;
-    scan_rows_kernel<<<height, kThreads, lds, stream>>> (prepared, spans, n_edges, row_flags, xmin, ymin,
+    scan_rows_kernel<<<height, kThreads, lds, stream>>> (prepared, spans, n_edges, xmin, ymin,
         xmax, ymax, even_odd, static_cast<uint8_t *> (dst), dst_stride, status, (int) lds,
-        g_scan_debug);
-  }
-  if (mode != 1)
+        g_scan_debug, pad_zero, mode == 0, seq);
+  } else {
     scan_sequential_kernel<<<1, 64, 0, stream>>> (edges_dev, n_edges, xmin, ymin, xmax, ymax,
-        even_odd, static_cast<uint8_t *> (dst), dst_stride, status, mode == 2, sedges, y_buckets,
-        cells, counters_dev);
+        even_odd, static_cast<uint8_t *> (dst), dst_stride, seq.sedges, seq.y_buckets, seq.cells);
+  }
   return hipGetLastError () == hipSuccess ? FLUTL_OK : FLUTL_ENODEV;
 }
 
@@ -1561,9 +1585,8 @@ extern "C" int flutl_scan_status (void *stream_, const void *scratch, uint32_t n
 {
   hipStream_t stream = static_cast<hipStream_t> (stream_);
   const uint8_t *p = static_cast<const uint8_t *> (scratch);
-  p += ((size_t) n_edges * sizeof (ScanEdge) + 255) & ~(size_t) 255;
-  p += ((size_t) n_edges * sizeof (int2) + 255) & ~(size_t) 255;
-  p += ((size_t) height + 255) & ~(size_t) 255;
+  (void) n_edges;
+  (void) height;
   if (hipMemcpyAsync (status_out, p, sizeof (uint32_t), hipMemcpyDeviceToHost, stream) != hipSuccess ||
       hipStreamSynchronize (stream) != hipSuccess)
     return FLUTL_ENODEV;

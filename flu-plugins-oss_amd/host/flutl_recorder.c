@@ -2721,6 +2721,41 @@ ops_to_mask (FlutlRecorder *rec, int fill)
     g_rec_mutex_lock (lk);
     e = &rec->strokes[idx];     /* (only this thread adds entries: it has not moved) */
     stroke_defer_commit (rec, e, &rb, j);
+  } else if (is_new && !fill && root_of (rec)->device_strokes) {
+    /* not deferred (no pipeline: FLUTL_SYNC, the request-pad mode, a blurred outline's
+     * temporary surface), but the device still makes the mask: the stroke's polygon right
+     * here -- a tenth of what Cairo's rasteriser would take on this thread */
+    const uint32_t idx = (uint32_t) (e - rec->strokes);
+    RasterBox rb;
+    int exact;
+    g_rec_mutex_unlock (lk);
+    StrokeJob *j = stroke_defer_prepare (rec, &rb, &exact);
+    const int made = j && stroke_job_polygon (j);
+    g_rec_mutex_lock (lk);
+    e = &rec->strokes[idx];
+    if (j && !made) {
+      /* a stroke the stroker does not take: Cairo draws it (the ops are still pending) */
+      stroke_job_unref (j);
+      stroke_job_unref (j);
+      e->translatable = stroke_rasterise (rec, e, fill);
+    } else {
+      e->w = e->h = 0;
+      memcpy (e->ext, j ? j->rb.ext : rb.ext, sizeof e->ext);
+      e->translatable = j ? j->rb.inside : rb.inside;
+      memcpy (e->lim, rb.lim, sizeof e->lim);
+      if (j && j->poly) {
+        e->x = j->x;
+        e->y = j->y;
+        e->w = j->w;
+        e->h = j->h;
+        e->offset = atlas_reserve_polygon (rec, j->poly) + MASK_PAD;
+        j->poly = NULL;
+      }
+      if (j) {
+        stroke_job_unref (j);   /* (made with two references: the entry's and a worker's) */
+        stroke_job_unref (j);
+      }
+    }
   } else if (is_new) {
     e->translatable = stroke_rasterise (rec, e, fill);
   }
