@@ -34,7 +34,8 @@ def measure(ttml, W, H, extra_env=None, log_path=None, sink="fakesink"):
            f"location={os.path.abspath(ttml)}", "!", "ttmlrender", "!",
            f"video/x-raw,width={W},height={H}", "!"] + sink.split()
     t0 = time.perf_counter()
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=tempfile.gettempdir())
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=tempfile.gettempdir(),
+                       timeout=300)
     wall = time.perf_counter() - t0
     lines = [l for l in r.stderr.split("\n") if "ttmlrender-hip timing" in l]
     if log_path:
@@ -76,7 +77,9 @@ def measure_streams(ttml, W, H, n, extra_env=None, log_path=None):
     for _ in range(n):
         cmd += ["filesrc", f"location={os.path.abspath(ttml)}", "!", "ttmlrender", "!",
                 f"video/x-raw,width={W},height={H}", "!", "fakesink"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=tempfile.gettempdir())
+    # (a pipeline that hangs must not hang the bench: 5 minutes is 100 times what it takes)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=tempfile.gettempdir(),
+                       timeout=300)
     lines = [l for l in r.stderr.split("\n") if "ttmlrender-hip timing" in l and "buffers=0 " not in l]
     if log_path:
         with open(log_path, "a") as f:

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """GPU box, under rocprofv3 --kernel-trace --stats: the polygon scan converter on one
-polygon (argv[1]: 'big' = the synthetic 4K line of tools/scan_timing.py, or an index into
+polygon (argv[1]: 'bench' = bench_data/outline_4k.npz, 'big' = the synthetic 4K line of
+tools/scan_timing.py, or an index into
 tests/golden/polygons.npz), 50 conversions."""
 import os
 import sys
@@ -15,7 +16,11 @@ import pyflutl as F  # noqa: E402
 z = np.load(os.path.join(ROOT, "tests", "golden", "polygons.npz"))
 meta = z["meta"]
 which = sys.argv[1] if len(sys.argv) > 1 else "big"
-if which == "big":
+if which == "bench":
+    # the outline bench.py's outline_scan block converts (a cue of a typical 4K stream)
+    b = np.load(os.path.join(ROOT, "bench_data", "outline_4k.npz"))
+    edges, box = b["edges0"], tuple(int(v) for v in b["meta"][0][1:5])
+elif which == "big":
     text = [i for i in range(len(meta)) if meta[i][0] == 2]
     parts, x = [], 0
     for i in text:
