@@ -26,6 +26,11 @@ inline bool hip_ok (hipError_t e) { return e == hipSuccess; }
 
 }  // namespace
 
+// (csrc/flutl_scan.hip; library internal: flutl_launch_scan with the statistics counter)
+extern "C" int flutl_launch_scan_counted (void *stream_, const int32_t *edges_dev, uint32_t n_edges,
+    const int32_t box[4], int even_odd, void *scratch, void *dst, size_t dst_stride, int mode,
+    uint32_t *counters_dev);
+
 struct flutl_list {
   uint32_t width, height;
   uint32_t n_regions, n_prims;
@@ -302,6 +307,18 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
     (void) hipMemsetAsync (c->scan_counters, 0, 4 * sizeof (uint32_t), c->stream);
   else
     c->scan_counters = nullptr;
+  if (c->scan) {
+    // (the runtime loads a kernel's code when it is first launched, a millisecond each:
+    // a triangle through the converter now, not with the first cue's outlines)
+    static const int32_t tri[21] = { 256, 256, 256, 1536, 256, 1536, 1,
+      256, 256, 1536, 1536, 256, 1536, -1, 0, 0, 0, 0, 0, 0, 0 };
+    const int32_t box[4] = { 1, 1, 7, 7 };
+    uint8_t *base = static_cast<uint8_t *> (c->scan);
+    const size_t own = flutl_scan_scratch_bytes (2, 6, 6);
+    if (hip_ok (hipMemcpyAsync (base + own, tri, sizeof tri, hipMemcpyHostToDevice, c->stream)))
+      (void) flutl_launch_scan_counted (c->stream, reinterpret_cast<const int32_t *> (base + own), 2,
+          box, 0, base, base + own + 256, 16, 0 | 16, nullptr);
+  }
   (void) hipStreamSynchronize (c->stream);
   *out = c;
   return FLUTL_OK;
@@ -432,10 +449,6 @@ extern "C" int flutl_atlas_put (flutl_ctx *c, const void *src, size_t bytes,
 
 static int upload_list (flutl_ctx *c, const flutl_region *regions, uint32_t n_regions,
     const flutl_prim *prims, uint32_t n_prims, flutl_region **rd, flutl_prim **pd);
-
-extern "C" int flutl_launch_scan_counted (void *stream_, const int32_t *edges_dev, uint32_t n_edges,
-    const int32_t box[4], int even_odd, void *scratch, void *dst, size_t dst_stride, int mode,
-    uint32_t *counters_dev);
 
 extern "C" size_t flutl_polygon_entry_bytes (uint32_t w, uint32_t h)
 {
