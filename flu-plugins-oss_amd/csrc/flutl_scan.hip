@@ -62,8 +62,23 @@ struct ScanEdge {
   int32_t pad;
 };
 
+// q = floor (a / d), r = a - q * d, for d > 0.  Where a fits a double's mantissa the quotient is
+// estimated in floating point (off by one at most) and settled in integers: a 64-bit integer
+// division is a hundred instructions and more here.
 __device__ inline void floor_divmod (int64_t a, int64_t d, int64_t &q, int64_t &r)
 {
+  if (a > -(1ll << 51) && a < (1ll << 51) && d < (1ll << 51)) {
+    q = (int64_t) floor ((double) a / (double) d);
+    r = a - q * d;
+    if (r < 0) {
+      q--;
+      r += d;
+    } else if (r >= d) {
+      q++;
+      r -= d;
+    }
+    return;
+  }
   q = a / d;
   r = a % d;
   if (r < 0) {
@@ -213,7 +228,7 @@ struct RowShared {
   int *unc;             // [width + 2] uncovered_area per pixel
   uint32_t *idx;        // [kMaxActive] slot -> edge index
   int8_t *dir;          // [kMaxActive] slot -> winding direction
-  int *part;            // [kThreads]
+  int *part;            // [16] the waves' totals of a workgroup prefix sum (16-byte aligned)
   int *sc;              // scalars: 0 n, 1 flag, 2 result, 4.. scratch of the tie rules
   uint64_t *key;        // sort keys of the row-start order (cell, edge index): [npad]; then
                         // the bins of the sample rows (the same memory)
@@ -223,7 +238,7 @@ struct RowShared {
 __host__ __device__ inline size_t row_shared_fixed_bytes (int width)
 {
   return (size_t) (width + 2) * sizeof (int) + (size_t) ((width + 3) / 2) * sizeof (int) +
-      kMaxActive * sizeof (uint32_t) + kMaxActive + kThreads * sizeof (int) + 16 * sizeof (int);
+      kMaxActive * sizeof (uint32_t) + kMaxActive + 16 * sizeof (int) + 16 * sizeof (int);
 }
 
 // covered heights are small (|sum| <= 15 * kMaxActive < 2^15): two to a 32-bit word, added to
@@ -1007,29 +1022,46 @@ __global__ void scan_sequential_kernel (const int32_t *__restrict__ in_edges, ui
 }
 
 // ---- wave-level helpers ------------------------------------------------------------------------
+// Inclusive prefix sum over the wave's 64 lanes on the DPP path (no LDS round trips):
+// shifts by 1, 2, 4, 8 within each row of 16 lanes (a lane without a source adds 0), then
+// lane 15 of a row added to the next row (rows 1 and 3), then lane 31 to rows 2 and 3.
 __device__ inline int wave_inclusive_scan (int v, int lane)
 {
-  for (int off = 1; off < 64; off <<= 1) {
-    const int u = __shfl_up (v, off, 64);
-    if (lane >= off)
-      v += u;
-  }
+  (void) lane;
+  v += __builtin_amdgcn_update_dpp (0, v, 0x111, 0xf, 0xf, true);     // row_shr:1
+  v += __builtin_amdgcn_update_dpp (0, v, 0x112, 0xf, 0xf, true);     // row_shr:2
+  v += __builtin_amdgcn_update_dpp (0, v, 0x114, 0xf, 0xf, true);     // row_shr:4
+  v += __builtin_amdgcn_update_dpp (0, v, 0x118, 0xf, 0xf, true);     // row_shr:8
+  v += __builtin_amdgcn_update_dpp (0, v, 0x142, 0xa, 0xf, false);    // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp (0, v, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2, 3
   return v;
 }
 
-// exclusive prefix sum of v over the workgroup's 256 threads (part: 4 words of LDS)
-__device__ inline int block_exclusive_scan (int v, int tid, int *part)
+// exclusive prefix sum of v over the workgroup's 1024 threads (part: 16 words of LDS, 16-byte
+// aligned).  `part` may be written again only behind a barrier of the caller's.
+__device__ inline int block_exclusive_scan_open (int v, int tid, int *part)
 {
   const int lane = tid & 63, wave = tid >> 6;
   const int incl = wave_inclusive_scan (v, lane);
   if (lane == 63)
     part[wave] = incl;
   __syncthreads ();
+  // the 16 waves' totals: four wide reads in flight together, summed below this wave
+  const int4 *p4 = reinterpret_cast<const int4 *> (part);
+  const int4 a = p4[0], b = p4[1], c = p4[2], d = p4[3];
+  const int t[16] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w };
   int base = 0;
-  for (int w = 0; w < wave; w++)
-    base += part[w];
-  __syncthreads ();
+#pragma unroll
+  for (int w = 0; w < 16; w++)
+    base += w < wave ? t[w] : 0;
   return base + incl - v;
+}
+
+__device__ inline int block_exclusive_scan (int v, int tid, int *part)
+{
+  const int r = block_exclusive_scan_open (v, tid, part);
+  __syncthreads ();
+  return r;
 }
 
 
@@ -1054,7 +1086,11 @@ scan_row (const ScanEdge *__restrict__ edges, const int2 *__restrict__ spans,
   RowShared S;
   {
     uint8_t *p = lds;
-    S.key = reinterpret_cast<uint64_t *> (p);           // (first: 16-byte aligned)
+    S.part = reinterpret_cast<int *> (p);               // (first: 16-byte aligned)
+    p += 16 * sizeof (int);
+    S.sc = reinterpret_cast<int *> (p);
+    p += 16 * sizeof (int);
+    S.key = reinterpret_cast<uint64_t *> (p);
     S.key_bytes = lds_bytes - (int) row_shared_fixed_bytes (width);
     p += S.key_bytes;
     S.cov = reinterpret_cast<int *> (p);
@@ -1063,10 +1099,6 @@ scan_row (const ScanEdge *__restrict__ edges, const int2 *__restrict__ spans,
     p += (size_t) (width + 2) * sizeof (int);
     S.idx = reinterpret_cast<uint32_t *> (p);
     p += kMaxActive * sizeof (uint32_t);
-    S.part = reinterpret_cast<int *> (p);
-    p += kThreads * sizeof (int);
-    S.sc = reinterpret_cast<int *> (p);
-    p += 16 * sizeof (int);
     S.dir = reinterpret_cast<int8_t *> (p);
   }
 
@@ -1092,13 +1124,23 @@ scan_row (const ScanEdge *__restrict__ edges, const int2 *__restrict__ spans,
       tb[u] = i < n_edges ? spans[i] : make_int2 (INT_MAX, INT_MIN);
     }
 #pragma unroll
-    for (int u = 0; u < 8; u++)
-      if (tb[u].x < s1 && tb[u].y > s0) {
-        const int k = atomicAdd (&S.sc[0], 1);
-        if (k < kMaxActive)
-          S.idx[k] = base + u * kThreads + tid;
-        inside |= tb[u].x > s0 || tb[u].y < s1;
+    for (int u = 0; u < 8; u++) {
+      // (one atomic per wave: its first lane takes places for all of the wave's edges)
+      const bool hit = tb[u].x < s1 && tb[u].y > s0;
+      const uint64_t hits = __ballot (hit);
+      if (hits) {
+        int k0 = 0;
+        if ((tid & 63) == 0)
+          k0 = atomicAdd (&S.sc[0], __popcll (hits));
+        k0 = __shfl (k0, 0, 64);
+        if (hit) {
+          const int k = k0 + __popcll (hits & ((1ull << (tid & 63)) - 1ull));
+          if (k < kMaxActive)
+            S.idx[k] = base + u * kThreads + tid;
+          inside |= tb[u].x > s0 || tb[u].y < s1;
+        }
       }
+    }
   }
   if (inside)
     S.sc[13] = 1;
@@ -1336,7 +1378,7 @@ scan_row (const ScanEdge *__restrict__ edges, const int2 *__restrict__ spans,
           v[k] = bin_a[tid * kPer + k];         // (edges + 65536 * winding: one exact integer)
           sum += v[k];
         }
-        int before = block_exclusive_scan (sum, tid, S.part);
+        int before = block_exclusive_scan_open (sum, tid, S.part);
 #pragma unroll
         for (int k = 0; k < kPer; k++) {
           if (v[k]) {
@@ -1349,14 +1391,18 @@ scan_row (const ScanEdge *__restrict__ edges, const int2 *__restrict__ spans,
       }
       __syncthreads ();
       DBG_PHASE (1);
+      int wordj[kSlots], countj[kSlots];
 #pragma unroll
       for (int j = 0; j < kSlots; j++) {
+        wordj[j] = countj[j] = 0;
         if (cellj[j] == INT_MIN)
           continue;
         const int b = ((cellj[j] >> 8) - range0) >> shift;
         const int in_bin = cellj[j] - ((range0 + (b << shift)) << 8);     // (< 16 pixels * 256)
         const uint32_t slot = (uint32_t) (tid + j * kThreads);
-        seg[(bin_b[b] & 0xfff) + posj[j]] = ((uint32_t) in_bin << 12) |
+        wordj[j] = bin_b[b];
+        countj[j] = (int) (int16_t) (bin_a[b] & 0xffff);
+        seg[(wordj[j] & 0xfff) + posj[j]] = ((uint32_t) in_bin << 12) |
             (S.dir[slot] > 0 ? 0x800u : 0u) | slot;
       }
       __syncthreads ();
@@ -1369,21 +1415,32 @@ scan_row (const ScanEdge *__restrict__ edges, const int2 *__restrict__ spans,
         const int b = (px - range0) >> shift;
         const uint32_t slot = (uint32_t) (tid + j * kThreads);
         const uint32_t mine = (uint32_t) (cellj[j] - ((range0 + (b << shift)) << 8));
-        const int word = bin_b[b];
-        const int place = word & 0xfff, count = (int) (int16_t) (bin_a[b] & 0xffff);
-        int wb = word >> 12, wa = wb;   // (place < 4096: exact)
+        // (nobody reads the bins' counts any more: clear for the next sample row)
+        bin_a[b] = 0;
+        const int place = wordj[j] & 0xfff, count = countj[j];
+        int wb = wordj[j] >> 12, wa = wb;   // (place < 4096: exact)
         uint32_t first = slot;          // the lowest slot among the edges of my cell speaks
-        for (int k = 0; k < count; k++) {
-          const uint32_t o = seg[place + k];
-          const uint32_t oc = o >> 12;
-          const int od = (o & 0x800u) ? 1 : -1;
-          if (oc < mine) {
-            wb += od;
-            wa += od;
-          } else if (oc == mine) {
-            wa += od;
-            if ((o & 0x7ff) < first)
-              first = o & 0x7ff;
+        // four reads in flight at a time (a read past the bin's end repeats its last edge and
+        // is not counted)
+        for (int k = 0; k < count; k += 4) {
+          uint32_t o[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            o[u] = seg[place + (k + u < count ? k + u : count - 1)];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            if (k + u >= count)
+              break;
+            const uint32_t oc = o[u] >> 12;
+            const int od = (o[u] & 0x800u) ? 1 : -1;
+            if (oc < mine) {
+              wb += od;
+              wa += od;
+            } else if (oc == mine) {
+              wa += od;
+              if ((o[u] & 0x7ff) < first)
+                first = o[u] & 0x7ff;
+            }
           }
         }
         if (first == slot) {
@@ -1394,13 +1451,6 @@ scan_row (const ScanEdge *__restrict__ edges, const int2 *__restrict__ spans,
           }
         }
       }
-      __syncthreads ();
-      DBG_PHASE (3);
-      // leave the bins clear for the next sample row
-#pragma unroll
-      for (int j = 0; j < kSlots; j++)
-        if (cellj[j] != INT_MIN)
-          bin_a[((cellj[j] >> 8) - range0) >> shift] = 0;
       if (tid == 0) {
         // a span that is open at the box's left side: one sample row in the catch-all
         if ((left_w & mask) != 0)
@@ -1408,6 +1458,7 @@ scan_row (const ScanEdge *__restrict__ edges, const int2 *__restrict__ spans,
         S.sc[10] = 0;
       }
       __syncthreads ();
+      DBG_PHASE (3);
     }
   }
 
