@@ -37,6 +37,8 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
+#include <atomic>
+
 #include "flutl.h"
 
 namespace {
@@ -46,7 +48,8 @@ constexpr int kThreads = 1024;
 constexpr int kMaxActive = 2048;        // edges crossing one pixel row
 constexpr int kMaxWidth = 4096;         // box width (accumulators live in LDS)
 constexpr int kBins = 2048;             // bins a row's pixels are cut into (sample-row path)
-constexpr int kMaxBucket = 32;          // edges starting on one sample row with one cell history
+constexpr int kMaxBucket = 32;
+constexpr size_t kLdsPerWorkgroup = 160 * 1024;    // gfx950: a workgroup may have all of a CU's LDS          // edges starting on one sample row with one cell history
 
 // status bits (device word)
 constexpr uint32_t kStatusTie = 1u;        // a tie the rules could not decide
@@ -1065,14 +1068,235 @@ __device__ inline int block_exclusive_scan (int v, int tid, int *part)
 }
 
 
+
+// ---- a pixel row's 15 sample rows, all at once (rows of up to kThreads edges) -----------------
+// What Cairo's sorted walk over a sample row yields depends on the order of cells only through
+// the winding before and after each group of equal cells -- so nothing is sorted.  A sample
+// row's pixels are cut into kBinsT bins (one pixel each where they suffice); every (edge,
+// sample row) counts itself and its direction into its bin (one LDS atomic, which also tells
+// it its place there); ONE prefix sum over the 15 x kBinsT bins gives every bin the winding
+// before it and where its entries go; the entries are laid out bin by bin; and then the
+// ENTRIES are dealt out to the threads afresh, each reading the entries of its own bin side
+// by side for the winding before and after its cell.  (Dealt out afresh: at the tips of
+// glyphs a pen fan puts two dozen edges into one pixel, on every sample row; they are
+// neighbours in the edge list, so by edges one wave would do all that work, 15 times over,
+// with the other 15 waiting at the barrier.)  Cells beyond the box's sides: left, only whether
+// the winding enters the box non-zero matters (one covered sample row in the catch-all pixel);
+// right, nothing.
+constexpr int kBinsT = 1024;
+constexpr int kTogetherWords = kGridY * kBinsT + 32 + kGridY * kThreads;   // bins, aux, entries
+
+__device__ __forceinline__ void
+sample_rows_together (RowShared &S, const ScanEdge *__restrict__ edges, int n, int s0, int xmin,
+    int xmax, unsigned mask, int tid, bool debug, uint32_t *dbg_ph, uint64_t &dbg_t)
+{
+#define DBG_PHASE_T(k) do { if (debug) { const uint64_t now_ = wall_clock64 (); dbg_ph[k] += (uint32_t) (now_ - dbg_t); dbg_t = now_; } } while (0)
+  int *bins = reinterpret_cast<int *> (S.key);          // [15 * kBinsT + 1] entries | winding << 16,
+                                                        // then: first place | winding before << 16
+  int *leftw = bins + kGridY * kBinsT + 1;              // [15] winding of the edges left of the box
+  int *rowbase = leftw + kGridY;                        // [15] the prefix sum at a sample row's start
+  uint32_t *seg = reinterpret_cast<uint32_t *> (bins + kGridY * kBinsT + 32);   // [15 * kThreads] by
+                                                        // bin: cell in the bin << 16 | direction (two bits, signed) << 14 | bin
+  const int width = xmax - xmin, s1 = s0 + kGridY;
+  const int lo_cell = (xmin - 1) * 256, hi_cell = (xmax + 1) * 256 - 1;
+  if (tid == 0) {
+    S.sc[8] = INT_MAX;          // the pixels the row's edges stay within
+    S.sc[9] = INT_MIN;
+  }
+#pragma unroll
+  for (int k = 0; k < kGridY; k++)
+    bins[k * kThreads + tid] = 0;
+  if (tid < 32)
+    bins[kGridY * kBinsT + tid] = 0;
+  __syncthreads ();
+  // this thread's edge: x at its first sample row in this pixel row, then Cairo's steps
+  int32_t eq = 0, edq = 0;
+  int64_t er = 0, edr = 0, eD = 0;
+  int esa = 0, esb = 0, dir = 0;
+  if (tid < n) {
+    const ScanEdge e = edges[S.idx[tid]];
+    esa = e.ytop > s0 ? e.ytop : s0;
+    esb = e.ybot < s1 ? e.ybot : s1;
+    dir = e.dir;
+    edge_x_at (e, esa, eq, er);
+    edq = e.dq;
+    edr = e.dr;
+    eD = e.D;
+    // (an edge is a straight line: every step advances it by dq plus a fraction in (-1, 1))
+    const int ca = cell_of (eq, er, eD);
+    const int steps = esb - esa - 1;
+    const int far = ca + steps * e.dq;
+    const int c0 = (ca < far - steps ? ca : far - steps) - 2;
+    const int c1 = (ca > far + steps ? ca : far + steps) + 2;
+    const int k0 = ((c0 < lo_cell ? lo_cell : (c0 > hi_cell ? hi_cell : c0)) - lo_cell) >> 8;
+    const int k1 = ((c1 < lo_cell ? lo_cell : (c1 > hi_cell ? hi_cell : c1)) - lo_cell) >> 8;
+    atomicMin (&S.sc[8], k0);
+    atomicMax (&S.sc[9], k1);
+  }
+  __syncthreads ();
+  // bins of 1 << shift pixels over [range0, range1)
+  const int range0 = S.sc[8] < 1 ? 1 : S.sc[8];
+  const int range1 = S.sc[9] + 1;
+  int shift = 0;
+  while (((range1 - range0 + (1 << shift) - 1) >> shift) > kBinsT)
+    shift++;
+  DBG_PHASE_T (4);
+  // count: rec = cell (from lo_cell) * 1024 + place in the bin; -1: not in a bin
+  int rec[kGridY];
+#pragma unroll
+  for (int k = 0; k < kGridY; k++) {
+    const int s = s0 + k;
+    rec[k] = -1;
+    if (s >= esa && s < esb) {
+      int cell = cell_of (eq, er, eD);
+      cell = cell < lo_cell ? lo_cell : (cell > hi_cell ? hi_cell : cell);
+      cell -= lo_cell;
+      const int px = cell >> 8;
+      if (px == 0) {
+        atomicAdd (&leftw[k], dir);
+      } else if (px <= width) {
+        const int old = atomicAdd (&bins[k * kBinsT + ((px - range0) >> shift)], dir * 65536 + 1);
+        rec[k] = cell * 1024 + (old & 0xffff);
+      }
+      if (eD) {
+        eq += edq;
+        er += edr;
+        normalise (eq, er, eD);
+      }
+    }
+  }
+  __syncthreads ();
+  DBG_PHASE_T (0);
+  // one prefix sum over all bins (entries + 65536 * winding: one exact integer, entries below
+  // 65536 in all): where a bin's entries go, and -- less what the sample row began with --
+  // the winding before it
+  {
+    int v[kGridY], sum = 0;
+#pragma unroll
+    for (int k = 0; k < kGridY; k++) {
+      v[k] = bins[tid * kGridY + k];
+      sum += v[k];
+    }
+    int before = block_exclusive_scan_open (sum, tid, S.part);
+#pragma unroll
+    for (int k = 0; k < kGridY; k++) {
+      const int i = tid * kGridY + k;
+      if ((i & (kBinsT - 1)) == 0)
+        rowbase[i / kBinsT] = before;
+      bins[i] = before;
+      before += v[k];
+    }
+    if (tid == kThreads - 1)
+      bins[kGridY * kBinsT] = before;
+  }
+  __syncthreads ();
+  DBG_PHASE_T (1);
+#pragma unroll
+  for (int k = 0; k < kGridY; k++) {
+    if (rec[k] < 0)
+      continue;
+    const int cell = rec[k] >> 10, pos = rec[k] & 1023;
+    const int b = ((cell >> 8) - range0) >> shift;
+    const int in_bin = cell - ((range0 + (b << shift)) << 8);   // (< 8 pixels * 256)
+    const int lin = k * kBinsT + b;
+    seg[(bins[lin] & 0xffff) + pos] = ((uint32_t) in_bin << 16) | (dir > 0 ? 0x4000u : 0xc000u) | (uint32_t) lin;
+  }
+  __syncthreads ();
+  DBG_PHASE_T (2);
+  {
+    // Entries are taken 64 at a time by whichever wave is free: a bin's entries lie side by
+    // side, so a crowded bin costs the wave that meets it (a wave's time per 64 entries is
+    // that of their most crowded bin), and dealt out in turn the waves' sums differ by 2-3x.
+    const int total = bins[kGridY * kBinsT] & 0xffff;
+    int *next_chunk = bins + kGridY * kBinsT + 31;
+    for (;;) {
+      int chunk = 0;
+      if ((tid & 63) == 0)
+        chunk = atomicAdd (next_chunk, 1);
+      chunk = __builtin_amdgcn_readfirstlane (chunk);
+      if (chunk * 64 >= total)
+        break;
+      const int i = chunk * 64 + (tid & 63);
+      if (i >= total)
+        continue;
+      const uint32_t me = seg[i];
+      const int lin = (int) (me & 0x3fffu);
+      const uint32_t mine = me >> 16;
+      const int k = lin / kBinsT, b = lin & (kBinsT - 1);
+      const int P = bins[lin], Pn = bins[lin + 1], R = rowbase[k];
+      const int place = P & 0xffff, count = (Pn & 0xffff) - place;
+      int wb = ((P - place) >> 16) - ((R - (R & 0xffff)) >> 16) + leftw[k];
+      int wa = wb;
+      // an entry's word orders by its cell first: "cell below mine" and "cell up to mine" are
+      // one comparison each; its direction is a signed two-bit field
+      const uint32_t below = mine << 16, upto = below + 65536u;
+      const int rank = i - place;
+      bool speaker = true;      // the first entry of a cell speaks for it
+      int c = 0;
+      // four reads in flight at a time
+      for (; c + 4 <= count; c += 4) {
+        uint32_t o[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          o[u] = seg[place + c + u];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int od = ((int) (o[u] << 16)) >> 30;
+          const bool lt = o[u] < below, le = o[u] < upto;
+          wb += lt ? od : 0;
+          wa += le ? od : 0;
+          if (le && !lt && c + u < rank)
+            speaker = false;
+        }
+      }
+      if (c < count) {
+        uint32_t o[3];
+#pragma unroll
+        for (int u = 0; u < 3; u++)
+          o[u] = seg[place + (c + u < count ? c + u : count - 1)];
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+          const int od = c + u < count ? ((int) (o[u] << 16)) >> 30 : 0;
+          const bool lt = o[u] < below, le = o[u] < upto;
+          wb += lt ? od : 0;
+          wa += le ? od : 0;
+          if (le && !lt && c + u < rank)
+            speaker = false;
+        }
+      }
+      if (speaker) {
+        const bool start = (wb & mask) == 0, end = (wa & mask) == 0;
+        if (start != end) {
+          const int px = range0 + (b << shift) + (int) (mine >> 8), fx = (int) (mine & 0xff);
+          atomicAdd (&S.unc[px], start ? 2 * fx : -2 * fx);
+          cov_add (S.cov, px, start ? 1 : -1);
+        }
+      }
+    }
+    // a span that is open at the box's left side: one sample row in the catch-all
+    if (tid < kGridY && (leftw[tid] & mask) != 0)
+      cov_add (S.cov, 0, 1);
+  }
+  __syncthreads ();
+  DBG_PHASE_T (3);
+#undef DBG_PHASE_T
+}
+
 // ---- one pixel row per workgroup ---------------------------------------------------------------
+constexpr size_t kRowKeyBytes = (size_t) kTogetherWords * sizeof (int);
+constexpr size_t kRowLdsBytes = ((size_t) (kMaxWidth + 2) * sizeof (int) + (size_t) ((kMaxWidth + 3) / 2) * sizeof (int) +
+    kMaxActive * sizeof (uint32_t) + kMaxActive + 32 * sizeof (int) + kRowKeyBytes + 15) & ~(size_t) 15;
+static_assert (kRowLdsBytes + 1024 <= kLdsPerWorkgroup, "a CU's LDS");
+static_assert (kRowKeyBytes >= kMaxActive * sizeof (uint64_t) &&
+    kRowKeyBytes >= kMaxActive * sizeof (uint32_t) + 2 * kBins * sizeof (int), "the other uses of the key region");
 __device__ __forceinline__ void
 scan_row (const ScanEdge *__restrict__ edges, const int2 *__restrict__ spans,
     uint32_t n_edges, int xmin, int ymin, int xmax, int ymax, int even_odd,
     uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ status, int lds_bytes,
     uint32_t *__restrict__ debug)
 {
-  extern __shared__ __align__ (16) uint8_t lds[];
+  // (static: a workgroup may have more than 64 KB of a CU's 160 only as a static array)
+  __shared__ __align__ (16) uint8_t lds[kRowLdsBytes];
   const int tid = threadIdx.x;
   const int row = blockIdx.x;
   const uint64_t t_begin = debug ? wall_clock64 () : 0;
@@ -1116,28 +1340,36 @@ scan_row (const ScanEdge *__restrict__ edges, const int2 *__restrict__ spans,
   // the edges that cross this row; and whether one of them starts or ends inside it (the
   // row is then converted by sample rows whatever the order of its edges)
   bool inside = false;
-  for (uint32_t base = 0; base < n_edges; base += kThreads * 8) {
-    int2 tb[8];
+  // (two spans to a read, six reads in flight: 12 288 edges per round of the workgroup)
+  for (uint32_t base = 0; base < n_edges; base += kThreads * 12) {
+    int4 tb[6];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const uint32_t i = base + u * kThreads + tid;
-      tb[u] = i < n_edges ? spans[i] : make_int2 (INT_MAX, INT_MIN);
+    for (int u = 0; u < 6; u++) {
+      const uint32_t i = base + (u * kThreads + tid) * 2;
+      tb[u] = i < n_edges ? *reinterpret_cast<const int4 *> (spans + i)
+                          : make_int4 (INT_MAX, INT_MIN, INT_MAX, INT_MIN);
+      if (i + 1 >= n_edges) {       // (beyond the last edge: the scratch buffer's padding)
+        tb[u].z = INT_MAX;
+        tb[u].w = INT_MIN;
+      }
     }
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < 12; u++) {
       // (one atomic per wave: its first lane takes places for all of the wave's edges)
-      const bool hit = tb[u].x < s1 && tb[u].y > s0;
+      const int top = (u & 1) ? tb[u >> 1].z : tb[u >> 1].x;
+      const int bot = (u & 1) ? tb[u >> 1].w : tb[u >> 1].y;
+      const bool hit = top < s1 && bot > s0;
       const uint64_t hits = __ballot (hit);
       if (hits) {
         int k0 = 0;
         if ((tid & 63) == 0)
           k0 = atomicAdd (&S.sc[0], __popcll (hits));
-        k0 = __shfl (k0, 0, 64);
+        k0 = __builtin_amdgcn_readfirstlane (k0);
         if (hit) {
           const int k = k0 + __popcll (hits & ((1ull << (tid & 63)) - 1ull));
           if (k < kMaxActive)
-            S.idx[k] = base + u * kThreads + tid;
-          inside |= tb[u].x > s0 || tb[u].y < s1;
+            S.idx[k] = base + ((u >> 1) * kThreads + tid) * 2 + (u & 1);
+          inside |= top > s0 || bot < s1;
         }
       }
     }
@@ -1162,9 +1394,6 @@ scan_row (const ScanEdge *__restrict__ edges, const int2 *__restrict__ spans,
   int npad = 2;
   while (npad < n)
     npad <<= 1;
-  for (int i = tid; i < n; i += kThreads)
-    S.dir[i] = (int8_t) edges[S.idx[i]].dir;
-
   bool full_row = false;
   if (!S.sc[13]) {
     dbg_mode |= 1;
@@ -1265,7 +1494,15 @@ scan_row (const ScanEdge *__restrict__ edges, const int2 *__restrict__ spans,
         render_edge (S, e, s0, -1, xmin, width);
     }
     __syncthreads ();
+  } else if (n <= kThreads) {
+    if (debug)
+      dbg_t = wall_clock64 ();
+    sample_rows_together (S, edges, n, s0, xmin, xmax, mask, tid, debug != nullptr, dbg_ph, dbg_t);
   } else {
+    // More than kThreads edges in the row: one sample row after the other (the same idea
+    // with the bins of one sample row at a time, two edges to a thread).
+    for (int i = tid; i < n; i += kThreads)
+      S.dir[i] = (int8_t) edges[S.idx[i]].dir;
     // By sample rows, without sorting.  What Cairo's sorted walk yields depends on the
     // order of cells only through the winding before and after each group of equal cells.
     // The row's pixels are cut into up to 2048 bins (one pixel each where they suffice).
@@ -1615,13 +1852,10 @@ extern "C" int flutl_launch_scan_counted (void *stream_, const int32_t *edges_de
     // LDS: the accumulators by the box width; a region that holds the sort keys of an
     // eligible row's order and then the bins of the sample rows
     const size_t fixed = row_shared_fixed_bytes ((int) width);
-    size_t keys = (size_t) kMaxActive * sizeof (uint32_t) + 2 * kBins * sizeof (int);
-    if (keys < (size_t) kMaxActive * sizeof (uint64_t))
-      keys = (size_t) kMaxActive * sizeof (uint64_t);
-    const size_t lds = fixed + keys;
-    if (lds > 65536)
+    const size_t lds = fixed + kRowKeyBytes;
+    if (lds > kRowLdsBytes)
       return FLUTL_ERANGE;
-    scan_rows_kernel<<<height, kThreads, lds, stream>>> (prepared, spans, n_edges, xmin, ymin,
+    scan_rows_kernel<<<height, kThreads, 0, stream>>> (prepared, spans, n_edges, xmin, ymin,
         xmax, ymax, even_odd, static_cast<uint8_t *> (dst), dst_stride, status, (int) lds,
         g_scan_debug, pad_zero, mode == 0, seq);
   } else {
