@@ -115,6 +115,53 @@ def test_random_polygons_match_the_restatement(gpu):
         assert np.array_equal(got, want), f"case {it}: {(got != want).sum()} px differ"
 
 
+def _random_polygon(rng, W, H, n, snap):
+    px = rng.integers(-20 * 256, (W + 20) * 256, n) // snap * snap
+    py = rng.integers(-10 * 256, (H + 10) * 256, n) // snap * snap
+    edges = []
+    for k in range(n):
+        x1, y1, x2, y2 = int(px[k]), int(py[k]), int(px[(k + 1) % n]), int(py[(k + 1) % n])
+        if y1 == y2:
+            continue
+        d = 1
+        if y1 > y2:
+            x1, y1, x2, y2, d = x2, y2, x1, y1, -1
+        edges.append((x1, y1, x2, y2, y1, y2, d))
+    return np.array(edges, np.int32)
+
+
+@pytest.mark.parametrize("W,H,n,snap", [
+    (900, 24, 1800, 1),       # ~600 edges in every row: all sample rows together, full bins
+    (900, 24, 1800, 64),      # ... with ties of cells all over
+    (3900, 20, 500, 1),       # bins of 4 pixels
+    (4090, 12, 900, 256),     # the widest box, pixel-aligned vertices
+    (700, 16, 2400, 1),       # 1024 < edges per row <= 2048: one sample row after the other
+    (700, 16, 2400, 128),
+    (500, 10, 5200, 1),       # > 2048 edges in a row: the overflow flag, the sequential sweep
+])
+def test_crowded_rows_and_windows(gpu, W, H, n, snap):
+    """rows with hundreds to thousands of edges (each path of the row kernel: sample rows
+    together, one by one, overflow), vertices beyond every side of the box (edges clipped
+    left, right, above, below), against oracle/flutl_tor_oracle.c"""
+    rng = np.random.default_rng(W * 31 + n + snap)
+    edges = _random_polygon(rng, W, H, n, snap)
+    box = (0, 0, W, H)
+    for eo in (False, True):
+        want = O.scan_polygon(edges, box, eo)
+        got, _ = hip_scan(gpu, edges, box, eo, mode=0)
+        assert np.array_equal(got, want), f"{(got != want).sum()} px differ (even_odd {eo})"
+    # how many edges the busiest row has (the case must exercise what it says)
+    top = (edges[:, 4].astype(np.int64) * 15 + 128) >> 8
+    bot = (edges[:, 5].astype(np.int64) * 15 + 128) >> 8
+    busiest = max(int(((top < (r + 1) * 15) & (bot > r * 15)).sum()) for r in range(H))
+    if n == 2400:
+        assert 1024 < busiest <= 2048
+    elif n == 5200:
+        assert busiest > 2048
+    else:
+        assert busiest <= 1024
+
+
 def test_polygon_becomes_an_atlas_entry_masks_can_read(gpu):
     """flutl_atlas_put_polygon: the coverage lands in the context's atlas in the MASK
     layout (4 zero bytes, rows of width + 4), composited by a MASK primitive it must give
