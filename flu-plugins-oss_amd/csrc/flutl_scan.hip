@@ -1086,9 +1086,24 @@ __device__ inline int block_exclusive_scan (int v, int tid, int *part)
 constexpr int kBinsT = 1024;
 constexpr int kTogetherWords = kGridY * kBinsT + 32 + kGridY * kThreads;   // bins, aux, entries
 
+// the bins of sample_rows_together, its 32 words beside them, the range of its pixels
+__device__ __forceinline__ void together_clear (RowShared &S, int tid)
+{
+  int *bins = reinterpret_cast<int *> (S.key);
+#pragma unroll
+  for (int k = 0; k < kGridY; k++)
+    bins[k * kThreads + tid] = 0;
+  if (tid < 32)
+    bins[kGridY * kBinsT + tid] = 0;
+  if (tid == 0) {
+    S.sc[8] = INT_MAX;
+    S.sc[9] = INT_MIN;
+  }
+}
+
 __device__ __forceinline__ void
 sample_rows_together (RowShared &S, const ScanEdge *__restrict__ edges, int n, int s0, int xmin,
-    int xmax, unsigned mask, int tid, bool debug, uint32_t *dbg_ph, uint64_t &dbg_t)
+    int xmax, unsigned mask, int tid, bool dirty, bool debug, uint32_t *dbg_ph, uint64_t &dbg_t)
 {
 #define DBG_PHASE_T(k) do { if (debug) { const uint64_t now_ = wall_clock64 (); dbg_ph[k] += (uint32_t) (now_ - dbg_t); dbg_t = now_; } } while (0)
   int *bins = reinterpret_cast<int *> (S.key);          // [15 * kBinsT + 1] entries | winding << 16,
@@ -1099,71 +1114,87 @@ sample_rows_together (RowShared &S, const ScanEdge *__restrict__ edges, int n, i
                                                         // bin: cell in the bin << 16 | direction (two bits, signed) << 14 | bin
   const int width = xmax - xmin, s1 = s0 + kGridY;
   const int lo_cell = (xmin - 1) * 256, hi_cell = (xmax + 1) * 256 - 1;
-  if (tid == 0) {
-    S.sc[8] = INT_MAX;          // the pixels the row's edges stay within
-    S.sc[9] = INT_MIN;
+  // (the bins were cleared when the row began -- under the latency of its first reads --
+  // unless the attempt at an analytic row has had its sort keys there since)
+  if (dirty) {
+    together_clear (S, tid);
+    __syncthreads ();
   }
+  // this thread's edge: x at its first sample row in this pixel row, then Cairo's steps to
+  // the cells of the row's 15 sample rows (from lo_cell; -1: the edge is not there)
+  int cellk[kGridY];
+  int dir = 0;
+  {
+    int32_t eq = 0, edq = 0;
+    int64_t er = 0, edr = 0, eD = 0;
+    int esa = 0, esb = 0;
+    if (tid < n) {
+      const ScanEdge e = edges[S.idx[tid]];
+      esa = e.ytop > s0 ? e.ytop : s0;
+      esb = e.ybot < s1 ? e.ybot : s1;
+      dir = e.dir;
+      edge_x_at (e, esa, eq, er);
+      edq = e.dq;
+      edr = e.dr;
+      eD = e.D;
+    }
+    int pmin = INT_MAX, pmax = INT_MIN;
 #pragma unroll
-  for (int k = 0; k < kGridY; k++)
-    bins[k * kThreads + tid] = 0;
-  if (tid < 32)
-    bins[kGridY * kBinsT + tid] = 0;
-  __syncthreads ();
-  // this thread's edge: x at its first sample row in this pixel row, then Cairo's steps
-  int32_t eq = 0, edq = 0;
-  int64_t er = 0, edr = 0, eD = 0;
-  int esa = 0, esb = 0, dir = 0;
-  if (tid < n) {
-    const ScanEdge e = edges[S.idx[tid]];
-    esa = e.ytop > s0 ? e.ytop : s0;
-    esb = e.ybot < s1 ? e.ybot : s1;
-    dir = e.dir;
-    edge_x_at (e, esa, eq, er);
-    edq = e.dq;
-    edr = e.dr;
-    eD = e.D;
-    // (an edge is a straight line: every step advances it by dq plus a fraction in (-1, 1))
-    const int ca = cell_of (eq, er, eD);
-    const int steps = esb - esa - 1;
-    const int far = ca + steps * e.dq;
-    const int c0 = (ca < far - steps ? ca : far - steps) - 2;
-    const int c1 = (ca > far + steps ? ca : far + steps) + 2;
-    const int k0 = ((c0 < lo_cell ? lo_cell : (c0 > hi_cell ? hi_cell : c0)) - lo_cell) >> 8;
-    const int k1 = ((c1 < lo_cell ? lo_cell : (c1 > hi_cell ? hi_cell : c1)) - lo_cell) >> 8;
-    atomicMin (&S.sc[8], k0);
-    atomicMax (&S.sc[9], k1);
+    for (int k = 0; k < kGridY; k++) {
+      const int s = s0 + k;
+      cellk[k] = -1;
+      if (s >= esa && s < esb) {
+        int cell = cell_of (eq, er, eD);
+        cell = cell < lo_cell ? lo_cell : (cell > hi_cell ? hi_cell : cell);
+        cell -= lo_cell;
+        const int px = cell >> 8;
+        if (px <= width) {
+          cellk[k] = cell;
+          if (px >= 1) {
+            pmin = px < pmin ? px : pmin;
+            pmax = px > pmax ? px : pmax;
+          }
+        }
+        if (eD) {
+          eq += edq;
+          er += edr;
+          normalise (eq, er, eD);
+        }
+      }
+    }
+    if (pmin <= pmax) {
+      atomicMin (&S.sc[8], pmin);       // the pixels the row's edges stay within
+      atomicMax (&S.sc[9], pmax);
+    }
   }
   __syncthreads ();
   // bins of 1 << shift pixels over [range0, range1)
-  const int range0 = S.sc[8] < 1 ? 1 : S.sc[8];
-  const int range1 = S.sc[9] + 1;
+  const bool any = S.sc[8] <= S.sc[9];
+  const int range0 = any ? S.sc[8] : 1;
+  const int range1 = any ? S.sc[9] + 1 : 2;
   int shift = 0;
   while (((range1 - range0 + (1 << shift) - 1) >> shift) > kBinsT)
     shift++;
   DBG_PHASE_T (4);
-  // count: rec = cell (from lo_cell) * 1024 + place in the bin; -1: not in a bin
+  // count: all of the thread's atomics in flight together; rec = cell * 1024 + place in the
+  // bin; -1: not in a bin
   int rec[kGridY];
+  {
+    int old[kGridY];
 #pragma unroll
-  for (int k = 0; k < kGridY; k++) {
-    const int s = s0 + k;
-    rec[k] = -1;
-    if (s >= esa && s < esb) {
-      int cell = cell_of (eq, er, eD);
-      cell = cell < lo_cell ? lo_cell : (cell > hi_cell ? hi_cell : cell);
-      cell -= lo_cell;
-      const int px = cell >> 8;
-      if (px == 0) {
-        atomicAdd (&leftw[k], dir);
-      } else if (px <= width) {
-        const int old = atomicAdd (&bins[k * kBinsT + ((px - range0) >> shift)], dir * 65536 + 1);
-        rec[k] = cell * 1024 + (old & 0xffff);
-      }
-      if (eD) {
-        eq += edq;
-        er += edr;
-        normalise (eq, er, eD);
+    for (int k = 0; k < kGridY; k++) {
+      old[k] = 0;
+      if (cellk[k] >= 0) {
+        const int px = cellk[k] >> 8;
+        if (px == 0)
+          atomicAdd (&leftw[k], dir);
+        else
+          old[k] = atomicAdd (&bins[k * kBinsT + ((px - range0) >> shift)], dir * 65536 + 1);
       }
     }
+#pragma unroll
+    for (int k = 0; k < kGridY; k++)
+      rec[k] = cellk[k] < 256 ? -1 : cellk[k] * 1024 + (old[k] & 0xffff);
   }
   __syncthreads ();
   DBG_PHASE_T (0);
@@ -1336,6 +1367,7 @@ scan_row (const ScanEdge *__restrict__ edges, const int2 *__restrict__ spans,
     S.sc[1] = 0;
     S.sc[13] = 0;
   }
+  together_clear (S, tid);
   __syncthreads ();
   // the edges that cross this row; and whether one of them starts or ends inside it (the
   // row is then converted by sample rows whatever the order of its edges)
@@ -1497,7 +1529,8 @@ scan_row (const ScanEdge *__restrict__ edges, const int2 *__restrict__ spans,
   } else if (n <= kThreads) {
     if (debug)
       dbg_t = wall_clock64 ();
-    sample_rows_together (S, edges, n, s0, xmin, xmax, mask, tid, debug != nullptr, dbg_ph, dbg_t);
+    sample_rows_together (S, edges, n, s0, xmin, xmax, mask, tid, (dbg_mode & 1) != 0, debug != nullptr,
+        dbg_ph, dbg_t);
   } else {
     // More than kThreads edges in the row: one sample row after the other (the same idea
     // with the bins of one sample row at a time, two edges to a thread).
