@@ -41,7 +41,7 @@ INC="-I$HERE -I$PKG/../include -I$T -I$REF/libs/common -I$REF/libs/flu/downloade
  -I$C/lib/gstreamer-1.0/include -I$C/include/libxml2 -I$C/include/pango-1.0
  -I$C/include/cairo -I$C/include/pixman-1 -I$C/include/harfbuzz
  -I$C/include/freetype2 -I$C/include/fribidi -I$C/include"
-DEFS="-DVERSION=\"fluttml-hip\" -DPACKAGE=\"flu-plugins-oss\" -DPACKAGE_NAME=\"flu-plugins-oss\"
+DEFS="-D_GNU_SOURCE -DVERSION=\"fluttml-hip\" -DPACKAGE=\"flu-plugins-oss\" -DPACKAGE_NAME=\"flu-plugins-oss\"
  -DBUILD_TTMLPARSE=1 -DBUILD_TTMLRENDER=1 -DFLUC_USE_THREADS=1 -D_FLUC_H_
  -include fluc/threads/fluc_threads.h -include fluc/bwmeter/fluc_bwmeter.h"
 # gstttmlstate.c on its own: its gst_ttml_state_save_data g_realloc()s a buffer

@@ -15,12 +15,17 @@
  *     other cases go to pixman (cairo-image-compositor.c);
  *   - glyphs land at floor (device position + 0.5) and always go to pixman.
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE               /* mremap */
+#endif
 #include "flutl_recorder.h"
 #include "flutl_stroker.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 
 #define ATLAS_SLACK 16u
 #define ATLAS_ALIGN 16u
@@ -199,6 +204,35 @@ xrealloc (void *p, size_t n)
   return q;
 }
 
+/* The host copy of the atlas is an anonymous mapping: pages nothing was written to
+ * cost nothing and read as zeros.  The space of an entry the device makes (an
+ * outline's coverage, half a megabyte per cue at 4K) is only set aside there, and
+ * starting over (drop_caches) gives the touched pages back instead of clearing a
+ * quarter of a gigabyte. */
+static uint8_t *
+atlas_map_grow (uint8_t *old, size_t old_cap, size_t cap)
+{
+  void *p = old ? mremap (old, old_cap, cap, MREMAP_MAYMOVE)
+                : mmap (NULL, cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+  if (p == MAP_FAILED) {
+    fprintf (stderr, "flutl_recorder: out of memory (atlas of %zu bytes)\n", cap);
+    abort ();
+  }
+  return p;
+}
+
+static void
+atlas_ensure (FlutlRecorder *rec, size_t need)
+{
+  if (need <= rec->atlas_cap)
+    return;
+  size_t cap = rec->atlas_cap ? rec->atlas_cap : (size_t) 1 << 20;
+  while (cap < need)
+    cap *= 2;
+  rec->atlas = atlas_map_grow (rec->atlas, rec->atlas_cap, cap);    /* (new pages: zeros) */
+  rec->atlas_cap = cap;
+}
+
 static FlutlRecorder *
 root_of (FlutlRecorder *rec)
 {
@@ -248,16 +282,11 @@ atlas_put_locked (FlutlRecorder *rec, const void *src, size_t bytes, int on_devi
 {
   size_t off = (rec->atlas_size + ATLAS_ALIGN - 1) & ~(size_t) (ATLAS_ALIGN - 1);
   size_t end = off + bytes;
-  if (end + ATLAS_SLACK > rec->atlas_cap) {
-    size_t cap = rec->atlas_cap ? rec->atlas_cap : 1 << 16;
-    while (cap < end + ATLAS_SLACK)
-      cap *= 2;
-    rec->atlas = xrealloc (rec->atlas, cap);
-    memset (rec->atlas + rec->atlas_cap, 0, cap - rec->atlas_cap);
-    rec->atlas_cap = cap;
-  }
-  memset (rec->atlas + rec->atlas_size, 0, off - rec->atlas_size);
-  memcpy (rec->atlas + off, src, bytes);
+  atlas_ensure (rec, end + ATLAS_SLACK);
+  /* (beyond atlas_size nothing has been written since the mapping was made or given
+   * back: zeros.  src == NULL: an entry of zeros) */
+  if (src)
+    memcpy (rec->atlas + off, src, bytes);
   rec->atlas_size = end;
   if (on_device)
     return (uint32_t) off;      /* produced on the device: nothing to upload */
@@ -283,11 +312,7 @@ atlas_reserve_polygon (FlutlRecorder *rec, FlutlPolygonEntry *pe)
 {
   rec = root_of (rec);
   const size_t bytes = MASK_PAD + ((size_t) pe->w + MASK_PAD) * pe->h;
-  uint8_t *zeros = calloc (bytes, 1);
-  if (!zeros)
-    abort ();
-  const uint32_t off = atlas_put_locked (rec, zeros, bytes, 0);
-  free (zeros);
+  const uint32_t off = atlas_put_locked (rec, NULL, bytes, 0);
   rec->new_poly[rec->n_new - 1] = pe;
   return off;
 }
@@ -585,7 +610,7 @@ drop_caches (FlutlRecorder *rec)
   rec->n_runs = 0;
   rec->n_run = 0;
   rec->atlas_size = ATLAS_SLACK;
-  if (rec->atlas)
+  if (rec->atlas && madvise (rec->atlas, rec->atlas_cap, MADV_DONTNEED) != 0)
     memset (rec->atlas, 0, rec->atlas_cap);
   for (uint32_t i = 0; i < rec->n_new; i++)
     flutl_polygon_entry_free (rec->new_poly[i]);
@@ -611,7 +636,8 @@ flutl_recorder_free (FlutlRecorder *rec)
   free (rec->prims);
   free (rec->prim_tags);
   free (rec->regions);
-  free (rec->atlas);
+  if (rec->atlas)
+    munmap (rec->atlas, rec->atlas_cap);
   for (uint32_t i = 0; i < rec->n_new; i++)
     flutl_polygon_entry_free (rec->new_poly ? rec->new_poly[i] : NULL);
   free (rec->new_off);
@@ -3156,11 +3182,7 @@ flutl_recorder_atlas (FlutlRecorder *rec, size_t *size)
 {
   /* [0, atlas_size) is data, followed by ATLAS_SLACK readable zero bytes */
   size_t need = rec->atlas_size + ATLAS_SLACK;
-  if (need > rec->atlas_cap) {
-    rec->atlas = xrealloc (rec->atlas, need);
-    memset (rec->atlas + rec->atlas_cap, 0, need - rec->atlas_cap);
-    rec->atlas_cap = need;
-  }
+  atlas_ensure (rec, need);
   *size = need;
   return rec->atlas;
 }

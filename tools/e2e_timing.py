@@ -23,7 +23,7 @@ import gstenv  # noqa: E402
 PIPELINE = "filesrc ! ttmlrender ! video/x-raw,width={W},height={H} ! fakesink"
 
 
-def measure(ttml, W, H, extra_env=None, log_path=None, sink="fakesink"):
+def measure(ttml, W, H, extra_env=None, log_path=None, sink="fakesink", props=()):
     extra = {"FLUTL_TIMING": "1"}
     for k, v in os.environ.items():
         if k.startswith("FLUTL_") and k != "FLUTL_BENCH_REHEARSAL":
@@ -31,7 +31,7 @@ def measure(ttml, W, H, extra_env=None, log_path=None, sink="fakesink"):
     extra.update(extra_env or {})
     env = gstenv.env_for(gstenv.HIP_PLUGIN_DIR, extra)
     cmd = [os.path.join(gstenv.CONDA, "bin", "gst-launch-1.0"), "-q", "filesrc",
-           f"location={os.path.abspath(ttml)}", "!", "ttmlrender", "!",
+           f"location={os.path.abspath(ttml)}", "!", "ttmlrender", *props, "!",
            f"video/x-raw,width={W},height={H}", "!"] + sink.split()
     t0 = time.perf_counter()
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=tempfile.gettempdir(),
