@@ -147,6 +147,11 @@ struct FlutlRecorder
    * come back as a different font */
   cairo_scaled_font_t **key_fonts;
   uint32_t n_key_fonts, cap_key_fonts;
+  /* outlines of single glyphs in 24.8 fixed point at origin 0 ("composed outline paths"
+   * below): (scaled font, glyph) -> GlyphOutline; the fonts are pinned in key_fonts */
+  GHashTable *outlines;
+  int check_paths;              /* FLUTL_CHECK_PATHS=1: every composed path against Cairo's */
+  int no_compose;               /* FLUTL_NO_COMPOSED_PATHS=1: every path built by Cairo (A/B) */
 
   /* glyph runs ("glyph runs" below): glyphs shown back to back in one colour under
    * one clip, held back until something else is drawn */
@@ -531,6 +536,8 @@ flutl_recorder_new (void)
     abort ();
   rec->atlas_size = ATLAS_SLACK;
   rec->line_split = g_getenv ("FLUTL_LINE_SPLIT") != NULL;
+  rec->check_paths = g_getenv ("FLUTL_CHECK_PATHS") != NULL;
+  rec->no_compose = g_getenv ("FLUTL_NO_COMPOSED_PATHS") != NULL;
   rec->no_run_merge = g_getenv ("FLUTL_NO_RUN_MERGE") != NULL;
   g_rec_mutex_init (&rec->lock);
   return rec;
@@ -602,6 +609,8 @@ drop_caches (FlutlRecorder *rec)
     }
   }
   rec->n_strokes = 0;
+  if (rec->outlines)            /* (keyed by the addresses of the fonts released next) */
+    g_hash_table_remove_all (rec->outlines);
   for (uint32_t i = 0; i < rec->n_key_fonts; i++)
     cairo_scaled_font_destroy (rec->key_fonts[i]);
   rec->n_key_fonts = 0;
@@ -648,6 +657,8 @@ flutl_recorder_free (FlutlRecorder *rec)
   path_ops_clear (rec);
   free (rec->ops);
   free (rec->strokes);
+  if (rec->outlines)
+    g_hash_table_destroy (rec->outlines);
   free (rec->key_fonts);
   free (rec->patches);
   free (rec->run);
@@ -2173,6 +2184,7 @@ typedef struct StrokeJob
 {
   gint refs;
   cairo_path_t *path;            /* device coordinates */
+  int path_cap;                  /* > 0: a composed path in a pooled buffer of that capacity */
   cairo_matrix_t ctm;            /* in force at cairo_stroke */
   double line_width, miter_limit;
   RasterBox rb;
@@ -2209,12 +2221,16 @@ worker_surface_free (gpointer data)
 
 static GPrivate worker_surface_key = G_PRIVATE_INIT (worker_surface_free);
 
+static void path_buffer_put (cairo_path_t *p, int cap);
+
 static void
 stroke_job_unref (StrokeJob *j)
 {
   if (!g_atomic_int_dec_and_test (&j->refs))
     return;
-  if (j->path)
+  if (j->path && j->path_cap)
+    path_buffer_put (j->path, j->path_cap);
+  else if (j->path)
     cairo_path_destroy (j->path);
   flutl_polygon_entry_free (j->poly);
   free (j->tight);
@@ -2422,6 +2438,367 @@ flutl_recorder_set_defer (FlutlRecorder *rec, int on)
   rec->defer = on && !rec->parent;
 }
 
+/* ---- composed outline paths ---------------------------------------------------------
+ * What a new outline costs the streaming thread was, by a sampling profile of a stream
+ * with new text in every cue (tools/sprof_stream.py): 8 % building the path on the
+ * tracking context (one pango_cairo_glyph_string_path per glyph) and 42 % copying it out
+ * again (cairo_copy_path: 100-150 KB allocated, written and freed per cue, every time
+ * past the allocator's trim threshold: page faults and brk calls).  Neither is needed
+ * where the path is glyphs under translations, the rule and not the exception
+ * (gstttmlrender.c:1138-1161): Cairo appends a glyph's outline -- a fixed-point path of
+ * its own, kept by the scaled font -- at the glyph's origin ROUNDED TO FIXED POINT
+ * (_cairo_scaled_font_glyph_path: _cairo_path_fixed_append (path, glyph_path,
+ * _cairo_fixed_from_double (x), _cairo_fixed_from_double (y))), an integer addition per
+ * point; and what cairo-path-fixed.c filters out of a path (degenerate and collinear
+ * line_tos) it has filtered out of the glyph's own path already, by differences that no
+ * translation changes.  So the path is composed here: each glyph's outline taken from
+ * Cairo ONCE (the same call at origin 0), then integer additions into a pooled buffer,
+ * laid out as the cairo_path_t cairo_copy_path would have returned, element for element.
+ * FLUTL_CHECK_PATHS=1 builds every such path both ways and aborts on any difference
+ * (tests/test_element_boundary.py; FLUTL_CHECK_PATHS=1 tools/fuzz_ttml.py).
+ * The path's extents (cairo_path_extents: points, and the exact bounds of curves whose
+ * control points lie outside the box so far -- _cairo_box_add_curve_to) come the same way:
+ * the box of each glyph's on-curve points moves with the glyph, and the few curves whose
+ * control points leave that box are bounded again at their place by the same arithmetic
+ * (flutl_stroker_box_add_curve; skipping a curve whose control points lie inside the box
+ * never changes the box, so which curves Cairo happened to skip does not matter). */
+typedef struct
+{
+  cairo_scaled_font_t *sf;
+  unsigned long glyph;
+} OutlineKey;
+
+typedef struct
+{
+  OutlineKey key;
+  int n_data;                   /* cairo_path_data_t elements (headers + points) */
+  int32_t *el;                  /* per element: header {type, length} or point {x, y}, 24.8 */
+  int32_t box[4];               /* of the on-curve points; n_data == 0: no outline */
+  int n_flagged;
+  int *flagged;                 /* element index of the CURVE_TO headers to bound again */
+} GlyphOutline;
+
+static gint64 composed_paths, composed_paths_checked;   /* statistics */
+
+uint64_t
+flutl_recorder_composed_paths (uint64_t *checked)
+{
+  if (checked)
+    *checked = (uint64_t) composed_paths_checked;
+  return (uint64_t) composed_paths;
+}
+
+static guint
+outline_key_hash (gconstpointer p)
+{
+  const OutlineKey *k = p;
+  return (guint) (((guintptr) k->sf >> 4) * 2654435761u) ^ (guint) (k->glyph * 40503u);
+}
+
+static gboolean
+outline_key_equal (gconstpointer a, gconstpointer b)
+{
+  const OutlineKey *x = a, *y = b;
+  return x->sf == y->sf && x->glyph == y->glyph;
+}
+
+static void
+outline_free (gpointer p)
+{
+  GlyphOutline *o = p;
+  free (o->el);
+  free (o->flagged);
+  free (o);
+}
+
+static int
+pt_in_box (const int32_t box[4], int32_t x, int32_t y)
+{
+  return x >= box[0] && x <= box[2] && y >= box[1] && y <= box[3];
+}
+
+/* the glyph's outline as Cairo appends it at origin (0, 0): taken once, by the very call
+ * raster_build_path makes */
+static GlyphOutline *
+outline_get (FlutlRecorder *rec, PangoFont *font, cairo_scaled_font_t *sf, PangoGlyph glyph)
+{
+  OutlineKey key = { sf, glyph };
+  if (!rec->outlines)
+    rec->outlines = g_hash_table_new_full (outline_key_hash, outline_key_equal, NULL, outline_free);
+  GlyphOutline *o = g_hash_table_lookup (rec->outlines, &key);
+  if (o)
+    return o;
+  cairo_t *cr = rec->cr;
+  PangoGlyphInfo gi;
+  memset (&gi, 0, sizeof gi);
+  gi.glyph = glyph;
+  PangoGlyphString one = { 1, &gi, NULL, 1 };
+  cairo_save (cr);
+  cairo_identity_matrix (cr);
+  cairo_reset_clip (cr);
+  cairo_new_path (cr);
+  pango_cairo_glyph_string_path (cr, font, &one);
+  cairo_path_t *path = cairo_copy_path (cr);
+  cairo_new_path (cr);
+  cairo_restore (cr);
+  if (!path || path->status != CAIRO_STATUS_SUCCESS) {
+    if (path)
+      cairo_path_destroy (path);
+    return NULL;
+  }
+  o = calloc (1, sizeof *o);
+  if (!o)
+    abort ();
+  o->key = key;
+  o->n_data = path->num_data;
+  o->el = malloc ((size_t) (path->num_data ? path->num_data : 1) * 2 * sizeof (int32_t));
+  o->flagged = malloc ((size_t) (path->num_data ? path->num_data : 1) * sizeof (int));
+  if (!o->el || !o->flagged)
+    abort ();
+  o->box[0] = o->box[1] = INT32_MAX;
+  o->box[2] = o->box[3] = INT32_MIN;
+  int ok = 1;
+  for (int i = 0; i < path->num_data && ok; i += path->data[i].header.length) {
+    const cairo_path_data_t *d = &path->data[i];
+    const int npt = d->header.length - 1;
+    o->el[2 * i] = (int32_t) d->header.type;
+    o->el[2 * i + 1] = d->header.length;
+    for (int k = 1; k <= npt; k++) {
+      /* (under the identity these are fixed-point values / 256, exactly) */
+      const double fx = d[k].point.x * 256.0, fy = d[k].point.y * 256.0;
+      if (fx != floor (fx) || fy != floor (fy) || fabs (fx) > 1e9 || fabs (fy) > 1e9)
+        ok = 0;
+      o->el[2 * (i + k)] = (int32_t) fx;
+      o->el[2 * (i + k) + 1] = (int32_t) fy;
+    }
+    if (npt > 0) {              /* the element's last point is on the curve */
+      const int32_t x = o->el[2 * (i + npt)], y = o->el[2 * (i + npt) + 1];
+      o->box[0] = x < o->box[0] ? x : o->box[0];
+      o->box[1] = y < o->box[1] ? y : o->box[1];
+      o->box[2] = x > o->box[2] ? x : o->box[2];
+      o->box[3] = y > o->box[3] ? y : o->box[3];
+    }
+  }
+  for (int i = 0, prev_len = 0; i < path->num_data && ok; i += prev_len) {
+    if (path->data[i].header.type == CAIRO_PATH_CURVE_TO &&
+        (!pt_in_box (o->box, o->el[2 * (i + 1)], o->el[2 * (i + 1) + 1]) ||
+         !pt_in_box (o->box, o->el[2 * (i + 2)], o->el[2 * (i + 2) + 1]))) {
+      if (prev_len < 2)
+        ok = 0;                 /* (a curve without a point before it: never from Cairo) */
+      o->flagged[o->n_flagged++] = i;
+    }
+    prev_len = path->data[i].header.length;
+  }
+  cairo_path_destroy (path);
+  if (!ok)
+    o->n_data = -1;             /* (remembered: not composable) */
+  key_font_pin (rec, sf);       /* (the key names the font by address) */
+  g_hash_table_insert (rec->outlines, &o->key, o);
+  return o;
+}
+
+/* path buffers go round: a cue's path is 100-150 KB, past the allocator's trim threshold */
+static GMutex path_pool_lock;
+static cairo_path_t *path_pool[16];
+static int path_pool_cap[16], path_pool_n;
+
+static cairo_path_t *
+path_buffer_get (int n_data)
+{
+  cairo_path_t *p = NULL;
+  int cap = 0;
+  g_mutex_lock (&path_pool_lock);
+  if (path_pool_n) {
+    path_pool_n--;
+    p = path_pool[path_pool_n];
+    cap = path_pool_cap[path_pool_n];
+  }
+  g_mutex_unlock (&path_pool_lock);
+  if (!p) {
+    p = calloc (1, sizeof *p);
+    if (!p)
+      abort ();
+  }
+  if (cap < n_data) {
+    cap = n_data + n_data / 2 + 64;
+    free (p->data);
+    p->data = malloc ((size_t) cap * sizeof (cairo_path_data_t));
+    if (!p->data)
+      abort ();
+  }
+  p->status = CAIRO_STATUS_SUCCESS;
+  p->num_data = cap;            /* (capacity, until the composer sets the count) */
+  return p;
+}
+
+static void
+path_buffer_put (cairo_path_t *p, int cap)
+{
+  g_mutex_lock (&path_pool_lock);
+  if (path_pool_n < 16) {
+    path_pool[path_pool_n] = p;
+    path_pool_cap[path_pool_n] = cap;
+    path_pool_n++;
+    p = NULL;
+  }
+  g_mutex_unlock (&path_pool_lock);
+  if (p) {
+    free (p->data);
+    free (p);
+  }
+}
+
+/* The pending ops as the path raster_build_path + cairo_copy_path would give, or NULL
+ * where this file does not compose (anything but glyphs under translations whose origins
+ * lie within the bounds Cairo keeps glyphs in).  ext: cairo_path_extents of it. */
+static cairo_path_t *
+compose_outline_path (FlutlRecorder *rec, const RasterBox *rb, double ext[4], int *cap_out)
+{
+  int ox, oy, total = 0;
+  raster_origin (rec, &ox, &oy);
+  ox -= rec->shift[0];
+  oy -= rec->shift[1];
+  if (rec->n_ops == 0)
+    return NULL;
+  /* pass 1: every op must be composable; how many elements */
+  GlyphOutline **outs = g_newa (GlyphOutline *, rec->n_ops);
+  for (uint32_t i = 0; i < rec->n_ops; i++) {
+    const PathOp *op = &rec->ops[i];
+    if (!op->font || op->sfont)
+      return NULL;
+    if (op->m.xx != 1.0 || op->m.yy != 1.0 || op->m.xy != 0.0 || op->m.yx != 0.0)
+      return NULL;
+    if (op->gi.glyph == PANGO_GLYPH_EMPTY || (op->gi.glyph & PANGO_GLYPH_UNKNOWN_FLAG))
+      return NULL;
+    cairo_scaled_font_t *sf = pango_cairo_font_get_scaled_font ((PangoCairoFont *) op->font);
+    cairo_matrix_t fm;
+    if (!sf)
+      return NULL;
+    /* (Cairo would pick another scaled font under a CTM whose linear part is not the
+     * font's own; a font matrix with a translation moves the glyphs) */
+    cairo_scaled_font_get_ctm (sf, &fm);
+    if (fm.xx != 1.0 || fm.yy != 1.0 || fm.xy != 0.0 || fm.yx != 0.0)
+      return NULL;
+    cairo_scaled_font_get_font_matrix (sf, &fm);
+    if (fm.x0 != 0.0 || fm.y0 != 0.0)
+      return NULL;
+    outs[i] = outline_get (rec, op->font, sf, op->gi.glyph);
+    if (!outs[i] || outs[i]->n_data < 0)
+      return NULL;
+    total += outs[i]->n_data;
+  }
+  if (total == 0)
+    return NULL;
+  cairo_path_t *path = path_buffer_get (total);
+  *cap_out = path->num_data;
+  cairo_path_data_t *out = path->data;
+  int32_t box[4] = { INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN };
+  int n = 0;
+  for (uint32_t i = 0; i < rec->n_ops; i++) {
+    const PathOp *op = &rec->ops[i];
+    const GlyphOutline *o = outs[i];
+    /* pango_cairo_renderer: position = (no current point: 0, 0) + offsets; then
+     * _cairo_gstate_transform_glyphs_to_backend under a translation: + (0 + x0 + 0) */
+    double cx = (double) op->gi.geometry.x_offset / PANGO_SCALE;
+    double cy = op->gi.geometry.y_offset == 0 ? 0.0 : (double) op->gi.geometry.y_offset / PANGO_SCALE;
+    double mx = op->m.x0, my = op->m.y0;
+    if (ox)
+      mx -= ox;
+    if (oy)
+      my -= oy;
+    if (mx != 0.0 || my != 0.0) {
+      cx += mx;
+      cy += my;
+    }
+    /* a glyph whose origin lies far outside surface x clip is dropped by Cairo: only
+     * origins inside are composed */
+    if (!(cx >= rb->lim[0] && cx <= rb->lim[2] && cy >= rb->lim[1] && cy <= rb->lim[3]) ||
+        !(cx >= 0 && cx <= rec->sw && cy >= 0 && cy <= rec->sh)) {
+      path_buffer_put (path, *cap_out);
+      return NULL;
+    }
+    if (o->n_data == 0)
+      continue;
+    const int32_t fx = fixed_from_double (cx), fy = fixed_from_double (cy);
+    const int32_t *el = o->el;
+    const int base = n;
+    for (int k = 0; k < o->n_data;) {
+      const int len = el[2 * k + 1];
+      out[n].header.type = (cairo_path_data_type_t) el[2 * k];
+      out[n].header.length = len;
+      for (int q = 1; q < len; q++) {
+        out[n + q].point.x = (double) (el[2 * (k + q)] + fx) / 256.0;
+        out[n + q].point.y = (double) (el[2 * (k + q) + 1] + fy) / 256.0;
+      }
+      n += len;
+      k += len;
+    }
+    box[0] = o->box[0] + fx < box[0] ? o->box[0] + fx : box[0];
+    box[1] = o->box[1] + fy < box[1] ? o->box[1] + fy : box[1];
+    box[2] = o->box[2] + fx > box[2] ? o->box[2] + fx : box[2];
+    box[3] = o->box[3] + fy > box[3] ? o->box[3] + fy : box[3];
+    for (int f = 0; f < o->n_flagged; f++) {
+      /* the curve's start is the last point of the element before it */
+      const int k = o->flagged[f];
+      int32_t p[8];
+      p[0] = el[2 * (k - 1)] + fx;
+      p[1] = el[2 * (k - 1) + 1] + fy;
+      for (int q = 1; q <= 3; q++) {
+        p[2 * q] = el[2 * (k + q)] + fx;
+        p[2 * q + 1] = el[2 * (k + q) + 1] + fy;
+      }
+      flutl_stroker_box_add_curve (box, p);
+    }
+    (void) base;
+  }
+  path->num_data = n;
+  __atomic_fetch_add (&composed_paths, 1, __ATOMIC_RELAXED);
+  ext[0] = box[0] / 256.0;
+  ext[1] = box[1] / 256.0;
+  ext[2] = box[2] / 256.0;
+  ext[3] = box[3] / 256.0;
+  return path;
+}
+
+/* FLUTL_CHECK_PATHS: the composed path and its extents against what Cairo builds */
+static void
+composed_path_check (FlutlRecorder *rec, RasterBox *rb, const cairo_path_t *composed,
+    const double ext[4])
+{
+  cairo_t *cr = rec->cr;
+  RasterBox tmp = *rb;
+  double e[4];
+  raster_build_path (rec, &tmp);
+  cairo_save (cr);
+  cairo_identity_matrix (cr);
+  cairo_path_extents (cr, &e[0], &e[1], &e[2], &e[3]);
+  cairo_path_t *ref = cairo_copy_path (cr);
+  cairo_restore (cr);
+  cairo_new_path (cr);
+  int bad = !ref || ref->status != CAIRO_STATUS_SUCCESS || ref->num_data != composed->num_data ||
+      memcmp (tmp.lim, rb->lim, sizeof tmp.lim) != 0;
+  if (!bad)
+    for (int i = 0; i < ref->num_data && !bad; i += ref->data[i].header.length) {
+      const cairo_path_data_t *a = &ref->data[i], *b = &composed->data[i];
+      if (a->header.type != b->header.type || a->header.length != b->header.length)
+        bad = 1;
+      for (int k = 1; k < a->header.length && !bad; k++)
+        if (a[k].point.x != b[k].point.x || a[k].point.y != b[k].point.y)
+          bad = 1;
+    }
+  if (!bad && (e[0] != ext[0] || e[1] != ext[1] || e[2] != ext[2] || e[3] != ext[3]))
+    bad = 2;
+  if (bad) {
+    fprintf (stderr, "flutl_recorder: FLUTL_CHECK_PATHS: composed outline path differs from Cairo's "
+        "(%s; %d vs %d elements; extents %.10g %.10g %.10g %.10g vs %.10g %.10g %.10g %.10g; %u ops)\n",
+        bad == 2 ? "extents" : "elements", composed->num_data, ref ? ref->num_data : -1,
+        ext[0], ext[1], ext[2], ext[3], e[0], e[1], e[2], e[3], rec->n_ops);
+    abort ();
+  }
+  cairo_path_destroy (ref);
+  __atomic_fetch_add (&composed_paths_checked, 1, __ATOMIC_RELAXED);
+}
+
 /* The stroke of the pending ops, prepared here and drawn elsewhere: the job, or
  * NULL if there is nothing to draw (rb is valid either way).  Touches nothing the
  * resolving thread shares: called WITHOUT the recorder's lock -- building the path
@@ -2431,17 +2808,37 @@ stroke_defer_prepare (FlutlRecorder *rec, RasterBox *rb, int *exact)
 {
   cairo_t *cr = rec->cr;
   double px1, py1, px2, py2;
-  raster_build_path (rec, rb);
+  /* glyphs under translations: the path is composed, not built and copied out */
+  cairo_path_t *composed = NULL;
+  int composed_cap = 0;
+  {
+    double ext[4];
+    current_limits (rec, rb->lim);
+    if (!root_of (rec)->no_compose)
+      composed = compose_outline_path (rec, rb, ext, &composed_cap);
+    if (composed) {
+      px1 = ext[0];
+      py1 = ext[1];
+      px2 = ext[2];
+      py2 = ext[3];
+      if (root_of (rec)->check_paths)
+        composed_path_check (rec, rb, composed, ext);
+    }
+  }
+  if (!composed)
+    raster_build_path (rec, rb);
   /* cairo_stroke_extents runs the stroker over the whole path: 4x what building
    * the path costs, and the worker can do it.  What this thread must decide
    * now -- does the stroke meet its target at all (Cairo's "clear" bookkeeping,
    * stroke_emit), may it be reused under a translation -- follows from bounds of
    * the extents in all but contrived cases: the stroke covers its path and reaches
    * at most half a line width times the miter limit beyond it. */
-  cairo_save (cr);
-  cairo_identity_matrix (cr);
-  cairo_path_extents (cr, &px1, &py1, &px2, &py2);
-  cairo_restore (cr);
+  if (!composed) {
+    cairo_save (cr);
+    cairo_identity_matrix (cr);
+    cairo_path_extents (cr, &px1, &py1, &px2, &py2);
+    cairo_restore (cr);
+  }
   const double reach = 0.5 * cairo_get_line_width (cr) * fmax (cairo_get_miter_limit (cr), 1.0) + 2.0;
   int gx, gy;
   raster_origin (rec, &gx, &gy);
@@ -2458,6 +2855,10 @@ stroke_defer_prepare (FlutlRecorder *rec, RasterBox *rb, int *exact)
     double ex1, ey1, ex2, ey2;
     cairo_save (cr);
     cairo_identity_matrix (cr);
+    if (composed) {             /* (rare: Cairo needs the path after all) */
+      cairo_new_path (cr);
+      cairo_append_path (cr, composed);
+    }
     cairo_stroke_extents (cr, &ex1, &ey1, &ex2, &ey2);
     cairo_restore (cr);
     raster_box_from_extents (rb, ex1, ey1, ex2, ey2, rec->sw, rec->sh);
@@ -2482,6 +2883,8 @@ stroke_defer_prepare (FlutlRecorder *rec, RasterBox *rb, int *exact)
   }
   if (rb->bx1 <= rb->bx0 || rb->by1 <= rb->by0) {
     cairo_new_path (cr);
+    if (composed)
+      path_buffer_put (composed, composed_cap);
     return NULL;
   }
   StrokeJob *j = calloc (1, sizeof *j);
@@ -2493,10 +2896,15 @@ stroke_defer_prepare (FlutlRecorder *rec, RasterBox *rb, int *exact)
   cairo_get_matrix (cr, &j->ctm);
   j->line_width = cairo_get_line_width (cr);
   j->miter_limit = cairo_get_miter_limit (cr);
-  cairo_save (cr);
-  cairo_identity_matrix (cr);
-  j->path = cairo_copy_path (cr);
-  cairo_restore (cr);
+  if (composed) {
+    j->path = composed;
+    j->path_cap = composed_cap;
+  } else {
+    cairo_save (cr);
+    cairo_identity_matrix (cr);
+    j->path = cairo_copy_path (cr);
+    cairo_restore (cr);
+  }
   cairo_new_path (cr);
   if (!j->path || j->path->status != CAIRO_STATUS_SUCCESS)
     abort ();

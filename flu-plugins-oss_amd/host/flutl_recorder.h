@@ -131,6 +131,9 @@ void flutl_polygon_entry_free (FlutlPolygonEntry *pe);
 /* Outlines without a mask leave the worker threads as polygons for the device instead
  * of as coverage rasterised by Cairo (only where strokes are deferred, set_defer). */
 void flutl_recorder_set_device_strokes (FlutlRecorder *rec, int on);
+/* outline paths composed from cached glyph outlines instead of built by Cairo and copied
+ * out (process-wide); *checked: how many of them FLUTL_CHECK_PATHS compared with Cairo's */
+uint64_t flutl_recorder_composed_paths (uint64_t *checked);
 uint64_t flutl_recorder_polygon_jobs (void);
 
 /* atlas entries appended since the last call (for incremental upload);

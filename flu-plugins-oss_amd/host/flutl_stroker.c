@@ -1219,6 +1219,20 @@ box_add_curve_bound (Box *box, const Pt *p0, const Pt *p1, const Pt *p2, const P
   box_add_point (box, p3);
 }
 
+/* _cairo_box_add_curve_to for a caller that keeps a path's extents itself (the
+ * recorder's composed outline paths): box {x0, y0, x1, y1}, p = the curve's four points */
+void
+flutl_stroker_box_add_curve (int32_t box[4], const int32_t p[8])
+{
+  Box b = { { box[0], box[1] }, { box[2], box[3] } };
+  const Pt p0 = { p[0], p[1] }, p1 = { p[2], p[3] }, p2 = { p[4], p[5] }, p3 = { p[6], p[7] };
+  box_add_curve_bound (&b, &p0, &p1, &p2, &p3);
+  box[0] = b.p1.x;
+  box[1] = b.p1.y;
+  box[2] = b.p2.x;
+  box[3] = b.p2.y;
+}
+
 static void
 pf_add (PathFixed *pf, int op, const Pt *pts, int n)
 {

@@ -46,4 +46,8 @@ int flutl_stroke_to_polygon (const cairo_path_t *path, const cairo_matrix_t *ctm
  * extents rounded out.  0 for an empty polygon. */
 int flutl_polygon_box (const FlutlPolygon *pg, int box[4]);
 
+/* cairo_path_fixed_t.extents taking in a curve (_cairo_box_add_curve_to: its end points and
+ * its extreme points), 24.8 fixed point: box {x0, y0, x1, y1}, p the curve's four points */
+void flutl_stroker_box_add_curve (int32_t box[4], const int32_t p[8]);
+
 #endif

@@ -83,6 +83,7 @@ enum
  * "flutl-hip-device-frame" on the memory (valid once the memory has been mapped).
  * FLUTL_FULL_D2H=1 restores synchronous whole-frame copies into writable memory. */
 #define MAX_IN_FLIGHT 16           /* buffers handed out but not yet queued on the device */
+#define DEVICE_STROKES_AHEAD 6     /* ... with outlines made on the device (run_ahead) */
 #define VIDEO_CUES_AHEAD 64        /* fused over-video: cues the TTML side may be ahead of the video */
 #define POOL_MAX_FREE 24
 #define POOL_BUDGET_BYTES ((gsize) 640 << 20)   /* page-locked frames kept per element (+ twins in HBM) */
@@ -2787,8 +2788,15 @@ run_ahead (GstTTMLRenderPrivate *priv, gint width, gint height)
 {
   if (priv->max_ahead)
     return priv->max_ahead;
-  return (guint) CLAMP (POOL_BUDGET_BYTES / MAX ((gsize) width * height * 4, 1), 3,
+  const guint by_size = (guint) CLAMP (POOL_BUDGET_BYTES / MAX ((gsize) width * height * 4, 1), 3,
       MAX_IN_FLIGHT);
+  /* Round 3: an outline is a polygon after 0.3-0.45 ms on its worker and coverage 30 us
+   * later, not 3 ms of cairo_stroke: 6 buffers ahead cover that at 11 k buffers/s
+   * (tools/ahead_sweep.py: a long stream 10.5-11.8 k at 6, 11.1-11.5 k at 8, 11.4-11.7 k
+   * at 16), and every pool frame never used before costs its first write-back, a whole
+   * frame over PCIe -- a 120-cue stream ran at 10 k with 6 ahead and at 6 k with 16.
+   * (Outlines by Cairo on the workers, FLUTL_HOST_STROKES: the old depth.) */
+  return priv->host_strokes ? by_size : MIN (by_size, DEVICE_STROKES_AHEAD);
 }
 
 /* Hand a recorded frame to the finisher.  The lists are copied: the recorder's
@@ -3226,6 +3234,8 @@ timing_report (GstTTMLRender *render)
   flutl_recorder_prepare_stats (&pp, &pe);
   uint64_t we = 0, wd = 0, wc = 0;
   flutl_recorder_stroke_split (&we, &wd, &wc);
+  uint64_t composed_chk = 0;
+  const uint64_t composed_n = flutl_recorder_composed_paths (&composed_chk);   /* (process-wide) */
   pipeline_drain (render);
   if (priv->ctx) {
     flutl_ctx_sync (priv->ctx);
@@ -3237,7 +3247,7 @@ timing_report (GstTTMLRender *render)
   }
   g_printerr ("ttmlrender-hip timing: buffers=%u record_us=%.1f device_us=%.1f "
       "span_us=%" G_GINT64_FORMAT " drained_us=%" G_GINT64_FORMAT " delta_bytes=%.0f "
-      "deferred=%u resolve_wait_us=%.1f atlas_upload_us=%.1f build_us=%.1f layout_us=%.1f region_hits=%u region_misses=%u strokes=%u stroke_us=%.0f stroke_queued_us=%.0f pure_wait_us=%.0f submit_us=%.1f push_block_us=%.1f runs_merged=%u runs_clashed=%u path_us=%.0f extents_us=%.0f miss_us=%.1f recoloured=%u worker_extents_us=%.0f worker_draw_us=%.0f worker_crop_us=%.0f polygons=%u polygon_edges=%" G_GUINT64_FORMAT " polygons_sequential=%u t_first_us=%" G_GINT64_FORMAT " t_end_us=%" G_GINT64_FORMAT "\n",
+      "deferred=%u resolve_wait_us=%.1f atlas_upload_us=%.1f build_us=%.1f layout_us=%.1f region_hits=%u region_misses=%u strokes=%u stroke_us=%.0f stroke_queued_us=%.0f pure_wait_us=%.0f submit_us=%.1f push_block_us=%.1f runs_merged=%u runs_clashed=%u path_us=%.0f extents_us=%.0f miss_us=%.1f recoloured=%u worker_extents_us=%.0f worker_draw_us=%.0f worker_crop_us=%.0f polygons=%u polygon_edges=%" G_GUINT64_FORMAT " polygons_sequential=%u composed_paths=%" G_GUINT64_FORMAT " composed_checked=%" G_GUINT64_FORMAT " t_first_us=%" G_GINT64_FORMAT " t_end_us=%" G_GINT64_FORMAT "\n",
       priv->n_timed, (double) priv->t_record / MAX (priv->n_timed - 1, 1),
       (double) (priv->t_device + priv->t_submit) / MAX (priv->n_timed - 1, 1),
       priv->t_last_return - priv->t_first_return,
@@ -3255,6 +3265,7 @@ timing_report (GstTTMLRender *render)
       (double) priv->t_miss / MAX (priv->n_timed - 1, 1), priv->region_recoloured,
       sj ? (double) we / sj : 0.0, sj ? (double) wd / sj : 0.0, sj ? (double) wc / sj : 0.0,
       priv->n_polygons, priv->polygon_edges, priv->ctx ? flutl_ctx_scan_fallbacks (priv->ctx) : 0,
+      (guint64) composed_n, (guint64) composed_chk,
       /* (CLOCK_MONOTONIC: comparable across the elements and processes of one box) */
       priv->t_first_return, MAX (t_drained, priv->t_last_return));
   priv->t_push_block = 0;

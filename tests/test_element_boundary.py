@@ -190,3 +190,23 @@ def test_video_mode_leaves_the_src_caps_to_the_video(tmp_path):
         assert len(src_caps) == 1 and "framerate=(fraction)3/1" in src_caps[0], src_caps
         # (record-only: cues are made, the frames pass through unchanged)
         assert open(out, "rb").read() == want, f"run {run}"
+
+
+@pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
+                    reason="fluttml-hip plugin / GStreamer runtime not present")
+def test_composed_outline_paths_are_the_paths_cairo_builds():
+    """An outline's path is composed from glyph outlines taken from Cairo once (the
+    recorder's "composed outline paths") instead of built on a context and copied out of
+    it for every cue.  FLUTL_CHECK_PATHS=1 builds every such path both ways inside the
+    element and aborts on any difference, element by element and in the path's extents:
+    a stream with new outlined text in every cue (120 cues, 96 px DejaVu Sans at 4K) and
+    the animated 8-region document, record-only (no device needed), strokes deferred to
+    the workers as in the real pipeline."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import e2e_timing
+    for doc, strokes in (("typical_4k", 120), ("cfg2", 8)):
+        r = e2e_timing.measure(os.path.join(ROOT, "bench_data", doc + ".ttml"), 3840, 2160, extra_env={
+            "FLUTL_DUMP_ONLY": "1", "FLUTL_DUMP_PACK": os.devnull, "FLUTL_DUMP_DEFER": "1",
+            "FLUTL_CHECK_PATHS": "1"})
+        assert r["strokes"] == strokes
+        assert r["composed_paths"] == strokes and r["composed_checked"] == strokes

@@ -17,6 +17,9 @@
 #include <sys/syscall.h>
 #include <sys/time.h>
 #include <unistd.h>
+#include <dirent.h>
+#include <pthread.h>
+#include <time.h>
 
 #define MAX_SAMPLES (1 << 16)
 #define DEPTH 192
@@ -44,6 +47,60 @@ on_tick (int sig, siginfo_t *si, void *uc)
   samples[i].n = DEPTH;
 }
 
+
+static volatile int sampler_stop;
+
+static int
+find_threads (const char *name, int *tids, int max)
+{
+  int n = 0;
+  DIR *d = opendir ("/proc/self/task");
+  struct dirent *e;
+  while (d && (e = readdir (d)) && n < max) {
+    char path[320], comm[64] = "";
+    if (e->d_name[0] < '0' || e->d_name[0] > '9')
+      continue;
+    snprintf (path, sizeof path, "/proc/self/task/%s/comm", e->d_name);
+    FILE *f = fopen (path, "r");
+    if (f) {
+      if (fgets (comm, sizeof comm, f) && strstr (comm, name))
+        tids[n++] = atoi (e->d_name);
+      fclose (f);
+    }
+  }
+  if (d)
+    closedir (d);
+  return n;
+}
+
+static void *
+sampler_main (void *arg)
+{
+  const long us = *(long *) arg;
+  const char *name = getenv ("SPROF_THREAD");
+  const int pid = getpid ();
+  int tids[16], n = 0, since = 1 << 30;
+  sigset_t all;
+  sigfillset (&all);
+  pthread_sigmask (SIG_BLOCK, &all, NULL);
+  if (getenv ("SPROF_DELAY_MS")) {      /* (the HIP runtime's start-up does not survive signals) */
+    struct timespec d = { atol (getenv ("SPROF_DELAY_MS")) / 1000, atol (getenv ("SPROF_DELAY_MS")) % 1000 * 1000000L };
+    nanosleep (&d, NULL);
+  }
+  while (!sampler_stop) {
+    struct timespec ts = { 0, us * 1000 };
+    if (since * us > 20000) {           /* (threads come and go) */
+      n = find_threads (name, tids, 16);
+      since = 0;
+    }
+    for (int i = 0; i < n; i++)
+      syscall (SYS_tgkill, pid, tids[i], SIGPROF);
+    nanosleep (&ts, NULL);
+    since++;
+  }
+  return NULL;
+}
+
 __attribute__ ((constructor)) static void
 sprof_start (void)
 {
@@ -57,6 +114,16 @@ sprof_start (void)
   sigaction (SIGPROF, &sa, NULL);
   const char *hz = getenv ("SPROF_HZ");
   long us = 1000000 / (hz ? atol (hz) : 1000);
+  if (getenv ("SPROF_THREAD")) {
+    /* wall-clock samples of the threads of that name only, sent by a thread of our own
+     * (ITIMER_PROF ticks with the scheduler: a few hundred a second, anywhere) */
+    static long period_us;
+    pthread_t t;
+    period_us = us;
+    pthread_create (&t, NULL, sampler_main, &period_us);
+    pthread_detach (t);
+    return;
+  }
   struct itimerval it = { { 0, us }, { 0, us } };
   setitimer (ITIMER_PROF, &it, NULL);
 }
@@ -69,6 +136,7 @@ sprof_stop (void)
     return;
   struct itimerval off = { { 0, 0 }, { 0, 0 } };
   setitimer (ITIMER_PROF, &off, NULL);
+  sampler_stop = 1;
   FILE *f = fopen (out, "w");
   if (!f)
     return;

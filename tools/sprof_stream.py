@@ -37,7 +37,7 @@ def main():
     document(cues, doc)
     so = os.path.join(tmp, "sprof.so")
     subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", os.path.join(ROOT, "tools", "sprof.c"),
-                           "-o", so])
+                           "-o", so, "-lpthread"])
     runs = int(sys.argv[3]) if len(sys.argv) > 3 else 8
     print(E.measure(doc, 3840, 2160), flush=True)            # (warm, and the rate without the profiler)
     pre = gstenv.env_for(gstenv.HIP_PLUGIN_DIR).get("LD_PRELOAD", "")
@@ -45,7 +45,8 @@ def main():
     for r in range(runs):
         outs.append(os.path.join(tmp, f"sprof{r}.txt"))
         print(E.measure(doc, 3840, 2160, extra_env={"LD_PRELOAD": (pre + ":" + so).strip(":"),
-                                                     "SPROF_OUT": outs[-1]}), flush=True)
+                                                     "SPROF_OUT": outs[-1], "SPROF_THREAD": "filesrc",
+                                                     "SPROF_HZ": "5000", "SPROF_DELAY_MS": "900"}), flush=True)
     # (the base class sorts spans in by insertion, O(cues^2): the parse is left out)
     subprocess.call([sys.executable, os.path.join(ROOT, "tools", "sprof_report.py"), *outs, "top=" + top,
                      "under=gst_ttmlrender_gen_buffer"])
