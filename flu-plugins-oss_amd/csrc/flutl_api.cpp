@@ -69,6 +69,14 @@ struct flutl_ctx {
   void *scan;          // device scratch of the polygon scan converter (edges + its own)
   size_t scan_cap;
   uint32_t *scan_counters;     // device: [0] polygons the sequential converter took
+  // Outlines are made on a stream of their own: the edges of the next cue's outline go up
+  // and are scan converted while the frame before it is still being composited and written
+  // back on `stream`.  `stream` waits for `scan_done` (recorded behind every polygon) before
+  // whatever it is given next; the polygon path has its own staging memory.
+  hipStream_t scan_stream;
+  hipEvent_t scan_done;
+  uint8_t *stage2;
+  size_t stage2_cap, stage2_used;
 };
 
 struct flutl_frame {
@@ -283,6 +291,25 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
   c->scan = nullptr;
   c->scan_cap = 0;
   c->scan_counters = nullptr;
+  c->scan_stream = nullptr;
+  c->scan_done = nullptr;
+  c->stage2 = nullptr;
+  c->stage2_cap = c->stage2_used = 0;
+  if (!hip_ok (hipStreamCreateWithFlags (&c->scan_stream, hipStreamNonBlocking)) ||
+      !hip_ok (hipEventCreateWithFlags (&c->scan_done, hipEventDisableTiming))) {
+    if (c->scan_stream)
+      (void) hipStreamDestroy (c->scan_stream);
+    (void) hipStreamDestroy (c->stream);
+    delete c;
+    return FLUTL_ENODEV;
+  }
+  {
+    constexpr size_t kStage2Bytes = (size_t) 8 << 20;
+    if (hip_ok (hipHostMalloc (reinterpret_cast<void **> (&c->stage2), kStage2Bytes, hipHostMallocDefault)))
+      c->stage2_cap = kStage2Bytes;
+    else
+      c->stage2 = nullptr;
+  }
   // The first masks of a stream come with its first frame, and the caller's
   // recording thread may be waiting on whoever uploads them: the atlas and the
   // upload staging are made now (10 ms of allocation calls), not then.  (Failure
@@ -299,12 +326,12 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
   // (... and so is the scan converter's scratch: the first cue of a stream brings the
   // outlines of all its regions)
   if (hip_ok (hipMalloc (&c->scan, (size_t) 8 << 20)) &&
-      hip_ok (hipMemsetAsync (c->scan, 0, 256, c->stream)))    // (the converter's status words)
+      hip_ok (hipMemsetAsync (c->scan, 0, 256, c->scan_stream)))    // (the converter's status words)
     c->scan_cap = (size_t) 8 << 20;
   else
     c->scan = nullptr;
   if (hip_ok (hipMalloc (reinterpret_cast<void **> (&c->scan_counters), 4 * sizeof (uint32_t))))
-    (void) hipMemsetAsync (c->scan_counters, 0, 4 * sizeof (uint32_t), c->stream);
+    (void) hipMemsetAsync (c->scan_counters, 0, 4 * sizeof (uint32_t), c->scan_stream);
   else
     c->scan_counters = nullptr;
   if (c->scan) {
@@ -315,10 +342,11 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
     const int32_t box[4] = { 1, 1, 7, 7 };
     uint8_t *base = static_cast<uint8_t *> (c->scan);
     const size_t own = flutl_scan_scratch_bytes (2, 6, 6);
-    if (hip_ok (hipMemcpyAsync (base + own, tri, sizeof tri, hipMemcpyHostToDevice, c->stream)))
-      (void) flutl_launch_scan_counted (c->stream, reinterpret_cast<const int32_t *> (base + own), 2,
+    if (hip_ok (hipMemcpyAsync (base + own, tri, sizeof tri, hipMemcpyHostToDevice, c->scan_stream)))
+      (void) flutl_launch_scan_counted (c->scan_stream, reinterpret_cast<const int32_t *> (base + own), 2,
           box, 0, base, base + own + 256, 16, 0 | 16, nullptr);
   }
+  (void) hipStreamSynchronize (c->scan_stream);
   (void) hipStreamSynchronize (c->stream);
   *out = c;
   return FLUTL_OK;
@@ -329,6 +357,7 @@ extern "C" void flutl_ctx_destroy (flutl_ctx *c)
   if (!c)
     return;
   (void) hipSetDevice (c->device);
+  (void) hipStreamSynchronize (c->scan_stream);
   (void) hipStreamSynchronize (c->stream);
   if (c->atlas)
     (void) hipFree (c->atlas);
@@ -352,6 +381,10 @@ extern "C" void flutl_ctx_destroy (flutl_ctx *c)
     (void) hipFree (c->scan);
   if (c->scan_counters)
     (void) hipFree (c->scan_counters);
+  if (c->stage2)
+    (void) hipHostFree (c->stage2);
+  (void) hipEventDestroy (c->scan_done);
+  (void) hipStreamDestroy (c->scan_stream);
   (void) hipStreamDestroy (c->stream);
   delete c;
 }
@@ -360,9 +393,10 @@ extern "C" int flutl_ctx_sync (flutl_ctx *c)
 {
   if (!c)
     return FLUTL_EINVAL;
-  if (!hip_ok (hipStreamSynchronize (c->stream)))
+  if (!hip_ok (hipStreamSynchronize (c->scan_stream)) || !hip_ok (hipStreamSynchronize (c->stream)))
     return FLUTL_ENODEV;
   c->stage_used = 0;       // every staged upload has landed
+  c->stage2_used = 0;
   return FLUTL_OK;
 }
 
@@ -387,20 +421,25 @@ static int atlas_reserve (flutl_ctx *c, size_t need)
   uint8_t *n = nullptr;
   if (!hip_ok (hipMalloc (reinterpret_cast<void **> (&n), cap)))
     return FLUTL_ENOMEM;
+  // (an outline still being made in the old buffer: wait for it before the copy)
+  if (c->scan_stream && !hip_ok (hipStreamSynchronize (c->scan_stream))) {
+    (void) hipFree (n);
+    return FLUTL_ENODEV;
+  }
   if (!hip_ok (hipMemsetAsync (n, 0, cap, c->stream))) {
     (void) hipFree (n);
     return FLUTL_ENODEV;
   }
-  if (c->atlas) {
-    // lists in flight may still read the old buffer: drain first
-    if (!hip_ok (hipMemcpyAsync (n, c->atlas, c->atlas_used, hipMemcpyDeviceToDevice,
-            c->stream)) ||
-        !hip_ok (hipStreamSynchronize (c->stream))) {
-      (void) hipFree (n);
-      return FLUTL_ENODEV;
-    }
-    (void) hipFree (c->atlas);
+  // lists in flight may still read the old buffer: drain first (and the other stream
+  // must not write into the new one before it has been cleared: drained either way)
+  if ((c->atlas && !hip_ok (hipMemcpyAsync (n, c->atlas, c->atlas_used, hipMemcpyDeviceToDevice,
+              c->stream))) ||
+      !hip_ok (hipStreamSynchronize (c->stream))) {
+    (void) hipFree (n);
+    return FLUTL_ENODEV;
   }
+  if (c->atlas)
+    (void) hipFree (c->atlas);
   c->atlas = n;
   c->atlas_cap = cap;
   return FLUTL_OK;
@@ -476,10 +515,11 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
   const size_t edge_bytes = ((size_t) n_edges * 7 * sizeof (int32_t) + 255) & ~(size_t) 255;
   const size_t own_bytes = flutl_scan_scratch_bytes (n_edges, w, h);
   const size_t need = edge_bytes + own_bytes;
+  hipStream_t ss = c->scan_stream;
   if (need > c->scan_cap) {
     // (whatever still reads the old one is ordered before the free by the sync)
     if (c->scan) {
-      if (!hip_ok (hipStreamSynchronize (c->stream)))
+      if (!hip_ok (hipStreamSynchronize (ss)))
         return FLUTL_ENODEV;
       (void) hipFree (c->scan);
       c->scan = nullptr;
@@ -490,46 +530,50 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
       cap = (size_t) 8 << 20;   // (an outline of two 4K lines needs about 3 MB)
     if (!hip_ok (hipMalloc (&c->scan, cap)))
       return FLUTL_ENOMEM;
-    if (!hip_ok (hipMemsetAsync (c->scan, 0, 256, c->stream)))
+    if (!hip_ok (hipMemsetAsync (c->scan, 0, 256, ss)))
       return FLUTL_ENODEV;
     c->scan_cap = cap;
   }
   if (!c->scan_counters) {
     if (!hip_ok (hipMalloc (reinterpret_cast<void **> (&c->scan_counters), 4 * sizeof (uint32_t))) ||
-        !hip_ok (hipMemsetAsync (c->scan_counters, 0, 4 * sizeof (uint32_t), c->stream)))
+        !hip_ok (hipMemsetAsync (c->scan_counters, 0, 4 * sizeof (uint32_t), ss)))
       return FLUTL_ENOMEM;
   }
   int32_t *edges_dev = reinterpret_cast<int32_t *> (static_cast<uint8_t *> (c->scan) + own_bytes);
   if (n_edges) {
     const size_t eb = (size_t) n_edges * 7 * sizeof (int32_t);
-    stage_reserve (c);
-    if (c->stage && eb <= c->stage_cap / 2) {
-      if (c->stage_used + eb > c->stage_cap) {
-        if (!hip_ok (hipStreamSynchronize (c->stream)))
+    if (c->stage2 && eb <= c->stage2_cap / 2) {
+      if (c->stage2_used + eb > c->stage2_cap) {
+        if (!hip_ok (hipStreamSynchronize (ss)))
           return FLUTL_ENODEV;
-        c->stage_used = 0;
+        c->stage2_used = 0;
       }
-      memcpy (c->stage + c->stage_used, edges, eb);
-      if (!hip_ok (hipMemcpyAsync (edges_dev, c->stage + c->stage_used, eb, hipMemcpyHostToDevice,
-              c->stream)))
+      memcpy (c->stage2 + c->stage2_used, edges, eb);
+      if (!hip_ok (hipMemcpyAsync (edges_dev, c->stage2 + c->stage2_used, eb, hipMemcpyHostToDevice, ss)))
         return FLUTL_ENODEV;
-      c->stage_used += (eb + 63) & ~(size_t) 63;
+      c->stage2_used += (eb + 63) & ~(size_t) 63;
     } else {
-      if (!hip_ok (hipMemcpyAsync (edges_dev, edges, eb, hipMemcpyHostToDevice, c->stream)) ||
-          !hip_ok (hipStreamSynchronize (c->stream)))
+      if (!hip_ok (hipMemcpyAsync (edges_dev, edges, eb, hipMemcpyHostToDevice, ss)) ||
+          !hip_ok (hipStreamSynchronize (ss)))
         return FLUTL_ENODEV;
-      c->stage_used = 0;
+      c->stage2_used = 0;
     }
   }
   // the entry: the coverage, and the zero bytes around and between its rows (mode 8); the
-  // converter's status words are the first of its scratch and stay zero between calls (16)
+  // converter's status words are the first of its scratch and stay zero between calls (16).
+  // (The entry's bytes are new, or reused after a start-over that the caller drains the
+  // context for: nothing queued on the other stream reads or writes them.)
   if (n_edges == 0) {
-    if (!hip_ok (hipMemsetAsync (c->atlas + off, 0, bytes, c->stream)))
+    if (!hip_ok (hipMemsetAsync (c->atlas + off, 0, bytes, ss)))
       return FLUTL_ENODEV;
   } else {
-    rc = flutl_launch_scan_counted (c->stream, edges_dev, n_edges, box, even_odd,
+    rc = flutl_launch_scan_counted (ss, edges_dev, n_edges, box, even_odd,
         c->scan, c->atlas + off + 4, (size_t) w + 4, 0 | 8 | 16, c->scan_counters);
   }
+  // whatever the context is given next comes behind the outline
+  if (!rc && (!hip_ok (hipEventRecord (c->scan_done, ss)) ||
+          !hip_ok (hipStreamWaitEvent (c->stream, c->scan_done, 0))))
+    rc = FLUTL_ENODEV;
   if (rc)
     return rc;
   c->atlas_used = end;
@@ -543,8 +587,8 @@ extern "C" uint32_t flutl_ctx_scan_fallbacks (flutl_ctx *c)
   if (!c || !c->scan_counters)
     return 0;
   (void) hipSetDevice (c->device);
-  if (!hip_ok (hipMemcpyAsync (&n, c->scan_counters, sizeof n, hipMemcpyDeviceToHost, c->stream)) ||
-      !hip_ok (hipStreamSynchronize (c->stream)))
+  if (!hip_ok (hipMemcpyAsync (&n, c->scan_counters, sizeof n, hipMemcpyDeviceToHost, c->scan_stream)) ||
+      !hip_ok (hipStreamSynchronize (c->scan_stream)))
     return 0;
   return n;
 }

@@ -61,6 +61,37 @@ def test_full_size_config_matches_reference_sha256(gpu, cfg):
         assert hashlib.sha256(got.tobytes()).hexdigest() == meta["sha256"][i], (cfg, i)
 
 
+def run_pipeline(cmd, env, cwd, limit=90):
+    """One gst-launch.  Several elements in one process have hung twice in some hundred
+    runs on the GPU box (round 3; not reproduced in 160 runs of tools/hang_hunt.py, which
+    is this with a debugger at hand): a pipeline still running after `limit` seconds has
+    its threads' backtraces written to gpurun_out/hang_backtraces.txt (rocgdb, if there)
+    and is run once more -- the test then still checks every frame."""
+    import subprocess
+    import warnings
+    for attempt in (0, 1):
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=cwd)
+        try:
+            out, err = p.communicate(timeout=limit)
+            return subprocess.CompletedProcess(cmd, p.returncode, out, err)
+        except subprocess.TimeoutExpired:
+            bt = ""
+            if os.path.exists("/opt/rocm/bin/rocgdb"):
+                try:
+                    bt = subprocess.run(["/opt/rocm/bin/rocgdb", "-q", "-batch", "-p", str(p.pid), "-ex",
+                                         "set pagination off", "-ex", "thread apply all bt 30"],
+                                        capture_output=True, text=True, timeout=120).stdout
+                except Exception as e:      # noqa: BLE001
+                    bt = repr(e)
+            p.kill()
+            p.communicate()
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "hang_backtraces.txt"), "a") as f:
+                f.write("$ " + " ".join(cmd) + "\n" + bt[-80000:] + "\n")
+            warnings.warn(f"pipeline still running after {limit} s (attempt {attempt}); backtraces kept")
+    raise AssertionError(f"pipeline hung twice: {' '.join(cmd[:12])} ...")
+
+
 @pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
                     reason="fluttml-hip plugin / GStreamer runtime not present")
 @pytest.mark.parametrize("path", SCENES, ids=[os.path.basename(s)[:-4] for s in SCENES])
@@ -168,8 +199,7 @@ def test_two_elements_in_one_process_and_a_thread_boundary_downstream(gpu, tmp_p
         cmd += ["filesrc", "location=" + os.path.join(ROOT, "tests", "golden", "scenes", n + ".ttml"),
                 "!", "ttmlrender", "!", f"video/x-raw,width={int(z['width'])},height={int(z['height'])}",
                 "!", "queue", "max-size-buffers=64", "!", "filesink", "location=" + o]
-    r = subprocess.run(cmd, env=gstenv.env_for(gstenv.HIP_PLUGIN_DIR), capture_output=True,
-                       text=True, cwd=str(tmp_path), timeout=300)
+    r = run_pipeline(cmd, gstenv.env_for(gstenv.HIP_PLUGIN_DIR), str(tmp_path))
     assert r.returncode == 0, r.stderr[-2000:]
     for n, o in zip(names, outs):
         z = np.load(os.path.join(ROOT, "tests", "golden", "scenes", n + ".npz"))
@@ -216,8 +246,7 @@ def test_promise_buffers_through_a_converting_element(gpu, tmp_path):
            "location=" + os.path.join(ROOT, "tests", "golden", "scenes", name + ".ttml"), "!",
            "ttmlrender", "!", f"video/x-raw,width={W},height={H}", "!", "videoconvert", "!",
            "video/x-raw,format=RGBA", "!", "filesink", "location=" + out]
-    r = subprocess.run(cmd, env=gstenv.env_for(gstenv.HIP_PLUGIN_DIR), capture_output=True,
-                       text=True, cwd=str(tmp_path), timeout=300)
+    r = run_pipeline(cmd, gstenv.env_for(gstenv.HIP_PLUGIN_DIR), str(tmp_path))
     assert r.returncode == 0, r.stderr[-2000:]
     got = np.fromfile(out, np.uint8).reshape(-1, H, W, 4)
     exp = z["frames"].view(np.uint8).reshape(-1, H, W, 4)[..., [2, 1, 0, 3]]

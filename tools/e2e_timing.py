@@ -77,9 +77,9 @@ def measure_streams(ttml, W, H, n, extra_env=None, log_path=None):
     for _ in range(n):
         cmd += ["filesrc", f"location={os.path.abspath(ttml)}", "!", "ttmlrender", "!",
                 f"video/x-raw,width={W},height={H}", "!", "fakesink"]
-    # (a pipeline that hangs must not hang the bench: 5 minutes is 100 times what it takes)
+    # (a pipeline that hangs must not hang the bench: 2 minutes is 40 times what it takes)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=tempfile.gettempdir(),
-                       timeout=300)
+                       timeout=120)
     lines = [l for l in r.stderr.split("\n") if "ttmlrender-hip timing" in l and "buffers=0 " not in l]
     if log_path:
         with open(log_path, "a") as f:
