@@ -2661,7 +2661,9 @@ compose_outline_path (FlutlRecorder *rec, const RasterBox *rb, double ext[4], in
   if (rec->n_ops == 0)
     return NULL;
   /* pass 1: every op must be composable; how many elements */
-  GlyphOutline **outs = g_newa (GlyphOutline *, rec->n_ops);
+  GlyphOutline **outs = rec->n_ops <= 2048 ? g_newa (GlyphOutline *, rec->n_ops) : NULL;
+  if (!outs)
+    return NULL;                /* (a path of thousands of glyphs: Cairo's way) */
   for (uint32_t i = 0; i < rec->n_ops; i++) {
     const PathOp *op = &rec->ops[i];
     if (!op->font || op->sfont)

@@ -214,9 +214,12 @@ def test_two_elements_in_one_process_and_a_thread_boundary_downstream(gpu, tmp_p
                                    {"FLUTL_FULL_D2H": "1"}, {"FLUTL_POOL_PREFILL": "0"},
                                    {"FLUTL_NO_SPAN_PLANS": "1", "FLUTL_NO_RUN_MERGE": "1"},
                                    {"FLUTL_QUEUE_ALWAYS": "1", "FLUTL_NO_LAYOUT_CACHE": "1"},
-                                   {"FLUTL_NO_RECOLOUR": "1"}],
+                                   {"FLUTL_NO_RECOLOUR": "1"}, {"FLUTL_HOST_STROKES": "1"},
+                                   {"FLUTL_NO_COMPOSED_PATHS": "1"},
+                                   {"FLUTL_CHECK_PATHS": "1", "FLUTL_MAX_AHEAD": "16"}],
                          ids=["sync", "no-region-cache", "ahead1", "full-d2h", "no-prefill",
-                              "no-plans-no-merge", "queue-always", "no-recolour"])
+                              "no-plans-no-merge", "queue-always", "no-recolour", "host-strokes",
+                              "paths-by-cairo", "paths-checked-ahead16"])
 def test_element_modes_all_reproduce_the_reference(gpu, knobs):
     """The element's pipeline knobs change how a buffer is produced, never what it
     holds: an outlined, animated scene and a moving outline under each of them."""
