@@ -498,7 +498,7 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
     const int32_t box[4], int even_odd, uint32_t *offset_out)
 {
   if (!c || !offset_out || !box || (n_edges && !edges) || box[2] <= box[0] || box[3] <= box[1] ||
-      box[0] < 0 || box[1] < 0 || box[2] - box[0] > 4096 || box[3] - box[1] > 32767)
+      box[0] < 0 || box[1] < 0 || box[2] - box[0] > 32767 || box[3] - box[1] > 32767)
     return FLUTL_EINVAL;
   (void) hipSetDevice (c->device);
   const uint32_t w = (uint32_t) (box[2] - box[0]), h = (uint32_t) (box[3] - box[1]);
@@ -513,7 +513,11 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
   // scratch: the converter's own (its status words first: they are zero between calls),
   // then the edges
   const size_t edge_bytes = ((size_t) n_edges * 7 * sizeof (int32_t) + 255) & ~(size_t) 255;
-  const size_t own_bytes = flutl_scan_scratch_bytes (n_edges, w, h);
+  // (the converter takes boxes of up to 4096 pixels' width: a wider entry -- a line of 8K
+  // text -- is converted in column windows, which is the same coverage: the conversion of
+  // a window is the crop of the conversion of the whole, tests/test_gpu_scan.py)
+  constexpr uint32_t kWindow = 4096;
+  const size_t own_bytes = flutl_scan_scratch_bytes (n_edges, w < kWindow ? w : kWindow, h);
   const size_t need = edge_bytes + own_bytes;
   hipStream_t ss = c->scan_stream;
   if (need > c->scan_cap) {
@@ -567,8 +571,15 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
     if (!hip_ok (hipMemsetAsync (c->atlas + off, 0, bytes, ss)))
       return FLUTL_ENODEV;
   } else {
-    rc = flutl_launch_scan_counted (ss, edges_dev, n_edges, box, even_odd,
-        c->scan, c->atlas + off + 4, (size_t) w + 4, 0 | 8 | 16, c->scan_counters);
+    for (uint32_t x = 0; x < w && !rc; x += kWindow) {
+      const uint32_t ww = w - x < kWindow ? w - x : kWindow;
+      const int32_t wbox[4] = { box[0] + (int32_t) x, box[1], box[0] + (int32_t) (x + ww), box[3] };
+      // (a window zeroes the 4 bytes after each of its rows; those of all but the last
+      // window are the next window's first pixels, written behind it in stream order)
+      const int pad = x == 0 ? 8 : (x + ww == w ? 32 : 0);
+      rc = flutl_launch_scan_counted (ss, edges_dev, n_edges, wbox, even_odd,
+          c->scan, c->atlas + off + 4 + x, (size_t) w + 4, 0 | pad | 16, c->scan_counters);
+    }
   }
   // whatever the context is given next comes behind the outline
   if (!rc && (!hip_ok (hipEventRecord (c->scan_done, ss)) ||

@@ -1774,7 +1774,7 @@ scan_rows_kernel (const ScanEdge *__restrict__ edges, const int2 *__restrict__ s
   if (pad_zero && tid < 4) {
     // the MASK layout's zero bytes: 4 after every row, 4 in front of the first
     dst[(size_t) blockIdx.x * dst_stride + width + tid] = 0;
-    if (blockIdx.x == 0)
+    if (blockIdx.x == 0 && pad_zero == 1)
       *(dst - 4 + tid) = 0;
   }
   if (!with_sequential)
@@ -1846,7 +1846,7 @@ extern "C" int flutl_launch_scan_counted (void *stream_, const int32_t *edges_de
   const int xmin = box[0], ymin = box[1], xmax = box[2], ymax = box[3];
   if (!dst || xmax <= xmin || ymax <= ymin || xmin < 0 || xmax > (1 << 22) || ymin < 0 ||
       ymax > (1 << 22) || (n_edges && (!edges_dev || !scratch)) ||
-      dst_stride < (size_t) (xmax - xmin) || mode < 0 || (mode & 7) > 2 || mode > 31)
+      dst_stride < (size_t) (xmax - xmin) || mode < 0 || (mode & 7) > 2 || mode > 63)
     return FLUTL_EINVAL;
   const uint32_t width = (uint32_t) (xmax - xmin), height = (uint32_t) (ymax - ymin);
   if (width > (uint32_t) kMaxWidth || height > 65535u || n_edges > (1u << 24))
@@ -1874,7 +1874,9 @@ extern "C" int flutl_launch_scan_counted (void *stream_, const int32_t *edges_de
   // (library internal, flutl_atlas_put_polygon: 8 = the MASK layout's zero bytes are the
   // rows' to write, 16 = the scratch's first 16 bytes are zero -- made so once, and left so
   // by every conversion)
-  const int pad_zero = mode & 8 ? 1 : 0, clean = mode & 16 ? 1 : 0;
+  // (... 32 = only the zero bytes after every row: the last of the column windows a wide
+  // entry is converted in)
+  const int pad_zero = mode & 8 ? 1 : (mode & 32 ? 2 : 0), clean = mode & 16 ? 1 : 0;
   mode &= 7;
   if (mode != 2) {
     // (the "rows done" counter must start at zero: a scratch buffer of unknown content)

@@ -325,7 +325,8 @@ int  flutl_atlas_put_blurred (flutl_ctx *ctx, uint32_t w, uint32_t h,
  * n_edges x 7 int32 {p1.x, p1.y, p2.x, p2.y, top, bottom, dir} in 24.8 fixed point
  * (a cairo_edge_t), box = {x0, y0, x1, y1} in pixels is where Cairo converts (the
  * polygon's extents within surface, clip and approximate stroke extents;
- * 0 <= x0 < x1 <= x0 + 4096).  The coverage becomes a NEW ATLAS ENTRY in the layout
+ * 0 <= x0 < x1 <= x0 + 32767; wider than 4096 it is converted in column windows, the
+ * same coverage).  The coverage becomes a NEW ATLAS ENTRY in the layout
  * MASK primitives read: 4 zero bytes, then box height rows of (width + 4) bytes, each
  * width coverage bytes + 4 zero bytes; *offset_out is the entry's offset (pixel (0,0)
  * of the box is at offset + 4).  Bit exact with Cairo 1.16 for any polygon, also

@@ -196,3 +196,51 @@ def test_polygon_becomes_an_atlas_entry_masks_can_read(gpu):
     P2["a"] = F.ATLAS_SLACK + 4
     want = gpu_util.hip_render(W, H, R, P2, atlas)
     assert np.array_equal(got, want)
+
+
+def test_a_window_of_the_box_is_the_crop_of_the_whole_and_wide_entries_use_that(gpu):
+    """The converter's boxes are at most 4096 pixels wide (a row's accumulators live in
+    LDS); flutl_atlas_put_polygon converts a wider entry -- a line of 8K text -- in column
+    windows.  That is the same coverage because the conversion of a window is the crop of
+    the conversion of the whole box (checked here against the oracle for windows of a
+    committed text stroke), and an entry 9 100 pixels wide must read back as the oracle's
+    conversion of the whole box."""
+    torch = gpu
+    i, kind, box, eo, edges, cov = next(p for p in _polygons() if p[1] == 2)
+    rng = np.random.default_rng(11)
+    for _ in range(6):
+        a = int(rng.integers(box[0], box[2] - 4))
+        b = int(rng.integers(a + 2, box[2] + 1))
+        got, _ = hip_scan(torch, edges, (a, box[1], b, box[3]), eo, mode=0)
+        assert np.array_equal(got, cov[:, a - box[0]:b - box[0]])
+    # a wide polygon: random, vertices beyond the box
+    W, H = 9100, 14
+    wide = _random_polygon(np.random.default_rng(5), W, H, 1200, 1)
+    want = O.scan_polygon(wide, (0, 0, W, H), False)
+    import gpu_util
+    FW, FH = W + 8, H + 8
+    R = np.zeros(1, F.REGION_DTYPE)
+    R["x0"], R["y0"], R["x1"], R["y1"], R["first"], R["count"] = 0, 0, W, H, 0, 1
+    P = np.zeros(1, F.PRIM_DTYPE)
+    P["op"], P["rule"] = F.OP_MASK, F.RULE_LERP
+    P["cx0"], P["cy0"], P["cx1"], P["cy1"] = 0, 0, W, H
+    P["color"] = 0xFF000000
+    with F.Context(0) as ctx:
+        off = ctx.atlas_put_polygon(wide, (0, 0, W, H), False)
+        fr = ctx.frame(FW, FH)
+        try:
+            P["a"], P["b"], P["c"], P["d"] = off + 4, W + 4, 0, 0
+            fr.submit(R, P)
+            fr.wait()
+            got = fr.host().copy()
+        finally:
+            fr.close()
+    # the oracle's coverage of the whole box as a mask uploaded from the host
+    padded = np.zeros((H, W + 4), np.uint8)
+    padded[:, :W] = want
+    atlas = np.concatenate([np.zeros(F.ATLAS_SLACK + 4, np.uint8), padded.ravel(),
+                            np.zeros(F.ATLAS_SLACK, np.uint8)])
+    P2 = P.copy()
+    P2["a"] = F.ATLAS_SLACK + 4
+    assert np.array_equal(got, gpu_util.hip_render(FW, FH, R, P2, atlas))
+    assert int((want > 0).sum()) > 10000

@@ -260,15 +260,19 @@ def test_promise_buffers_through_a_converting_element(gpu, tmp_path):
                     reason="fluttml-hip plugin / GStreamer runtime not present")
 @pytest.mark.parametrize("doc,knobs", [("cfg2", {}), ("typical_4k", {}),
                                        ("cfg2", {"FLUTL_QUEUE_ALWAYS": "1"}),
-                                       ("typical_4k", {"FLUTL_SYNC": "1"})],
-                         ids=["cfg2", "typical_4k", "cfg2-queued", "typical_4k-sync"])
+                                       ("typical_4k", {"FLUTL_SYNC": "1"}),
+                                       ("wide_8k", {}), ("wide_8k", {"FLUTL_SYNC": "1"})],
+                         ids=["cfg2", "typical_4k", "cfg2-queued", "typical_4k-sync", "wide_8k",
+                              "wide_8k-sync"])
 def test_element_at_full_size_is_the_reference_s(gpu, doc, knobs):
     """The documents bench.py's end-to-end figures are measured on, through the real
     pipeline at 3840x2160 (`filesrc ! ttmlrender ! caps ! fdsink`, frames read from the
     pipe): SHA-256 of EVERY frame equals that of the frame the reference plugin rendered
     from the same TTML (bench_data/<doc>.e2e_sha256.json, tools/make_e2e_sha.py) -- 241
     frames of cfg2 (regions played back in other colours, delta read-back into pooled
-    frames) and 121 of typical_4k (an outline stroked on a worker thread per cue)."""
+    frames) and 121 of typical_4k (an outline stroked on a worker thread per cue); and
+    wide_8k at 7680x4320: lines of 180 px text whose outlines are 6 000 pixels wide, beyond
+    the scan converter's 4 096-pixel boxes (converted in column windows)."""
     import json
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import make_e2e_sha
