@@ -84,6 +84,7 @@ enum
  * FLUTL_FULL_D2H=1 restores synchronous whole-frame copies into writable memory. */
 #define MAX_IN_FLIGHT 16           /* buffers handed out but not yet queued on the device */
 #define DEVICE_STROKES_AHEAD 6     /* ... with outlines made on the device (run_ahead) */
+#define DEVICE_STROKES_AHEAD_MAX 12
 #define VIDEO_CUES_AHEAD 64        /* fused over-video: cues the TTML side may be ahead of the video */
 #define POOL_MAX_FREE 24
 #define POOL_BUDGET_BYTES ((gsize) 640 << 20)   /* page-locked frames kept per element (+ twins in HBM) */
@@ -478,6 +479,7 @@ typedef struct
   guint pool_prefill;        /* FLUTL_POOL_PREFILL (default 8): frames made ahead */
   gboolean pool_prefill_set;
   guint max_ahead;           /* FLUTL_MAX_AHEAD: buffers ahead of the device (0: by size) */
+  guint n_pushed;            /* buffers handed to the finisher since the last reset */
   gboolean queue_always;     /* FLUTL_QUEUE_ALWAYS=1: every frame goes through the finisher
                               * (default: a frame with all its masks there is queued on the
                               * device by the streaming thread itself when the finisher is
@@ -2796,7 +2798,11 @@ run_ahead (GstTTMLRenderPrivate *priv, gint width, gint height)
    * at 16), and every pool frame never used before costs its first write-back, a whole
    * frame over PCIe -- a 120-cue stream ran at 10 k with 6 ahead and at 6 k with 16.
    * (Outlines by Cairo on the workers, FLUTL_HOST_STROKES: the old depth.) */
-  return priv->host_strokes ? by_size : MIN (by_size, DEVICE_STROKES_AHEAD);
+  if (priv->host_strokes)
+    return by_size;
+  /* ... and deeper as the stream goes on (a long one runs 15-20 % faster at 12 than at 6):
+   * one more frame every 64 buffers */
+  return MIN (by_size, MIN (DEVICE_STROKES_AHEAD + priv->n_pushed / 64, DEVICE_STROKES_AHEAD_MAX));
 }
 
 /* Hand a recorded frame to the finisher.  The lists are copied: the recorder's
@@ -2837,6 +2843,7 @@ pipeline_push (GstTTMLRender *render, gint width, gint height, const flutl_regio
     priv->t_push_block += g_get_monotonic_time () - t_b;
   }
   priv->in_flight++;
+  priv->n_pushed++;
   if (n_patches)
     priv->waiting_in_flight++;
   g_mutex_unlock (&priv->flight_lock);
@@ -3284,6 +3291,7 @@ gst_ttmlrender_reset (GstTTMLBase *base)
   GstTTMLRender *render = GST_TTMLRENDER (base);
   GstTTMLRenderPrivate *priv = get_priv (render);
   timing_report (render);       /* (the document ends here: its frames are drained) */
+  priv->n_pushed = 0;
   /* per-document caches: decoded images, layouts, glyph/outline atlas (host + HBM) */
   if (priv->images) {
     g_hash_table_unref (priv->images);
