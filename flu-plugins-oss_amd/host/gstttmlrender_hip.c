@@ -24,6 +24,7 @@
  * (nothing the reference can render in a sane time; what is beyond a limit fails the buffer).
  */
 #ifdef HAVE_CONFIG_H
+#include <libxml/parser.h>
 #include "config.h"
 #endif
 
@@ -3688,6 +3689,17 @@ gst_ttmlrender_class_init (GstTTMLRenderClass *klass)
   gobject_class->dispose = gst_ttmlrender_dispose;
   gobject_class->set_property = gst_ttmlrender_set_property;
   gobject_class->get_property = gst_ttmlrender_get_property;
+
+  /* The base class creates its libxml2 push parser on the streaming thread
+   * (gstttmlbase.c: xmlCreatePushParserCtxt in the sink chain function) and nothing in
+   * the plugin ever calls xmlInitParser: with several elements in one process their
+   * streaming threads race through libxml2's lazy set-up of its globals, and now and
+   * then one of them locks a mutex another is just replacing -- it never returns
+   * (caught with tools/hang_hunt.py: a thread in xmlInitializeGlobalState <-
+   * xmlCreatePushParserCtxt, the other chains waiting for its preroll for ever; 2 of
+   * some 700 runs of four and five chains).  libxml2 asks for exactly this call, once,
+   * before any thread uses the library: here, where the class is made. */
+  xmlInitParser ();
 
   g_object_class_install_property (gobject_class, PROP_DEFAULT_FONT_FAMILY,
       g_param_spec_string ("default_font_family", "Default font family",

@@ -62,11 +62,12 @@ def test_full_size_config_matches_reference_sha256(gpu, cfg):
 
 
 def run_pipeline(cmd, env, cwd, limit=90):
-    """One gst-launch.  Several elements in one process have hung twice in some hundred
-    runs on the GPU box (round 3; not reproduced in 160 runs of tools/hang_hunt.py, which
-    is this with a debugger at hand): a pipeline still running after `limit` seconds has
-    its threads' backtraces written to gpurun_out/hang_backtraces.txt (rocgdb, if there)
-    and is run once more -- the test then still checks every frame."""
+    """One gst-launch.  Several elements in one process hung twice in some 700 runs on the
+    GPU box in round 3 -- libxml2 initialised lazily by racing streaming threads, found with
+    tools/hang_hunt.py and fixed (xmlInitParser in class_init).  The net stays:
+    a pipeline still running after `limit` seconds has its threads' backtraces written to
+    gpurun_out/hang_backtraces.txt (rocgdb, if it may attach) and is run once more -- the
+    test then still checks every frame."""
     import subprocess
     import warnings
     for attempt in (0, 1):
