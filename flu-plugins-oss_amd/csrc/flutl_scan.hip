@@ -1004,7 +1004,7 @@ __device__ __noinline__ void sequential_sweep (const int32_t *__restrict__ in_ed
         const int16_t cover = (int16_t) (c * 512);
         const int16_t area = (int16_t) (cover - (int16_t) t.unc[x + 1]);
         const int v = (int) area;
-        row[x] = (uint8_t) ((v + (v << 4) + 256) >> 9);
+        row[x] = (uint8_t) ((v * 17 + 256) >> 9);
       }
       for (int r = i + 1; r < j; r++)
         for (int x = 0; x < width; x++)
@@ -1747,7 +1747,7 @@ scan_row (const ScanEdge *__restrict__ edges, const int2 *__restrict__ spans,
         const int16_t cover = (int16_t) (c * 512);
         const int16_t area = (int16_t) (cover - (int16_t) S.unc[p]);
         const int v = (int) area;
-        out[p - 1] = (uint8_t) ((v + (v << 4) + 256) >> 9);
+        out[p - 1] = (uint8_t) ((v * 17 + 256) >> 9);
       }
     }
   }

@@ -34,7 +34,7 @@
 #include <string.h>
 
 #define GRID_Y 15
-#define ALPHA(c) ((uint8_t) (((c) + ((c) << 4) + 256) >> 9))
+#define ALPHA(c) ((uint8_t) (((c) * 17 + 256) >> 9))     /* (c may be negative: no shift) */
 
 typedef struct Edge
 {
@@ -530,9 +530,10 @@ flutl_tor_oracle (const int32_t *edges, int n, int xmin, int ymin, int xmax, int
     } else {
       const int64_t dx = (int64_t) p2x - p1x;
       const int64_t Dy = ((int64_t) p2y - p1y) * GRID_Y * 512;
-      const int64_t Ex = dx << 8;
-      e->dq = (int32_t) ((dx << 17) / Dy);
-      e->dr = (dx << 17) % Dy;
+      /* (multiplications, not shifts: dx may be negative) */
+      const int64_t Ex = dx * 256;
+      e->dq = (int32_t) ((dx * 131072) / Dy);
+      e->dr = (dx * 131072) % Dy;
       const int64_t num = ((int64_t) (2 * ytop + 1) * 256 - 2 * (int64_t) GRID_Y * p1y) * Ex;
       e->xq = (int32_t) (num / Dy) + p1x;
       e->xr = num % Dy;
