@@ -415,7 +415,10 @@ static int atlas_reserve (flutl_ctx *c, size_t need)
   // (growing costs a device allocation, a copy and a drained stream, on the frame
   // that brings a cue's first masks: start where 4K text with outlines ends up;
   // HBM is not what is short on this device)
-  size_t cap = c->atlas_cap ? c->atlas_cap : (size_t) 64 << 20;
+  // (320 MB: the element starts its mask caches over at 256 MB of atlas, so a stream never
+  // grows it -- a 4K stream of outlined text passes 64 MB after 116 cues, and growing is a
+  // device allocation, a copy and a drained stream in the middle of it)
+  size_t cap = c->atlas_cap ? c->atlas_cap : (size_t) 320 << 20;
   while (cap < need)
     cap *= 2;
   uint8_t *n = nullptr;

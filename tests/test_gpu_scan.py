@@ -244,3 +244,48 @@ def test_a_window_of_the_box_is_the_crop_of_the_whole_and_wide_entries_use_that(
     P2["a"] = F.ATLAS_SLACK + 4
     assert np.array_equal(got, gpu_util.hip_render(FW, FH, R, P2, atlas))
     assert int((want > 0).sum()) > 10000
+
+
+def test_entries_survive_the_growing_of_the_atlas(gpu):
+    """The context's atlas starts at 320 MB (an element starts its caches over at 256 MB)
+    and doubles when more is asked of it: a device allocation, a copy, both streams drained.
+    An outline made on the device and a mask uploaded before the growing must composite the
+    same afterwards."""
+    import gpu_util
+    torch = gpu
+    i, kind, box, eo, edges, cov = next(p for p in _polygons() if p[1] == 2)
+    h, w = cov.shape
+    W, H = box[2] + 8, box[3] + 8
+    R = np.zeros(1, F.REGION_DTYPE)
+    R["x0"], R["y0"], R["x1"], R["y1"], R["first"], R["count"] = box[0], box[1], box[2], box[3], 0, 1
+    P = np.zeros(1, F.PRIM_DTYPE)
+    P["op"], P["rule"] = F.OP_MASK, F.RULE_LERP
+    P["cx0"], P["cy0"], P["cx1"], P["cy1"] = box[0], box[1], box[2], box[3]
+    P["color"] = 0xFF000000
+    with F.Context(0) as ctx:
+        off = ctx.atlas_put_polygon(edges, box, eo)
+        P["a"], P["b"], P["c"], P["d"] = off + 4, w + 4, box[0], box[1]
+        filler = np.full(48 << 20, 0x5A, np.uint8)
+        before = ctx.atlas_size()
+        for _ in range(8):              # 384 MB: beyond the first allocation
+            ctx.atlas_put(filler)
+        assert ctx.atlas_size() >= before + 8 * len(filler)
+        off2 = ctx.atlas_put_polygon(edges, box, eo)      # ... and one made after it
+        fr = ctx.frame(W, H)
+        try:
+            got = []
+            for o in (off, off2):
+                P["a"] = o + 4
+                fr.submit(R, P)
+                fr.wait()
+                got.append(fr.host().copy())
+        finally:
+            fr.close()
+    padded = np.zeros((h, w + 4), np.uint8)
+    padded[:, :w] = cov
+    atlas = np.concatenate([np.zeros(F.ATLAS_SLACK + 4, np.uint8), padded.ravel(),
+                            np.zeros(F.ATLAS_SLACK, np.uint8)])
+    P2 = P.copy()
+    P2["a"] = F.ATLAS_SLACK + 4
+    want = gpu_util.hip_render(W, H, R, P2, atlas)
+    assert np.array_equal(got[0], want) and np.array_equal(got[1], want)
