@@ -24,9 +24,16 @@
  *     row by 15 sample rows with non-zero (or even-odd) winding spans;
  *   - per pixel: covered_height (sample rows) and uncovered_area accumulate in
  *     16-bit cells; alpha from the running cover.
- * Pinned against the real libcairo of this image by oracle/kat_gen.c (tables
- * `torfill`: random polygons through cairo_fill on an A8 surface) and, for whole
- * strokes, `stroke2` -- see tests/test_oracle_kats.py.
+ * Pinned against the real libcairo of this image (cairo 1.16.0):
+ *   - oracle/tor_check.c: random polygons through cairo_fill on an A8 surface, on grids
+ *     that make Cairo's sort meet equal keys all the time, differentially against this
+ *     file (43 000 polygons when it was written; 3 000 in the CPU suite,
+ *     tests/test_live_reference.py);
+ *   - oracle/stroke_check.c: whole strokes, cairo_stroke against host/flutl_stroker.c +
+ *     this file (720 000; 3 500 in the CPU suite);
+ *   - tests/golden/polygons.npz (oracle/polygon_kats.c: 321 polygons with the real
+ *     Cairo's coverage): tests/test_oracle_kats.py::test_tor_restatement_reproduces_
+ *     cairos_coverage, and the HIP kernels against the same in tests/test_gpu_scan.py.
  */
 #include <limits.h>
 #include <stdint.h>
