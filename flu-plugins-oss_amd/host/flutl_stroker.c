@@ -5,7 +5,7 @@
  * glyph paths of a layout (plugins/ttml/gstttmlrender.c:1209-1212); under that call
  * Cairo's image backend (1) turns the path into a polygon -- two offset contours per
  * closed sub-path, pen fans along the curves, miter joins -- and (2) scan converts
- * the polygon.  (2) is the pixel work and runs on the GPU here (flutl_scan_kernel,
+ * the polygon.  (2) is the pixel work and runs on the GPU here (scan_rows_kernel & co.,
  * csrc/flutl_scan.hip); this file is (1): geometry on the host, in the doubles and
  * the 24.8 fixed point Cairo uses, so that the polygon is the SAME polygon, edge for
  * edge.  Third-party arithmetic absent from /root/reference: cairo 1.16.0
@@ -15,9 +15,12 @@
  * paths and real glyph outlines through cairo_stroke, byte for byte).
  *
  * Supported: what the element strokes -- closed and open sub-paths of lines and
- * cubic curves, miter joins, butt caps, no dashes, any invertible CTM, optional limits
- * (one clip box).  Anything else returns FLUTL_STROKER_UNSUPPORTED and
- * the caller fails the buffer (never a frame that differs).
+ * cubic curves, miter joins, butt caps, no dashes, a CTM that is a similarity
+ * (translation, rotation, reflection, uniform scale: see flutl_stroke_to_polygon for why
+ * not more), the target box Cairo cuts the polygon to.  Anything else returns
+ * FLUTL_STROKER_UNSUPPORTED (a path of axis-aligned rectangles only:
+ * FLUTL_STROKER_RECTILINEAR) and the caller lets Cairo itself stroke it, as before
+ * round 3 (flutl_recorder.c: stroke_job_run) -- never a frame that differs.
  */
 #include "flutl_stroker.h"
 #include <math.h>
