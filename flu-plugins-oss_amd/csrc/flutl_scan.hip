@@ -23,22 +23,26 @@
 //     joined on, else the merge sort of the edges that started together.  (Measured on
 //     6 000 strokes of text: 0.5 % of the eligible rows have such a tie, and the rules
 //     decide all but 1 in 700 of them; none was ever decided wrongly.)
-//   * what the rules cannot decide is not guessed: the row raises a flag and the
-//     polygon is converted again by flutl_scan_sequential_kernel, a literal one-lane
-//     sweep (slow, exact by construction), launched behind the row kernel and
-//     returning at once when no flag is up.  No host round trip either way.
-//   * by sample rows: cells of the row's edges at that sample row, bitonic sort in LDS,
-//     winding by prefix sum, span starts / ends add into per-pixel accumulators
-//     (LDS atomics); analytically: the span-bounding edges add their exact trapezoid
+//   * what the rules cannot decide is not guessed: the row raises a flag, and the row
+//     kernel's workgroup that finishes last converts the polygon again by
+//     sequential_sweep, a literal one-lane sweep (slow, exact by construction), when a
+//     flag is up.  No host round trip, no second launch.
+//   * by sample rows, without sorting (sample_rows_together): what the sorted walk yields
+//     depends on the order of cells only through the winding before and after each group
+//     of equal cells.  All 15 sample rows of a pixel row at once: every (edge, sample row)
+//     counts itself into one of 15 x 1024 pixel bins, one prefix sum gives every bin its
+//     entries' place and the winding before it, the entries are laid out bin by bin and
+//     dealt to the waves afresh, each reading the entries of its own bin side by side;
+//     span starts / ends add into per-pixel accumulators (LDS atomics).  Analytically:
+//     bitonic sort of the row's cells, the span-bounding edges add their exact trapezoid
 //     areas.  The row's alpha is a prefix sum over the accumulators.
-// Bound: LDS / integer issue (sorting), not HBM: the mask is written once, W * H bytes.
+// Bound: latency (two thirds of a wave's cycles are waits: profiles/r03_scan_pmc.txt), not
+// HBM: the mask is written once, W * H bytes; DESIGN.md 5.7.
 // Pinned: tests/test_gpu_scan.py -- the real cairo_fill / cairo_stroke coverage of
 // committed polygons (tests/golden/polygons.npz) and oracle/flutl_tor_oracle.c.
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
-#include <atomic>
-
 #include "flutl.h"
 
 namespace {
