@@ -77,7 +77,22 @@ struct flutl_ctx {
   hipEvent_t scan_done;
   uint8_t *stage2;
   size_t stage2_cap, stage2_used;
+  bool outline_pending;         // `stream` has not been told yet to wait for `scan_done`
 };
+
+// The context's main stream, for anything that may read the atlas: whatever is queued on it
+// comes behind the outlines made so far (recorded in `scan_done` on their own stream).  The
+// wait is put in here, lazily, and not when the outline is queued: a frame's list goes up
+// in front of it (flutl_frame_submit), while the outline is still being converted -- 8 us
+// less per cue on the frame's path.  Every use of the stream goes through here.
+static hipStream_t main_stream (flutl_ctx *c)
+{
+  if (c->outline_pending) {
+    c->outline_pending = false;
+    (void) hipStreamWaitEvent (c->stream, c->scan_done, 0);
+  }
+  return c->stream;
+}
 
 struct flutl_frame {
   int device;
@@ -295,6 +310,7 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
   c->scan_done = nullptr;
   c->stage2 = nullptr;
   c->stage2_cap = c->stage2_used = 0;
+  c->outline_pending = false;
   if (!hip_ok (hipStreamCreateWithFlags (&c->scan_stream, hipStreamNonBlocking)) ||
       !hip_ok (hipEventCreateWithFlags (&c->scan_done, hipEventDisableTiming))) {
     if (c->scan_stream)
@@ -320,8 +336,8 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
   // first such copy, 8 ms measured: zeros over the zeros of the fresh atlas)
   if (c->atlas && c->stage) {
     memset (c->stage, 0, (size_t) 1 << 20);
-    (void) hipMemcpyAsync (c->atlas, c->stage, (size_t) 1 << 20, hipMemcpyHostToDevice, c->stream);
-    (void) hipStreamSynchronize (c->stream);
+    (void) hipMemcpyAsync (c->atlas, c->stage, (size_t) 1 << 20, hipMemcpyHostToDevice, main_stream (c));
+    (void) hipStreamSynchronize (main_stream (c));
   }
   // (... and so is the scan converter's scratch: the first cue of a stream brings the
   // outlines of all its regions)
@@ -347,7 +363,7 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
           box, 0, base, base + own + 256, 16, 0 | 16, nullptr);
   }
   (void) hipStreamSynchronize (c->scan_stream);
-  (void) hipStreamSynchronize (c->stream);
+  (void) hipStreamSynchronize (main_stream (c));
   *out = c;
   return FLUTL_OK;
 }
@@ -358,7 +374,7 @@ extern "C" void flutl_ctx_destroy (flutl_ctx *c)
     return;
   (void) hipSetDevice (c->device);
   (void) hipStreamSynchronize (c->scan_stream);
-  (void) hipStreamSynchronize (c->stream);
+  (void) hipStreamSynchronize (main_stream (c));
   if (c->atlas)
     (void) hipFree (c->atlas);
   if (c->frame)
@@ -393,7 +409,7 @@ extern "C" int flutl_ctx_sync (flutl_ctx *c)
 {
   if (!c)
     return FLUTL_EINVAL;
-  if (!hip_ok (hipStreamSynchronize (c->scan_stream)) || !hip_ok (hipStreamSynchronize (c->stream)))
+  if (!hip_ok (hipStreamSynchronize (c->scan_stream)) || !hip_ok (hipStreamSynchronize (main_stream (c))))
     return FLUTL_ENODEV;
   c->stage_used = 0;       // every staged upload has landed
   c->stage2_used = 0;
@@ -429,15 +445,15 @@ static int atlas_reserve (flutl_ctx *c, size_t need)
     (void) hipFree (n);
     return FLUTL_ENODEV;
   }
-  if (!hip_ok (hipMemsetAsync (n, 0, cap, c->stream))) {
+  if (!hip_ok (hipMemsetAsync (n, 0, cap, main_stream (c)))) {
     (void) hipFree (n);
     return FLUTL_ENODEV;
   }
   // lists in flight may still read the old buffer: drain first (and the other stream
   // must not write into the new one before it has been cleared: drained either way)
   if ((c->atlas && !hip_ok (hipMemcpyAsync (n, c->atlas, c->atlas_used, hipMemcpyDeviceToDevice,
-              c->stream))) ||
-      !hip_ok (hipStreamSynchronize (c->stream))) {
+              main_stream (c)))) ||
+      !hip_ok (hipStreamSynchronize (main_stream (c)))) {
     (void) hipFree (n);
     return FLUTL_ENODEV;
   }
@@ -468,19 +484,19 @@ extern "C" int flutl_atlas_put (flutl_ctx *c, const void *src, size_t bytes,
   stage_reserve (c);
   if (c->stage && bytes <= c->stage_cap / 2) {
     if (c->stage_used + bytes > c->stage_cap) {
-      if (!hip_ok (hipStreamSynchronize (c->stream)))
+      if (!hip_ok (hipStreamSynchronize (main_stream (c))))
         return FLUTL_ENODEV;
       c->stage_used = 0;
     }
     memcpy (c->stage + c->stage_used, src, bytes);
     if (!hip_ok (hipMemcpyAsync (c->atlas + off, c->stage + c->stage_used, bytes,
-            hipMemcpyHostToDevice, c->stream)))
+            hipMemcpyHostToDevice, main_stream (c))))
       return FLUTL_ENODEV;
     c->stage_used += (bytes + 63) & ~(size_t) 63;
   } else {
     if (!hip_ok (hipMemcpyAsync (c->atlas + off, src, bytes, hipMemcpyHostToDevice,
-            c->stream)) ||
-        !hip_ok (hipStreamSynchronize (c->stream)))
+            main_stream (c))) ||
+        !hip_ok (hipStreamSynchronize (main_stream (c))))
       return FLUTL_ENODEV;
     c->stage_used = 0;
   }
@@ -585,9 +601,12 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
     }
   }
   // whatever the context is given next comes behind the outline
-  if (!rc && (!hip_ok (hipEventRecord (c->scan_done, ss)) ||
-          !hip_ok (hipStreamWaitEvent (c->stream, c->scan_done, 0))))
-    rc = FLUTL_ENODEV;
+  if (!rc) {
+    if (!hip_ok (hipEventRecord (c->scan_done, ss)))
+      rc = FLUTL_ENODEV;
+    else
+      c->outline_pending = true;        // (main_stream: the wait, when the stream is next used)
+  }
   if (rc)
     return rc;
   c->atlas_used = end;
@@ -651,7 +670,7 @@ extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
                                               : bytes;
   if (need > c->frame_cap) {
     if (c->frame) {
-      (void) hipStreamSynchronize (c->stream);
+      (void) hipStreamSynchronize (main_stream (c));
       (void) hipFree (c->frame);
       c->frame = nullptr;
       c->frame_cap = 0;
@@ -664,7 +683,7 @@ extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
   flutl_prim *pd;
   if ((rc = upload_list (c, regions, n_regions, prims, n_prims, &rd, &pd)))
     return rc;
-  if ((rc = flutl_launch_frame (c->stream, w, h, c->frame, tight, rd, n_regions, pd,
+  if ((rc = flutl_launch_frame (main_stream (c), w, h, c->frame, tight, rd, n_regions, pd,
            c->atlas)))
     return rc;
   // Gaussian weights: host -> small device buffer
@@ -678,28 +697,28 @@ extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
   const size_t slot0 = rbytes > bytes ? rbytes : bytes;
   uint8_t *blurred = (resample || rotate_cw)
       ? static_cast<uint8_t *> (c->frame) + slot0 : c->atlas + off;
-  bool ok = hip_ok (hipMemcpyAsync (wdev, weights.data (), wbytes, hipMemcpyHostToDevice, c->stream));
+  bool ok = hip_ok (hipMemcpyAsync (wdev, weights.data (), wbytes, hipMemcpyHostToDevice, main_stream (c)));
   if (ok)
-    ok = flutl_launch_blur (c->stream, c->frame, blurred, w, h, tight, wdev,
+    ok = flutl_launch_blur (main_stream (c), c->frame, blurred, w, h, tight, wdev,
         radius) == FLUTL_OK;
   if (ok && resample && !rotate_cw)
-    ok = flutl_launch_resample (c->stream, blurred, c->atlas + off, w, h, tight, etight,
+    ok = flutl_launch_resample (main_stream (c), blurred, c->atlas + off, w, h, tight, etight,
         distx, disty, box) == FLUTL_OK;
   if (ok && rotate_cw) {
     const uint8_t *turn_src = blurred;
     if (resample) {         // resample (no box) into staging slot 0, then turn that
-      ok = flutl_launch_resample (c->stream, blurred, c->frame, w, h, tight, (size_t) rw * 4,
+      ok = flutl_launch_resample (main_stream (c), blurred, c->frame, w, h, tight, (size_t) rw * 4,
           distx, disty, nullptr) == FLUTL_OK;
       turn_src = static_cast<const uint8_t *> (c->frame);
     }
     if (ok)
-      ok = flutl_launch_rotate_cw (c->stream, turn_src, c->atlas + off, rw, rh,
+      ok = flutl_launch_rotate_cw (main_stream (c), turn_src, c->atlas + off, rw, rh,
           (size_t) rw * 4, etight, box) == FLUTL_OK;
   }
   if (ok && host_copy)
     ok = hip_ok (hipMemcpyAsync (host_copy, c->atlas + off, ebytes, hipMemcpyDeviceToHost,
-        c->stream));
-  ok = hip_ok (hipStreamSynchronize (c->stream)) && ok;
+        main_stream (c)));
+  ok = hip_ok (hipStreamSynchronize (main_stream (c))) && ok;
   (void) hipFree (wdev);
   if (!ok)
     return FLUTL_ENODEV;
@@ -768,11 +787,11 @@ extern "C" int flutl_list_create (flutl_ctx *c, uint32_t width, uint32_t height,
   bool ok = true;
   if (n_regions)
     ok = ok && hip_ok (hipMemcpyAsync (l->regions, regions,
-        (size_t) n_regions * sizeof (flutl_region), hipMemcpyHostToDevice, c->stream));
+        (size_t) n_regions * sizeof (flutl_region), hipMemcpyHostToDevice, main_stream (c)));
   if (n_prims)
     ok = ok && hip_ok (hipMemcpyAsync (l->prims, prims, pb, hipMemcpyHostToDevice,
-        c->stream));
-  ok = ok && hip_ok (hipStreamSynchronize (c->stream));
+        main_stream (c)));
+  ok = ok && hip_ok (hipStreamSynchronize (main_stream (c)));
   if (!ok) {
     (void) hipFree (l->mem);
     delete l;
@@ -788,7 +807,7 @@ extern "C" void flutl_list_destroy (flutl_ctx *c, flutl_list *l)
     return;
   if (c) {
     (void) hipSetDevice (c->device);
-    (void) hipStreamSynchronize (c->stream);
+    (void) hipStreamSynchronize (main_stream (c));
   }
   if (l->mem)
     (void) hipFree (l->mem);
@@ -801,7 +820,7 @@ extern "C" int flutl_render (flutl_ctx *c, const flutl_list *l, void *dst_dev,
   if (!c || !l || !dst_dev)
     return FLUTL_EINVAL;
   (void) hipSetDevice (c->device);
-  return flutl_launch_frame (c->stream, l->width, l->height, dst_dev,
+  return flutl_launch_frame (main_stream (c), l->width, l->height, dst_dev,
       dst_stride_bytes, l->regions, l->n_regions, l->prims, c->atlas);
 }
 
@@ -863,7 +882,7 @@ static int upload_list (flutl_ctx *c, const flutl_region *regions, uint32_t n_re
   const size_t pb = (size_t) n_prims * sizeof (flutl_prim);
   if (rb + pb + 32 > c->listbuf_cap) {
     if (c->listbuf) {
-      (void) hipStreamSynchronize (c->stream);
+      (void) hipStreamSynchronize (main_stream (c));
       (void) hipFree (c->listbuf);
       c->listbuf = nullptr;
       c->listbuf_cap = 0;
@@ -880,9 +899,9 @@ static int upload_list (flutl_ctx *c, const flutl_region *regions, uint32_t n_re
   bool ok = true;
   if (n_regions)
     ok = ok && hip_ok (hipMemcpyAsync (rd, regions, (size_t) n_regions * sizeof (flutl_region),
-        hipMemcpyHostToDevice, c->stream));
+        hipMemcpyHostToDevice, main_stream (c)));
   if (n_prims)
-    ok = ok && hip_ok (hipMemcpyAsync (pd, prims, pb, hipMemcpyHostToDevice, c->stream));
+    ok = ok && hip_ok (hipMemcpyAsync (pd, prims, pb, hipMemcpyHostToDevice, main_stream (c)));
   if (!ok)
     return FLUTL_ENODEV;
   *rd_out = rd;
@@ -914,7 +933,7 @@ static int render_lists_to_host (flutl_ctx *c, uint32_t width, uint32_t height,
   const size_t need = tight * l->height;
   if (need > c->frame_cap) {
     if (c->frame) {
-      (void) hipStreamSynchronize (c->stream);
+      (void) hipStreamSynchronize (main_stream (c));
       (void) hipFree (c->frame);
       c->frame = nullptr;
       c->frame_cap = 0;
@@ -923,7 +942,7 @@ static int render_lists_to_host (flutl_ctx *c, uint32_t width, uint32_t height,
       return FLUTL_ENOMEM;
     c->frame_cap = need;
   }
-  int rc = flutl_launch_frame (c->stream, l->width, l->height, c->frame, tight,
+  int rc = flutl_launch_frame (main_stream (c), l->width, l->height, c->frame, tight,
       l->regions, l->n_regions, l->prims, c->atlas);
   if (rc)
     return rc;
@@ -943,12 +962,12 @@ static int render_lists_to_host (flutl_ctx *c, uint32_t width, uint32_t height,
         (size_t) col0 * 4;
     const size_t wbytes = (size_t) (col1 - col0) * 4;
     if (dst_stride_bytes == tight && wbytes == tight)
-      ok = hip_ok (hipMemcpyAsync (d, sp, tight * rows, hipMemcpyDeviceToHost, c->stream));
+      ok = hip_ok (hipMemcpyAsync (d, sp, tight * rows, hipMemcpyDeviceToHost, main_stream (c)));
     else
       ok = hip_ok (hipMemcpy2DAsync (d, dst_stride_bytes, sp, tight, wbytes, rows,
-          hipMemcpyDeviceToHost, c->stream));
+          hipMemcpyDeviceToHost, main_stream (c)));
   }
-  if (!hip_ok (hipStreamSynchronize (c->stream)) || !ok)
+  if (!hip_ok (hipStreamSynchronize (main_stream (c))) || !ok)
     return FLUTL_ENODEV;
   return FLUTL_OK;
 }
@@ -979,7 +998,7 @@ extern "C" int flutl_blend_over_host (flutl_ctx *c, uint32_t width, uint32_t hei
   const uint32_t fy0 = y0 & ~15u, fy1 = ((y1 + 15u) & ~15u) < height ? ((y1 + 15u) & ~15u) : height;
   const size_t tight = (size_t) width * 4, frame_bytes = tight * height;
   if (2 * frame_bytes > c->frame_cap) {
-    (void) hipStreamSynchronize (c->stream);
+    (void) hipStreamSynchronize (main_stream (c));
     if (c->frame)
       (void) hipFree (c->frame);
     c->frame = nullptr;
@@ -997,14 +1016,14 @@ extern "C" int flutl_blend_over_host (flutl_ctx *c, uint32_t width, uint32_t hei
   const size_t rows = fy1 - fy0;
   bool ok = hip_ok (hipMemcpy2DAsync (vid + (size_t) fy0 * tight, tight,
       host + (size_t) fy0 * stride_bytes, stride_bytes, tight, rows, hipMemcpyHostToDevice,
-      c->stream));
+      main_stream (c)));
   if (ok)
-    ok = flutl_launch_frame_over_rows (c->stream, width, height, dst, vid, tight, rd, n_regions,
+    ok = flutl_launch_frame_over_rows (main_stream (c), width, height, dst, vid, tight, rd, n_regions,
         pd, c->atlas, fy0, fy1) == FLUTL_OK;
   if (ok)
     ok = hip_ok (hipMemcpy2DAsync (host + (size_t) fy0 * stride_bytes, stride_bytes,
-        dst + (size_t) fy0 * tight, tight, tight, rows, hipMemcpyDeviceToHost, c->stream));
-  if (!hip_ok (hipStreamSynchronize (c->stream)) || !ok)
+        dst + (size_t) fy0 * tight, tight, tight, rows, hipMemcpyDeviceToHost, main_stream (c)));
+  if (!hip_ok (hipStreamSynchronize (main_stream (c))) || !ok)
     return FLUTL_ENODEV;
   return FLUTL_OK;
 }
@@ -1040,9 +1059,9 @@ extern "C" int flutl_frame_create (flutl_ctx *c, uint32_t width, uint32_t height
   // the transparent frame, in both copies: cleared by the device in stream order
   // (the host block over PCIe: no 33 MB memset on the caller's thread, and no
   // wait -- whatever is submitted into the frame comes later on the same stream)
-  ok = ok && hip_ok (hipMemsetAsync (f->twin, 0, bytes, c->stream)) &&
-      hip_ok (hipMemsetAsync (f->host_dev, 0, bytes, c->stream)) &&
-      hip_ok (hipEventRecord (f->done, c->stream));
+  ok = ok && hip_ok (hipMemsetAsync (f->twin, 0, bytes, main_stream (c))) &&
+      hip_ok (hipMemsetAsync (f->host_dev, 0, bytes, main_stream (c))) &&
+      hip_ok (hipEventRecord (f->done, main_stream (c)));
   if (ok)
     f->pending = true;
   if (!ok) {
@@ -1096,8 +1115,8 @@ extern "C" uint64_t flutl_ctx_delta_bytes (flutl_ctx *c)
   if (!c || !c->delta_segments)
     return 0;
   (void) hipSetDevice (c->device);
-  if (!hip_ok (hipMemcpyAsync (&n, c->delta_segments, sizeof n, hipMemcpyDeviceToHost, c->stream)) ||
-      !hip_ok (hipStreamSynchronize (c->stream)))
+  if (!hip_ok (hipMemcpyAsync (&n, c->delta_segments, sizeof n, hipMemcpyDeviceToHost, main_stream (c))) ||
+      !hip_ok (hipStreamSynchronize (main_stream (c))))
     return 0;
   return n * flutl_delta_segment_bytes ();
 }
@@ -1177,7 +1196,7 @@ extern "C" int flutl_frame_submit (flutl_ctx *c, flutl_frame *f,
   // scratch frame of the context (here: where translucent groups park pixels)
   const size_t need = (size_t) width * 4 * height;
   if (need > c->frame_cap) {
-    (void) hipStreamSynchronize (c->stream);
+    (void) hipStreamSynchronize (main_stream (c));
     if (c->frame)
       (void) hipFree (c->frame);
     c->frame = nullptr;
@@ -1188,6 +1207,7 @@ extern "C" int flutl_frame_submit (flutl_ctx *c, flutl_frame *f,
   }
   bool ok = true;
   if (rb + pb + (n_order ? ob : 0))
+    // (the list itself does not depend on the outlines: in front of the wait for them)
     ok = hip_ok (hipMemcpyAsync (sl.dev, sl.host, rb + pb + (n_order ? ob : 0),
         hipMemcpyHostToDevice, c->stream));
   if (!ok)
@@ -1196,23 +1216,23 @@ extern "C" int flutl_frame_submit (flutl_ctx *c, flutl_frame *f,
   const flutl_prim *pd = reinterpret_cast<const flutl_prim *> (static_cast<uint8_t *> (sl.dev) + rb);
   if (!c->delta_segments) {
     if (!hip_ok (hipMalloc (reinterpret_cast<void **> (&c->delta_segments), sizeof (uint64_t))) ||
-        !hip_ok (hipMemsetAsync (c->delta_segments, 0, sizeof (uint64_t), c->stream)))
+        !hip_ok (hipMemsetAsync (c->delta_segments, 0, sizeof (uint64_t), main_stream (c))))
       rc = FLUTL_ENOMEM;
   }
   // one launch: composite those rows, compare with the twin, write what differs
   // into the twin and the host block (flutl_launch_frame_delta)
   if (rc == FLUTL_OK && n_order)
-    rc = flutl_launch_frame_delta (c->stream, width, height, f->twin, f->host_dev, c->frame,
+    rc = flutl_launch_frame_delta (main_stream (c), width, height, f->twin, f->host_dev, c->frame,
         (size_t) width * 4, rd, n_regions, pd, c->atlas, y0, y1,
         reinterpret_cast<const uint16_t *> (static_cast<uint8_t *> (sl.dev) + rb + pb),
         c->delta_segments);
-  ok = rc == FLUTL_OK && hip_ok (hipEventRecord (sl.done, c->stream)) &&
-      hip_ok (hipEventRecord (f->done, c->stream));
+  ok = rc == FLUTL_OK && hip_ok (hipEventRecord (sl.done, main_stream (c))) &&
+      hip_ok (hipEventRecord (f->done, main_stream (c)));
   sl.busy = true;
   f->pending = true;
   if (!ok) {
     // whatever was queued: the frame's content is unknown from here on
-    (void) hipStreamSynchronize (c->stream);
+    (void) hipStreamSynchronize (main_stream (c));
     f->error = rc ? rc : FLUTL_ENODEV;
     return f->error;
   }
