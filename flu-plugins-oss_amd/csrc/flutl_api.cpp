@@ -30,6 +30,9 @@ inline bool hip_ok (hipError_t e) { return e == hipSuccess; }
 extern "C" int flutl_launch_scan_counted (void *stream_, const int32_t *edges_dev, uint32_t n_edges,
     const int32_t box[4], int even_odd, void *scratch, void *dst, size_t dst_stride, int mode,
     uint32_t *counters_dev);
+extern "C" int flutl_launch_scan_hosted (void *stream_, const int32_t *edges, int32_t *raw_copy_dev,
+    uint32_t n_edges, const int32_t box[4], int even_odd, void *scratch, void *dst, size_t dst_stride,
+    int mode, uint32_t *counters_dev);
 
 struct flutl_list {
   uint32_t width, height;
@@ -69,15 +72,24 @@ struct flutl_ctx {
   void *scan;          // device scratch of the polygon scan converter (edges + its own)
   size_t scan_cap;
   uint32_t *scan_counters;     // device: [0] polygons the sequential converter took
-  // Outlines are made on a stream of their own: the edges of the next cue's outline go up
-  // and are scan converted while the frame before it is still being composited and written
-  // back on `stream`.  `stream` waits for `scan_done` (recorded behind every polygon) before
-  // whatever it is given next; the polygon path has its own staging memory.
+  // A second stream (outlines were made on it for a while: a wait of the main stream for
+  // another queue's kernel costs 10-15 us each time, tools/stream_trace.py).
+  // Now: what the context sets up when it is created, nothing per outline.
   hipStream_t scan_stream;
   hipEvent_t scan_done;
   uint8_t *stage2;
   size_t stage2_cap, stage2_used;
   bool outline_pending;         // `stream` has not been told yet to wait for `scan_done`
+  // An outline's edges stay in page-locked host memory: scan_prepare_kernel reads them from
+  // there over PCIe (7 us more than from HBM for a 12 000-edge outline) -- no upload on
+  // another queue and no wait for it (12 + 13 us of a 73 us cycle, tools/stream_trace.py).
+  // `stage2` is used in two halves; a half is written again only after `half_done` of its
+  // last use (recorded behind the last kernel that read it) has been waited for on the host,
+  // some twenty outlines later.
+  hipEvent_t half_done[2];
+  bool half_set[2];
+  int cur_half;
+  size_t half_used;
 };
 
 // The context's main stream, for anything that may read the atlas: whatever is queued on it
@@ -311,6 +323,12 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
   c->stage2 = nullptr;
   c->stage2_cap = c->stage2_used = 0;
   c->outline_pending = false;
+  c->half_done[0] = c->half_done[1] = nullptr;
+  c->half_set[0] = c->half_set[1] = false;
+  c->cur_half = 0;
+  c->half_used = 0;
+  (void) hipEventCreateWithFlags (&c->half_done[0], hipEventDisableTiming);
+  (void) hipEventCreateWithFlags (&c->half_done[1], hipEventDisableTiming);
   if (!hip_ok (hipStreamCreateWithFlags (&c->scan_stream, hipStreamNonBlocking)) ||
       !hip_ok (hipEventCreateWithFlags (&c->scan_done, hipEventDisableTiming))) {
     if (c->scan_stream)
@@ -397,6 +415,9 @@ extern "C" void flutl_ctx_destroy (flutl_ctx *c)
     (void) hipFree (c->scan);
   if (c->scan_counters)
     (void) hipFree (c->scan_counters);
+  for (int k = 0; k < 2; k++)
+    if (c->half_done[k])
+      (void) hipEventDestroy (c->half_done[k]);
   if (c->stage2)
     (void) hipHostFree (c->stage2);
   (void) hipEventDestroy (c->scan_done);
@@ -413,6 +434,8 @@ extern "C" int flutl_ctx_sync (flutl_ctx *c)
     return FLUTL_ENODEV;
   c->stage_used = 0;       // every staged upload has landed
   c->stage2_used = 0;
+  c->half_used = 0;        // (... and every outline's edges have been read)
+  c->half_set[0] = c->half_set[1] = false;
   return FLUTL_OK;
 }
 
@@ -538,11 +561,11 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
   constexpr uint32_t kWindow = 4096;
   const size_t own_bytes = flutl_scan_scratch_bytes (n_edges, w < kWindow ? w : kWindow, h);
   const size_t need = edge_bytes + own_bytes;
-  hipStream_t ss = c->scan_stream;
+  hipStream_t ms = main_stream (c);
   if (need > c->scan_cap) {
     // (whatever still reads the old one is ordered before the free by the sync)
     if (c->scan) {
-      if (!hip_ok (hipStreamSynchronize (ss)))
+      if (!hip_ok (hipStreamSynchronize (ms)))
         return FLUTL_ENODEV;
       (void) hipFree (c->scan);
       c->scan = nullptr;
@@ -553,41 +576,52 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
       cap = (size_t) 8 << 20;   // (an outline of two 4K lines needs about 3 MB)
     if (!hip_ok (hipMalloc (&c->scan, cap)))
       return FLUTL_ENOMEM;
-    if (!hip_ok (hipMemsetAsync (c->scan, 0, 256, ss)))
+    if (!hip_ok (hipMemsetAsync (c->scan, 0, 256, ms)))
       return FLUTL_ENODEV;
     c->scan_cap = cap;
   }
   if (!c->scan_counters) {
     if (!hip_ok (hipMalloc (reinterpret_cast<void **> (&c->scan_counters), 4 * sizeof (uint32_t))) ||
-        !hip_ok (hipMemsetAsync (c->scan_counters, 0, 4 * sizeof (uint32_t), ss)))
+        !hip_ok (hipMemsetAsync (c->scan_counters, 0, 4 * sizeof (uint32_t), ms)))
       return FLUTL_ENOMEM;
   }
+  // the edges' copy in device memory (made by the prepare kernel: the sequential sweep's)
   int32_t *edges_dev = reinterpret_cast<int32_t *> (static_cast<uint8_t *> (c->scan) + own_bytes);
+  const int32_t *edges_src = edges_dev;         // what the prepare kernel reads
+  int32_t *raw_copy = nullptr;
   if (n_edges) {
     const size_t eb = (size_t) n_edges * 7 * sizeof (int32_t);
-    if (c->stage2 && eb <= c->stage2_cap / 2) {
-      if (c->stage2_used + eb > c->stage2_cap) {
-        if (!hip_ok (hipStreamSynchronize (ss)))
+    const size_t half_cap = c->stage2 ? c->stage2_cap / 2 : 0;
+    if (c->half_done[0] && c->half_done[1] && eb <= half_cap) {
+      if (c->half_used + eb > half_cap) {
+        // this half is full: it may be written again behind everything queued so far
+        if (!hip_ok (hipEventRecord (c->half_done[c->cur_half], ms)))
           return FLUTL_ENODEV;
-        c->stage2_used = 0;
+        c->half_set[c->cur_half] = true;
+        c->cur_half ^= 1;
+        c->half_used = 0;
+        if (c->half_set[c->cur_half]) {
+          if (!hip_ok (hipEventSynchronize (c->half_done[c->cur_half])))
+            return FLUTL_ENODEV;
+          c->half_set[c->cur_half] = false;
+        }
       }
-      memcpy (c->stage2 + c->stage2_used, edges, eb);
-      if (!hip_ok (hipMemcpyAsync (edges_dev, c->stage2 + c->stage2_used, eb, hipMemcpyHostToDevice, ss)))
-        return FLUTL_ENODEV;
-      c->stage2_used += (eb + 63) & ~(size_t) 63;
+      uint8_t *at = c->stage2 + (size_t) c->cur_half * half_cap + c->half_used;
+      memcpy (at, edges, eb);
+      c->half_used += (eb + 255) & ~(size_t) 255;
+      edges_src = reinterpret_cast<const int32_t *> (at);
+      raw_copy = edges_dev;
     } else {
-      if (!hip_ok (hipMemcpyAsync (edges_dev, edges, eb, hipMemcpyHostToDevice, ss)) ||
-          !hip_ok (hipStreamSynchronize (ss)))
+      // (more edges than half the staging memory holds: uploaded, and waited for)
+      if (!hip_ok (hipMemcpyAsync (edges_dev, edges, eb, hipMemcpyHostToDevice, ms)) ||
+          !hip_ok (hipStreamSynchronize (ms)))
         return FLUTL_ENODEV;
-      c->stage2_used = 0;
     }
   }
   // the entry: the coverage, and the zero bytes around and between its rows (mode 8); the
-  // converter's status words are the first of its scratch and stay zero between calls (16).
-  // (The entry's bytes are new, or reused after a start-over that the caller drains the
-  // context for: nothing queued on the other stream reads or writes them.)
+  // converter's status words are the first of its scratch and stay zero between calls (16)
   if (n_edges == 0) {
-    if (!hip_ok (hipMemsetAsync (c->atlas + off, 0, bytes, ss)))
+    if (!hip_ok (hipMemsetAsync (c->atlas + off, 0, bytes, ms)))
       return FLUTL_ENODEV;
   } else {
     for (uint32_t x = 0; x < w && !rc; x += kWindow) {
@@ -596,16 +630,11 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
       // (a window zeroes the 4 bytes after each of its rows; those of all but the last
       // window are the next window's first pixels, written behind it in stream order)
       const int pad = x == 0 ? 8 : (x + ww == w ? 32 : 0);
-      rc = flutl_launch_scan_counted (ss, edges_dev, n_edges, wbox, even_odd,
-          c->scan, c->atlas + off + 4 + x, (size_t) w + 4, 0 | pad | 16, c->scan_counters);
+      // (the first window's prepare kernel makes the device copy; the others read that)
+      rc = flutl_launch_scan_hosted (ms, x == 0 ? edges_src : edges_dev, x == 0 ? raw_copy : nullptr,
+          n_edges, wbox, even_odd, c->scan, c->atlas + off + 4 + x, (size_t) w + 4, 0 | pad | 16,
+          c->scan_counters);
     }
-  }
-  // whatever the context is given next comes behind the outline
-  if (!rc) {
-    if (!hip_ok (hipEventRecord (c->scan_done, ss)))
-      rc = FLUTL_ENODEV;
-    else
-      c->outline_pending = true;        // (main_stream: the wait, when the stream is next used)
   }
   if (rc)
     return rc;
@@ -620,8 +649,8 @@ extern "C" uint32_t flutl_ctx_scan_fallbacks (flutl_ctx *c)
   if (!c || !c->scan_counters)
     return 0;
   (void) hipSetDevice (c->device);
-  if (!hip_ok (hipMemcpyAsync (&n, c->scan_counters, sizeof n, hipMemcpyDeviceToHost, c->scan_stream)) ||
-      !hip_ok (hipStreamSynchronize (c->scan_stream)))
+  if (!hip_ok (hipMemcpyAsync (&n, c->scan_counters, sizeof n, hipMemcpyDeviceToHost, main_stream (c))) ||
+      !hip_ok (hipStreamSynchronize (main_stream (c))))
     return 0;
   return n;
 }

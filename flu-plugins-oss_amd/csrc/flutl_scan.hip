@@ -136,16 +136,26 @@ __device__ inline void normalise (int32_t &q, int64_t &r, int64_t D)
 }
 
 // ---- edges: cairo_edge_t -> ScanEdge (glitter_scan_converter_add_edge) ----------------
+// (raw_copy: where `edges` is page-locked HOST memory read over PCIe -- the element's
+// outlines, flutl_atlas_put_polygon -- a copy in device memory for the sequential sweep)
 __global__ void scan_prepare_kernel (const int32_t *__restrict__ edges, uint32_t n,
     int ymin, int ymax, ScanEdge *__restrict__ out, int2 *__restrict__ spans,
-    uint32_t *__restrict__ status)
+    uint32_t *__restrict__ status, int32_t *__restrict__ raw_copy)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0)
     status[0] = 0;              // (the rows run behind this kernel in stream order)
   if (i >= n)
     return;
-  const int32_t *in = edges + (size_t) i * 7;
+  int32_t in[7];
+#pragma unroll
+  for (int k = 0; k < 7; k++)
+    in[k] = edges[(size_t) i * 7 + k];
+  if (raw_copy) {
+#pragma unroll
+    for (int k = 0; k < 7; k++)
+      raw_copy[(size_t) i * 7 + k] = in[k];
+  }
   ScanEdge e;
   int ytop = (int) (((int64_t) in[4] * kGridY + 128) >> 8);
   int ybot = (int) (((int64_t) in[5] * kGridY + 128) >> 8);
@@ -1841,10 +1851,24 @@ extern "C" int flutl_launch_scan (void *stream_, const int32_t *edges_dev, uint3
       dst_stride, mode, nullptr);
 }
 
+extern "C" int flutl_launch_scan_hosted (void *stream_, const int32_t *edges, int32_t *raw_copy_dev,
+    uint32_t n_edges, const int32_t box[4], int even_odd, void *scratch, void *dst, size_t dst_stride,
+    int mode, uint32_t *counters_dev);
+
 // (library internal: counters_dev[0] counts the polygons the sequential kernel converted)
 extern "C" int flutl_launch_scan_counted (void *stream_, const int32_t *edges_dev, uint32_t n_edges,
     const int32_t box[4], int even_odd, void *scratch, void *dst, size_t dst_stride, int mode,
     uint32_t *counters_dev)
+{
+  return flutl_launch_scan_hosted (stream_, edges_dev, nullptr, n_edges, box, even_odd, scratch, dst,
+      dst_stride, mode, counters_dev);
+}
+
+// (library internal: `edges` may be page-locked host memory the device can read; then
+// raw_copy_dev, n_edges x 7 int32 of device memory, is where the sequential sweep finds them)
+extern "C" int flutl_launch_scan_hosted (void *stream_, const int32_t *edges_dev, int32_t *raw_copy_dev,
+    uint32_t n_edges, const int32_t box[4], int even_odd, void *scratch, void *dst, size_t dst_stride,
+    int mode, uint32_t *counters_dev)
 {
   hipStream_t stream = static_cast<hipStream_t> (stream_);
   const int xmin = box[0], ymin = box[1], xmax = box[2], ymax = box[3];
@@ -1868,7 +1892,7 @@ extern "C" int flutl_launch_scan_counted (void *stream_, const int32_t *edges_de
   int2 *spans = reinterpret_cast<int2 *> (p);
   p += ((size_t) n_edges * sizeof (int2) + 255) & ~(size_t) 255;
   SeqArgs seq;
-  seq.in_edges = edges_dev;
+  seq.in_edges = raw_copy_dev ? raw_copy_dev : edges_dev;
   seq.sedges = reinterpret_cast<SeqEdge *> (p);
   p += ((size_t) (n_edges + 2) * sizeof (SeqEdge) + 255) & ~(size_t) 255;
   seq.y_buckets = reinterpret_cast<SeqEdge **> (p);
@@ -1887,7 +1911,7 @@ extern "C" int flutl_launch_scan_counted (void *stream_, const int32_t *edges_de
     if (!clean && hipMemsetAsync (status, 0, 16, stream) != hipSuccess)
       return FLUTL_ENODEV;
     scan_prepare_kernel<<<(n_edges + 255) / 256, 256, 0, stream>>> (edges_dev, n_edges, ymin, ymax,
-        prepared, spans, status);
+        prepared, spans, status, raw_copy_dev);
     // LDS: the accumulators by the box width; a region that holds the sort keys of an
     // eligible row's order and then the bins of the sample rows
     const size_t fixed = row_shared_fixed_bytes ((int) width);
