@@ -91,14 +91,209 @@ def profiled_traffic(cfg, batch):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this very
     command (profiles/<round>_<cfg>_b<batch>_summary.json, tools/profile_gpu.sh):
     WRITE_SIZE (exact for 16-byte stores) + FETCH_SIZE (raw: uncalibrated for the
-    4-byte mask reads).  None if that configuration has not been profiled."""
+    4-byte mask reads), and the file it comes from -- counters of ANOTHER run of this
+    command (another box, another day), which is why the line names the file
+    (`traffic_from`).  None if that configuration has not been profiled."""
     import glob
     pat = os.path.join(ROOT, "profiles", f"r*_{cfg.split('_')[0]}_b{batch}_summary.json")
     files = sorted(glob.glob(pat))
     if not files:
         return None
     t = json.load(open(files[-1])).get("hbm_traffic_bytes_per_launch")
-    return int(t["write"] + t["fetch_raw"]) if t else None
+    return (int(t["write"] + t["fetch_raw"]), "profiles/" + os.path.basename(files[-1])) if t else None
+
+
+class Resident:
+    """One BASELINE config made resident in HBM for the `configs` block: display lists of
+    `n_states` distinct scene states + atlas + an output ring larger than the Infinity
+    Cache, and the launch of one step (the same calls main() times for the headline)."""
+
+    def __init__(self, cfg, batch, n_states=64, ordered=True):
+        import torch
+        import pyflutl as F
+        import scenes
+        import streams
+        self.F, self.torch, self.streams = F, torch, streams
+        W, H, states, atlas, source = load_states(cfg, n_states, None)
+        self.W, self.H, self.B, self.source = W, H, batch, source
+        self.n_states = len(states)
+        self.frame_bytes = W * 4 * H
+        ring = max(2 * batch, (640 << 20) // self.frame_bytes + 1)
+        self.ring = (ring + batch - 1) // batch * batch
+        alg = [scenes.algorithmic_bytes(W, H, R, P) for (R, P) in states]
+        self.alg_source = "display list"
+        if source.endswith(".flpk.z"):
+            meta_path = os.path.join(ROOT, source[:-len(".flpk.z")] + ".sha256.json")
+            if os.path.exists(meta_path):
+                ab = json.load(open(meta_path)).get("algorithmic_bytes")
+                if ab and len(ab) >= self.n_states:
+                    alg = [float(x) for x in ab[:self.n_states]]
+                    self.alg_source = "one mask per glyph instance (" + os.path.basename(meta_path) + ")"
+        self.alg_bytes = float(np.mean(alg))
+        regs, prims, self.r_first, self.r_count = [], [], [], []
+        for (R, P) in states:
+            R = R.copy()
+            R["first"] += sum(len(p) for p in prims)
+            self.r_first.append(sum(len(r) for r in regs))
+            self.r_count.append(len(R))
+            regs.append(R)
+            prims.append(P)
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).cuda()
+        self.R_dev, self.P_dev, self.A_dev = dev(np.concatenate(regs)), dev(np.concatenate(prims)), dev(atlas)
+        self.out = torch.empty(self.ring * self.frame_bytes, dtype=torch.uint8, device="cuda")
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.states = states
+        if batch > 1:
+            self.n_desc = min(max((self.n_states * self.ring) // np.gcd(self.n_states, self.ring) // batch, 1), 1024)
+            descs = np.zeros(self.n_desc * batch, F.FRAME_DTYPE)
+            for st in range(self.n_desc):
+                for j, k in enumerate(streams.state_schedule(self.n_states, 0, st, batch, 1)):
+                    descs[st * batch + j] = (self.r_first[k], self.r_count[k],
+                                             ((st * batch + j) % self.ring) * self.frame_bytes)
+            self.D_dev = dev(descs)
+        else:
+            self.o_len = (H + 15) // 16
+            O_all = np.zeros((self.n_states, self.o_len), np.uint16)
+            for i, (R, P) in enumerate(states):
+                o = F.row_order(W, H, R, P)
+                O_all[i, :len(o)] = o
+            self.O_dev = dev(O_all) if ordered else None
+
+    def step(self, s):
+        F = self.F
+        if self.B > 1:
+            ds = s % self.n_desc
+            F.launch_batch(self.stream, self.W, self.H, self.out, self.D_dev.data_ptr() + ds * self.B * 16,
+                           self.B, self.R_dev, self.P_dev, self.A_dev)
+        else:
+            st, slot = s % self.n_states, s % self.ring
+            F.launch_frame_ordered(self.stream, self.W, self.H, self.out.data_ptr() + slot * self.frame_bytes,
+                                   self.R_dev.data_ptr() + self.r_first[st] * 16, self.r_count[st],
+                                   self.P_dev, self.A_dev, 0, self.H,
+                                   self.O_dev.data_ptr() + st * self.o_len * 2)
+
+    def measure(self, launches, warm):
+        """HIP events around every launch on the stream it is launched on, and the wall
+        time of the whole run: (mean kernel ms, median, frames/s over the run)."""
+        torch = self.torch
+        for s in range(warm):
+            self.step(s)
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+               for _ in range(launches)]
+        t0 = time.perf_counter()
+        for i, (a, b) in enumerate(evs):
+            a.record()
+            self.step(warm + i)
+            b.record()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        ms = np.array([a.elapsed_time(b) for a, b in evs])
+        return float(ms.mean()), float(np.median(ms)), launches * self.B / wall
+
+    def free(self):
+        del self.out, self.R_dev, self.P_dev, self.A_dev
+        self.torch.cuda.empty_cache()
+
+
+def delta_stream_block():
+    """The launch the ELEMENT makes per buffer (the DELTA instantiation of the compositor,
+    flutl_launch_frame_delta): cfg2's scene states in turn into 3 twin / page-locked host
+    pairs, each launch over the rows the old and the new content span, rows heaviest first;
+    the segments that differ go to the twin and straight into host memory over PCIe.
+    Bound: HBM reads of the twin's rows (4 B per pixel composited) + the masks."""
+    import torch
+    import pyflutl as F
+    W, H, states, atlas, source = load_states("cfg2_2160p_8regions_outline", 64, None)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).cuda()
+    A_dev = dev(atlas)
+    nf = 3
+    twins = [torch.zeros(W * H * 4, dtype=torch.uint8, device="cuda") for _ in range(nf)]
+    hosts = [torch.zeros(W * H * 4, dtype=torch.uint8).pin_memory() for _ in range(nf)]
+    park = torch.zeros(W * H * 4, dtype=torch.uint8, device="cuda")
+    changed = torch.zeros(1, dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    per = []
+    for (R, P) in states:
+        live = [r for r in R if r["y1"] > r["y0"]]
+        y0 = min(int(r["y0"]) for r in live)
+        y1 = max(int(r["y1"]) for r in live)
+        m = P[P["op"] == F.OP_MASK]
+        masks = int(((m["cx1"].astype(np.int64) - m["cx0"]) * (m["cy1"].astype(np.int64) - m["cy0"])).sum())
+        per.append((dev(R), len(R), dev(P), y0, y1, dev(F.row_order(W, H, R, P, y0, y1)),
+                    4 * W * (y1 - y0) + masks + R.nbytes + P.nbytes))
+    def launch(i):
+        rd, nr, pd, y0, y1, od, _ = per[i % len(per)]
+        F.launch_frame_delta(stream, W, H, twins[i % nf], hosts[i % nf], park, rd, nr, pd, A_dev,
+                             y0, y1, od, changed)
+    for i in range(3 * len(per)):
+        launch(i)
+    torch.cuda.synchronize()
+    before = int(changed.item())
+    n = 1500
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for i, (a, b) in enumerate(evs):
+        a.record()
+        launch(i)
+        b.record()
+    torch.cuda.synchronize()
+    us = np.array([a.elapsed_time(b) for a, b in evs]) * 1000.0
+    seg = int(changed.item()) - before
+    alg = float(np.mean([p[6] for p in per]))
+    rows = float(np.mean([p[4] - p[3] for p in per]))
+    return {"what": "flutl_launch_frame_delta (the element's per-buffer launch), cfg2 states into "
+                    "3 twin + page-locked host pairs, rows of the regions only",
+            "kernel": "flutl_composite_kernel<DELTA>", "launches_timed": n,
+            "kernel_us": round(float(us.mean()), 2), "kernel_us_median": round(float(np.median(us)), 2),
+            "frames_per_s": round(1e6 / float(us.mean()), 1),
+            "rows_composited": round(rows, 1),
+            "algorithmic_bytes_per_launch": int(alg),
+            "algorithmic_bytes_are": "4*W*rows (twin read) + mask boxes + list; the delta written is extra",
+            "achieved": round(alg / (float(us.mean()) * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(alg / (float(us.mean()) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+            "delta_bytes_per_launch": int(seg * F.delta_segment_bytes() / n)}
+
+
+def configs_block(skip=None):
+    """Every BASELINE config that fits one GPU, in the run the driver makes: 1080p (cfg1)
+    and 4320p (cfg4) batch launches, the 2160p single-frame ordered launch, the element's
+    DELTA launch.  Each: frames/s, kernel time from HIP events, algorithmic bytes per
+    launch and the fraction of the 8 TB/s HBM peak."""
+    out = {}
+    plan = [("cfg1_1080p_4regions", 64, 400, 40), ("cfg4_4320p_16regions", 64, 40, 6),
+            ("cfg2_2160p_8regions_outline", 1, 2000, 200)]
+    for cfg, batch, launches, warm in plan:
+        name = f"{cfg.split('_')[0]}_b{batch}"
+        if skip and name == skip:
+            continue
+        print(f"bench configs: {name}", file=sys.stderr, flush=True)
+        try:
+            r = Resident(cfg, batch)
+            mean_ms, med_ms, fps = r.measure(launches, warm)
+            alg = r.alg_bytes * batch
+            d = {"workload": cfg, "width": r.W, "height": r.H, "frames_per_launch": batch,
+                 "launch": "flutl_launch_batch" if batch > 1 else "flutl_launch_frame_ordered (rows heaviest first)",
+                 "kernel": "flutl_composite_kernel", "launches_timed": launches,
+                 "frames_per_s": round(fps, 1), "mpix_per_s": round(fps * r.W * r.H / 1e6, 1),
+                 "kernel_ms": round(mean_ms, 5), "kernel_ms_median": round(med_ms, 5),
+                 "algorithmic_bytes_per_launch": int(alg), "algorithmic_bytes_from": r.alg_source,
+                 "achieved": round(alg / (mean_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(alg / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 "frac_median": round(alg / (med_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 "scene_source": r.source}
+            tr = profiled_traffic(cfg, batch)
+            if tr:
+                d["traffic"], d["traffic_from"] = tr[0], tr[1]
+            out[name] = d
+            r.free()
+        except Exception as e:      # noqa: BLE001
+            out[name] = {"error": repr(e)[:300]}
+    print("bench configs: delta stream", file=sys.stderr, flush=True)
+    try:
+        out["cfg2_delta_stream"] = delta_stream_block()
+    except Exception as e:      # noqa: BLE001
+        out["cfg2_delta_stream"] = {"error": repr(e)[:300]}
+    return out
 
 
 def self_launch(n):
@@ -253,6 +448,9 @@ def e2e_block(W, H, cpu_baseline, gpu_warm=None, defer_cfg2_ref=False):
             "reference": ref, "reference_from": "typical_4k (120 cues of the same generator)"}
     except Exception as e:      # noqa: BLE001
         out["typical_4k_3000_cues"] = {"error": repr(e)[:300]}
+    # (one attempt per leg; a leg that failed -- or a pipeline killed at its time limit --
+    # is counted here and keeps its error text: nothing is run again)
+    out["errors"] = sum(1 for v in out.values() if isinstance(v, dict) and "error" in v)
     return out
 
 
@@ -274,15 +472,18 @@ def outline_block(with_cpu):
                           device="cuda")
     dst = torch.zeros(h * (w + 4), dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
+    # (as the element's context does: the scratch's leading words are zeroed once and every
+    # conversion leaves them zero -- no memset in front of each)
+    scratch[:F.scan_zero_bytes()].zero_()
     for _ in range(5):
-        F.launch_scan(stream, ed, len(edges), box, 0, scratch, dst, w + 4, 0)
+        F.launch_scan(stream, ed, len(edges), box, 0, scratch, dst, w + 4, F.SCAN_CLEAN)
     torch.cuda.synchronize()
     got = dst.cpu().numpy().reshape(h, w + 4)[:, :w]
     n = 200
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(n):
-        F.launch_scan(stream, ed, len(edges), box, 0, scratch, dst, w + 4, 0)
+        F.launch_scan(stream, ed, len(edges), box, 0, scratch, dst, w + 4, F.SCAN_CLEAN)
     b.record()
     torch.cuda.synchronize()
     us = a.elapsed_time(b) / n * 1000.0
@@ -328,6 +529,8 @@ def main():
     ap.add_argument("--no-row-order", action="store_true",
                     help="--batch 1: supertile rows top to bottom instead of heaviest first")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` block (cfg1 / cfg4 batches, cfg2 single frames, DELTA)")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the element end-to-end block (GStreamer pipeline runs)")
     ap.add_argument("--kernel-launches", type=int, default=400,
@@ -568,10 +771,11 @@ def main():
         }
         if not args.over_video:
             tr = profiled_traffic(args.config, B)
-            res["roofline"]["traffic"] = tr
             if tr:      # HBM-honest fraction: counter bytes, not algorithmic bytes
+                res["roofline"]["traffic"] = tr[0]
+                res["roofline"]["traffic_from"] = tr[1] + " (rocprofv3 PMC passes of this command in an earlier run)"
                 res["roofline"]["traffic_frac"] = round(
-                    tr / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                    tr[0] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         # The element end to end BEFORE the CPU baseline: that leg keeps the GPU idle for a
         # minute (32 reference pipelines on the host cores), after which its clocks are down
         # and stay down under the short bursts of small kernels a 40 ms pipeline run is --
@@ -583,6 +787,9 @@ def main():
             while time.perf_counter() - t0 < 0.5:
                 step(0)
             torch.cuda.synchronize()
+        if world == 1 and not args.no_configs:
+            # (beside the headline's own tensors, which gpu_warm still uses: cfg4's ring is 17 GB)
+            res["configs"] = configs_block(skip=f"{args.config.split('_')[0]}_b{B}")
         if world == 1:
             try:
                 res["outline_scan"] = outline_block(not args.no_cpu_baseline)

@@ -30,6 +30,7 @@ inline bool hip_ok (hipError_t e) { return e == hipSuccess; }
 extern "C" int flutl_launch_scan_counted (void *stream_, const int32_t *edges_dev, uint32_t n_edges,
     const int32_t box[4], int even_odd, void *scratch, void *dst, size_t dst_stride, int mode,
     uint32_t *counters_dev);
+extern "C" size_t flutl_scan_zero_bytes (void);     // (the scratch's leading words that are zero between conversions)
 extern "C" int flutl_launch_scan_hosted (void *stream_, const int32_t *edges, int32_t *raw_copy_dev,
     uint32_t n_edges, const int32_t box[4], int even_odd, void *scratch, void *dst, size_t dst_stride,
     int mode, uint32_t *counters_dev);
@@ -72,14 +73,11 @@ struct flutl_ctx {
   void *scan;          // device scratch of the polygon scan converter (edges + its own)
   size_t scan_cap;
   uint32_t *scan_counters;     // device: [0] polygons the sequential converter took
-  // A second stream (outlines were made on it for a while: a wait of the main stream for
-  // another queue's kernel costs 10-15 us each time, tools/stream_trace.py).
-  // Now: what the context sets up when it is created, nothing per outline.
-  hipStream_t scan_stream;
-  hipEvent_t scan_done;
+  // (ONE stream per context.  Outlines had a stream of their own for a while: a wait of the
+  // main stream for another queue's kernel costs 10-15 us each time, tools/stream_trace.py;
+  // DESIGN 5.7.)
   uint8_t *stage2;
-  size_t stage2_cap, stage2_used;
-  bool outline_pending;         // `stream` has not been told yet to wait for `scan_done`
+  size_t stage2_cap;
   // An outline's edges stay in page-locked host memory: scan_prepare_kernel reads them from
   // there over PCIe (7 us more than from HBM for a 12 000-edge outline) -- no upload on
   // another queue and no wait for it (12 + 13 us of a 73 us cycle, tools/stream_trace.py).
@@ -91,20 +89,6 @@ struct flutl_ctx {
   int cur_half;
   size_t half_used;
 };
-
-// The context's main stream, for anything that may read the atlas: whatever is queued on it
-// comes behind the outlines made so far (recorded in `scan_done` on their own stream).  The
-// wait is put in here, lazily, and not when the outline is queued: a frame's list goes up
-// in front of it (flutl_frame_submit), while the outline is still being converted -- 8 us
-// less per cue on the frame's path.  Every use of the stream goes through here.
-static hipStream_t main_stream (flutl_ctx *c)
-{
-  if (c->outline_pending) {
-    c->outline_pending = false;
-    (void) hipStreamWaitEvent (c->stream, c->scan_done, 0);
-  }
-  return c->stream;
-}
 
 struct flutl_frame {
   int device;
@@ -318,25 +302,17 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
   c->scan = nullptr;
   c->scan_cap = 0;
   c->scan_counters = nullptr;
-  c->scan_stream = nullptr;
-  c->scan_done = nullptr;
   c->stage2 = nullptr;
-  c->stage2_cap = c->stage2_used = 0;
-  c->outline_pending = false;
+  c->stage2_cap = 0;
   c->half_done[0] = c->half_done[1] = nullptr;
   c->half_set[0] = c->half_set[1] = false;
   c->cur_half = 0;
   c->half_used = 0;
-  (void) hipEventCreateWithFlags (&c->half_done[0], hipEventDisableTiming);
-  (void) hipEventCreateWithFlags (&c->half_done[1], hipEventDisableTiming);
-  if (!hip_ok (hipStreamCreateWithFlags (&c->scan_stream, hipStreamNonBlocking)) ||
-      !hip_ok (hipEventCreateWithFlags (&c->scan_done, hipEventDisableTiming))) {
-    if (c->scan_stream)
-      (void) hipStreamDestroy (c->scan_stream);
-    (void) hipStreamDestroy (c->stream);
-    delete c;
-    return FLUTL_ENODEV;
-  }
+  // (without both events an outline's edges are uploaded and waited for instead:
+  // flutl_atlas_put_polygon checks for them)
+  for (int k = 0; k < 2; k++)
+    if (!hip_ok (hipEventCreateWithFlags (&c->half_done[k], hipEventDisableTiming)))
+      c->half_done[k] = nullptr;
   {
     constexpr size_t kStage2Bytes = (size_t) 8 << 20;
     if (hip_ok (hipHostMalloc (reinterpret_cast<void **> (&c->stage2), kStage2Bytes, hipHostMallocDefault)))
@@ -354,18 +330,23 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
   // first such copy, 8 ms measured: zeros over the zeros of the fresh atlas)
   if (c->atlas && c->stage) {
     memset (c->stage, 0, (size_t) 1 << 20);
-    (void) hipMemcpyAsync (c->atlas, c->stage, (size_t) 1 << 20, hipMemcpyHostToDevice, main_stream (c));
-    (void) hipStreamSynchronize (main_stream (c));
+    (void) hipMemcpyAsync (c->atlas, c->stage, (size_t) 1 << 20, hipMemcpyHostToDevice, c->stream);
+    (void) hipStreamSynchronize (c->stream);
   }
   // (... and so is the scan converter's scratch: the first cue of a stream brings the
   // outlines of all its regions)
-  if (hip_ok (hipMalloc (&c->scan, (size_t) 8 << 20)) &&
-      hip_ok (hipMemsetAsync (c->scan, 0, 256, c->scan_stream)))    // (the converter's status words)
-    c->scan_cap = (size_t) 8 << 20;
-  else
+  // (64 MB: the outline of a 4K cue of two lines needs 35 -- each of its 240 pixel rows a
+  // block of up to 2 048 edge records of 64 bytes)
+  if (hip_ok (hipMalloc (&c->scan, (size_t) 64 << 20)) &&
+      hip_ok (hipMemsetAsync (c->scan, 0, flutl_scan_zero_bytes (), c->stream)))    // (the converter's status words, the rows' counts)
+    c->scan_cap = (size_t) 64 << 20;
+  else {
+    if (c->scan)
+      (void) hipFree (c->scan);
     c->scan = nullptr;
+  }
   if (hip_ok (hipMalloc (reinterpret_cast<void **> (&c->scan_counters), 4 * sizeof (uint32_t))))
-    (void) hipMemsetAsync (c->scan_counters, 0, 4 * sizeof (uint32_t), c->scan_stream);
+    (void) hipMemsetAsync (c->scan_counters, 0, 4 * sizeof (uint32_t), c->stream);
   else
     c->scan_counters = nullptr;
   if (c->scan) {
@@ -376,12 +357,11 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
     const int32_t box[4] = { 1, 1, 7, 7 };
     uint8_t *base = static_cast<uint8_t *> (c->scan);
     const size_t own = flutl_scan_scratch_bytes (2, 6, 6);
-    if (hip_ok (hipMemcpyAsync (base + own, tri, sizeof tri, hipMemcpyHostToDevice, c->scan_stream)))
-      (void) flutl_launch_scan_counted (c->scan_stream, reinterpret_cast<const int32_t *> (base + own), 2,
+    if (hip_ok (hipMemcpyAsync (base + own, tri, sizeof tri, hipMemcpyHostToDevice, c->stream)))
+      (void) flutl_launch_scan_counted (c->stream, reinterpret_cast<const int32_t *> (base + own), 2,
           box, 0, base, base + own + 256, 16, 0 | 16, nullptr);
   }
-  (void) hipStreamSynchronize (c->scan_stream);
-  (void) hipStreamSynchronize (main_stream (c));
+  (void) hipStreamSynchronize (c->stream);
   *out = c;
   return FLUTL_OK;
 }
@@ -391,8 +371,7 @@ extern "C" void flutl_ctx_destroy (flutl_ctx *c)
   if (!c)
     return;
   (void) hipSetDevice (c->device);
-  (void) hipStreamSynchronize (c->scan_stream);
-  (void) hipStreamSynchronize (main_stream (c));
+  (void) hipStreamSynchronize (c->stream);
   if (c->atlas)
     (void) hipFree (c->atlas);
   if (c->frame)
@@ -420,8 +399,6 @@ extern "C" void flutl_ctx_destroy (flutl_ctx *c)
       (void) hipEventDestroy (c->half_done[k]);
   if (c->stage2)
     (void) hipHostFree (c->stage2);
-  (void) hipEventDestroy (c->scan_done);
-  (void) hipStreamDestroy (c->scan_stream);
   (void) hipStreamDestroy (c->stream);
   delete c;
 }
@@ -430,10 +407,9 @@ extern "C" int flutl_ctx_sync (flutl_ctx *c)
 {
   if (!c)
     return FLUTL_EINVAL;
-  if (!hip_ok (hipStreamSynchronize (c->scan_stream)) || !hip_ok (hipStreamSynchronize (main_stream (c))))
+  if (!hip_ok (hipStreamSynchronize (c->stream)))
     return FLUTL_ENODEV;
   c->stage_used = 0;       // every staged upload has landed
-  c->stage2_used = 0;
   c->half_used = 0;        // (... and every outline's edges have been read)
   c->half_set[0] = c->half_set[1] = false;
   return FLUTL_OK;
@@ -463,20 +439,14 @@ static int atlas_reserve (flutl_ctx *c, size_t need)
   uint8_t *n = nullptr;
   if (!hip_ok (hipMalloc (reinterpret_cast<void **> (&n), cap)))
     return FLUTL_ENOMEM;
-  // (an outline still being made in the old buffer: wait for it before the copy)
-  if (c->scan_stream && !hip_ok (hipStreamSynchronize (c->scan_stream))) {
+  if (!hip_ok (hipMemsetAsync (n, 0, cap, c->stream))) {
     (void) hipFree (n);
     return FLUTL_ENODEV;
   }
-  if (!hip_ok (hipMemsetAsync (n, 0, cap, main_stream (c)))) {
-    (void) hipFree (n);
-    return FLUTL_ENODEV;
-  }
-  // lists in flight may still read the old buffer: drain first (and the other stream
-  // must not write into the new one before it has been cleared: drained either way)
+  // lists in flight may still read the old buffer: drain first
   if ((c->atlas && !hip_ok (hipMemcpyAsync (n, c->atlas, c->atlas_used, hipMemcpyDeviceToDevice,
-              main_stream (c)))) ||
-      !hip_ok (hipStreamSynchronize (main_stream (c)))) {
+              c->stream))) ||
+      !hip_ok (hipStreamSynchronize (c->stream))) {
     (void) hipFree (n);
     return FLUTL_ENODEV;
   }
@@ -507,19 +477,19 @@ extern "C" int flutl_atlas_put (flutl_ctx *c, const void *src, size_t bytes,
   stage_reserve (c);
   if (c->stage && bytes <= c->stage_cap / 2) {
     if (c->stage_used + bytes > c->stage_cap) {
-      if (!hip_ok (hipStreamSynchronize (main_stream (c))))
+      if (!hip_ok (hipStreamSynchronize (c->stream)))
         return FLUTL_ENODEV;
       c->stage_used = 0;
     }
     memcpy (c->stage + c->stage_used, src, bytes);
     if (!hip_ok (hipMemcpyAsync (c->atlas + off, c->stage + c->stage_used, bytes,
-            hipMemcpyHostToDevice, main_stream (c))))
+            hipMemcpyHostToDevice, c->stream)))
       return FLUTL_ENODEV;
     c->stage_used += (bytes + 63) & ~(size_t) 63;
   } else {
     if (!hip_ok (hipMemcpyAsync (c->atlas + off, src, bytes, hipMemcpyHostToDevice,
-            main_stream (c))) ||
-        !hip_ok (hipStreamSynchronize (main_stream (c))))
+            c->stream)) ||
+        !hip_ok (hipStreamSynchronize (c->stream)))
       return FLUTL_ENODEV;
     c->stage_used = 0;
   }
@@ -561,7 +531,7 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
   constexpr uint32_t kWindow = 4096;
   const size_t own_bytes = flutl_scan_scratch_bytes (n_edges, w < kWindow ? w : kWindow, h);
   const size_t need = edge_bytes + own_bytes;
-  hipStream_t ms = main_stream (c);
+  hipStream_t ms = c->stream;
   if (need > c->scan_cap) {
     // (whatever still reads the old one is ordered before the free by the sync)
     if (c->scan) {
@@ -572,12 +542,15 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
       c->scan_cap = 0;
     }
     size_t cap = need + need / 2;
-    if (cap < ((size_t) 8 << 20))
-      cap = (size_t) 8 << 20;   // (an outline of two 4K lines needs about 3 MB)
+    if (cap < ((size_t) 64 << 20))
+      cap = (size_t) 64 << 20;  // (an outline of two 4K lines needs about 35 MB)
     if (!hip_ok (hipMalloc (&c->scan, cap)))
       return FLUTL_ENOMEM;
-    if (!hip_ok (hipMemsetAsync (c->scan, 0, 256, ms)))
+    if (!hip_ok (hipMemsetAsync (c->scan, 0, flutl_scan_zero_bytes (), ms))) {
+      (void) hipFree (c->scan);
+      c->scan = nullptr;
       return FLUTL_ENODEV;
+    }
     c->scan_cap = cap;
   }
   if (!c->scan_counters) {
@@ -649,8 +622,8 @@ extern "C" uint32_t flutl_ctx_scan_fallbacks (flutl_ctx *c)
   if (!c || !c->scan_counters)
     return 0;
   (void) hipSetDevice (c->device);
-  if (!hip_ok (hipMemcpyAsync (&n, c->scan_counters, sizeof n, hipMemcpyDeviceToHost, main_stream (c))) ||
-      !hip_ok (hipStreamSynchronize (main_stream (c))))
+  if (!hip_ok (hipMemcpyAsync (&n, c->scan_counters, sizeof n, hipMemcpyDeviceToHost, c->stream)) ||
+      !hip_ok (hipStreamSynchronize (c->stream)))
     return 0;
   return n;
 }
@@ -699,7 +672,7 @@ extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
                                               : bytes;
   if (need > c->frame_cap) {
     if (c->frame) {
-      (void) hipStreamSynchronize (main_stream (c));
+      (void) hipStreamSynchronize (c->stream);
       (void) hipFree (c->frame);
       c->frame = nullptr;
       c->frame_cap = 0;
@@ -712,7 +685,7 @@ extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
   flutl_prim *pd;
   if ((rc = upload_list (c, regions, n_regions, prims, n_prims, &rd, &pd)))
     return rc;
-  if ((rc = flutl_launch_frame (main_stream (c), w, h, c->frame, tight, rd, n_regions, pd,
+  if ((rc = flutl_launch_frame (c->stream, w, h, c->frame, tight, rd, n_regions, pd,
            c->atlas)))
     return rc;
   // Gaussian weights: host -> small device buffer
@@ -726,28 +699,28 @@ extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
   const size_t slot0 = rbytes > bytes ? rbytes : bytes;
   uint8_t *blurred = (resample || rotate_cw)
       ? static_cast<uint8_t *> (c->frame) + slot0 : c->atlas + off;
-  bool ok = hip_ok (hipMemcpyAsync (wdev, weights.data (), wbytes, hipMemcpyHostToDevice, main_stream (c)));
+  bool ok = hip_ok (hipMemcpyAsync (wdev, weights.data (), wbytes, hipMemcpyHostToDevice, c->stream));
   if (ok)
-    ok = flutl_launch_blur (main_stream (c), c->frame, blurred, w, h, tight, wdev,
+    ok = flutl_launch_blur (c->stream, c->frame, blurred, w, h, tight, wdev,
         radius) == FLUTL_OK;
   if (ok && resample && !rotate_cw)
-    ok = flutl_launch_resample (main_stream (c), blurred, c->atlas + off, w, h, tight, etight,
+    ok = flutl_launch_resample (c->stream, blurred, c->atlas + off, w, h, tight, etight,
         distx, disty, box) == FLUTL_OK;
   if (ok && rotate_cw) {
     const uint8_t *turn_src = blurred;
     if (resample) {         // resample (no box) into staging slot 0, then turn that
-      ok = flutl_launch_resample (main_stream (c), blurred, c->frame, w, h, tight, (size_t) rw * 4,
+      ok = flutl_launch_resample (c->stream, blurred, c->frame, w, h, tight, (size_t) rw * 4,
           distx, disty, nullptr) == FLUTL_OK;
       turn_src = static_cast<const uint8_t *> (c->frame);
     }
     if (ok)
-      ok = flutl_launch_rotate_cw (main_stream (c), turn_src, c->atlas + off, rw, rh,
+      ok = flutl_launch_rotate_cw (c->stream, turn_src, c->atlas + off, rw, rh,
           (size_t) rw * 4, etight, box) == FLUTL_OK;
   }
   if (ok && host_copy)
     ok = hip_ok (hipMemcpyAsync (host_copy, c->atlas + off, ebytes, hipMemcpyDeviceToHost,
-        main_stream (c)));
-  ok = hip_ok (hipStreamSynchronize (main_stream (c))) && ok;
+        c->stream));
+  ok = hip_ok (hipStreamSynchronize (c->stream)) && ok;
   (void) hipFree (wdev);
   if (!ok)
     return FLUTL_ENODEV;
@@ -816,11 +789,11 @@ extern "C" int flutl_list_create (flutl_ctx *c, uint32_t width, uint32_t height,
   bool ok = true;
   if (n_regions)
     ok = ok && hip_ok (hipMemcpyAsync (l->regions, regions,
-        (size_t) n_regions * sizeof (flutl_region), hipMemcpyHostToDevice, main_stream (c)));
+        (size_t) n_regions * sizeof (flutl_region), hipMemcpyHostToDevice, c->stream));
   if (n_prims)
     ok = ok && hip_ok (hipMemcpyAsync (l->prims, prims, pb, hipMemcpyHostToDevice,
-        main_stream (c)));
-  ok = ok && hip_ok (hipStreamSynchronize (main_stream (c)));
+        c->stream));
+  ok = ok && hip_ok (hipStreamSynchronize (c->stream));
   if (!ok) {
     (void) hipFree (l->mem);
     delete l;
@@ -836,7 +809,7 @@ extern "C" void flutl_list_destroy (flutl_ctx *c, flutl_list *l)
     return;
   if (c) {
     (void) hipSetDevice (c->device);
-    (void) hipStreamSynchronize (main_stream (c));
+    (void) hipStreamSynchronize (c->stream);
   }
   if (l->mem)
     (void) hipFree (l->mem);
@@ -849,7 +822,7 @@ extern "C" int flutl_render (flutl_ctx *c, const flutl_list *l, void *dst_dev,
   if (!c || !l || !dst_dev)
     return FLUTL_EINVAL;
   (void) hipSetDevice (c->device);
-  return flutl_launch_frame (main_stream (c), l->width, l->height, dst_dev,
+  return flutl_launch_frame (c->stream, l->width, l->height, dst_dev,
       dst_stride_bytes, l->regions, l->n_regions, l->prims, c->atlas);
 }
 
@@ -911,7 +884,7 @@ static int upload_list (flutl_ctx *c, const flutl_region *regions, uint32_t n_re
   const size_t pb = (size_t) n_prims * sizeof (flutl_prim);
   if (rb + pb + 32 > c->listbuf_cap) {
     if (c->listbuf) {
-      (void) hipStreamSynchronize (main_stream (c));
+      (void) hipStreamSynchronize (c->stream);
       (void) hipFree (c->listbuf);
       c->listbuf = nullptr;
       c->listbuf_cap = 0;
@@ -928,9 +901,9 @@ static int upload_list (flutl_ctx *c, const flutl_region *regions, uint32_t n_re
   bool ok = true;
   if (n_regions)
     ok = ok && hip_ok (hipMemcpyAsync (rd, regions, (size_t) n_regions * sizeof (flutl_region),
-        hipMemcpyHostToDevice, main_stream (c)));
+        hipMemcpyHostToDevice, c->stream));
   if (n_prims)
-    ok = ok && hip_ok (hipMemcpyAsync (pd, prims, pb, hipMemcpyHostToDevice, main_stream (c)));
+    ok = ok && hip_ok (hipMemcpyAsync (pd, prims, pb, hipMemcpyHostToDevice, c->stream));
   if (!ok)
     return FLUTL_ENODEV;
   *rd_out = rd;
@@ -962,7 +935,7 @@ static int render_lists_to_host (flutl_ctx *c, uint32_t width, uint32_t height,
   const size_t need = tight * l->height;
   if (need > c->frame_cap) {
     if (c->frame) {
-      (void) hipStreamSynchronize (main_stream (c));
+      (void) hipStreamSynchronize (c->stream);
       (void) hipFree (c->frame);
       c->frame = nullptr;
       c->frame_cap = 0;
@@ -971,7 +944,7 @@ static int render_lists_to_host (flutl_ctx *c, uint32_t width, uint32_t height,
       return FLUTL_ENOMEM;
     c->frame_cap = need;
   }
-  int rc = flutl_launch_frame (main_stream (c), l->width, l->height, c->frame, tight,
+  int rc = flutl_launch_frame (c->stream, l->width, l->height, c->frame, tight,
       l->regions, l->n_regions, l->prims, c->atlas);
   if (rc)
     return rc;
@@ -991,12 +964,12 @@ static int render_lists_to_host (flutl_ctx *c, uint32_t width, uint32_t height,
         (size_t) col0 * 4;
     const size_t wbytes = (size_t) (col1 - col0) * 4;
     if (dst_stride_bytes == tight && wbytes == tight)
-      ok = hip_ok (hipMemcpyAsync (d, sp, tight * rows, hipMemcpyDeviceToHost, main_stream (c)));
+      ok = hip_ok (hipMemcpyAsync (d, sp, tight * rows, hipMemcpyDeviceToHost, c->stream));
     else
       ok = hip_ok (hipMemcpy2DAsync (d, dst_stride_bytes, sp, tight, wbytes, rows,
-          hipMemcpyDeviceToHost, main_stream (c)));
+          hipMemcpyDeviceToHost, c->stream));
   }
-  if (!hip_ok (hipStreamSynchronize (main_stream (c))) || !ok)
+  if (!hip_ok (hipStreamSynchronize (c->stream)) || !ok)
     return FLUTL_ENODEV;
   return FLUTL_OK;
 }
@@ -1027,7 +1000,7 @@ extern "C" int flutl_blend_over_host (flutl_ctx *c, uint32_t width, uint32_t hei
   const uint32_t fy0 = y0 & ~15u, fy1 = ((y1 + 15u) & ~15u) < height ? ((y1 + 15u) & ~15u) : height;
   const size_t tight = (size_t) width * 4, frame_bytes = tight * height;
   if (2 * frame_bytes > c->frame_cap) {
-    (void) hipStreamSynchronize (main_stream (c));
+    (void) hipStreamSynchronize (c->stream);
     if (c->frame)
       (void) hipFree (c->frame);
     c->frame = nullptr;
@@ -1045,14 +1018,14 @@ extern "C" int flutl_blend_over_host (flutl_ctx *c, uint32_t width, uint32_t hei
   const size_t rows = fy1 - fy0;
   bool ok = hip_ok (hipMemcpy2DAsync (vid + (size_t) fy0 * tight, tight,
       host + (size_t) fy0 * stride_bytes, stride_bytes, tight, rows, hipMemcpyHostToDevice,
-      main_stream (c)));
+      c->stream));
   if (ok)
-    ok = flutl_launch_frame_over_rows (main_stream (c), width, height, dst, vid, tight, rd, n_regions,
+    ok = flutl_launch_frame_over_rows (c->stream, width, height, dst, vid, tight, rd, n_regions,
         pd, c->atlas, fy0, fy1) == FLUTL_OK;
   if (ok)
     ok = hip_ok (hipMemcpy2DAsync (host + (size_t) fy0 * stride_bytes, stride_bytes,
-        dst + (size_t) fy0 * tight, tight, tight, rows, hipMemcpyDeviceToHost, main_stream (c)));
-  if (!hip_ok (hipStreamSynchronize (main_stream (c))) || !ok)
+        dst + (size_t) fy0 * tight, tight, tight, rows, hipMemcpyDeviceToHost, c->stream));
+  if (!hip_ok (hipStreamSynchronize (c->stream)) || !ok)
     return FLUTL_ENODEV;
   return FLUTL_OK;
 }
@@ -1088,9 +1061,9 @@ extern "C" int flutl_frame_create (flutl_ctx *c, uint32_t width, uint32_t height
   // the transparent frame, in both copies: cleared by the device in stream order
   // (the host block over PCIe: no 33 MB memset on the caller's thread, and no
   // wait -- whatever is submitted into the frame comes later on the same stream)
-  ok = ok && hip_ok (hipMemsetAsync (f->twin, 0, bytes, main_stream (c))) &&
-      hip_ok (hipMemsetAsync (f->host_dev, 0, bytes, main_stream (c))) &&
-      hip_ok (hipEventRecord (f->done, main_stream (c)));
+  ok = ok && hip_ok (hipMemsetAsync (f->twin, 0, bytes, c->stream)) &&
+      hip_ok (hipMemsetAsync (f->host_dev, 0, bytes, c->stream)) &&
+      hip_ok (hipEventRecord (f->done, c->stream));
   if (ok)
     f->pending = true;
   if (!ok) {
@@ -1144,8 +1117,8 @@ extern "C" uint64_t flutl_ctx_delta_bytes (flutl_ctx *c)
   if (!c || !c->delta_segments)
     return 0;
   (void) hipSetDevice (c->device);
-  if (!hip_ok (hipMemcpyAsync (&n, c->delta_segments, sizeof n, hipMemcpyDeviceToHost, main_stream (c))) ||
-      !hip_ok (hipStreamSynchronize (main_stream (c))))
+  if (!hip_ok (hipMemcpyAsync (&n, c->delta_segments, sizeof n, hipMemcpyDeviceToHost, c->stream)) ||
+      !hip_ok (hipStreamSynchronize (c->stream)))
     return 0;
   return n * flutl_delta_segment_bytes ();
 }
@@ -1225,7 +1198,7 @@ extern "C" int flutl_frame_submit (flutl_ctx *c, flutl_frame *f,
   // scratch frame of the context (here: where translucent groups park pixels)
   const size_t need = (size_t) width * 4 * height;
   if (need > c->frame_cap) {
-    (void) hipStreamSynchronize (main_stream (c));
+    (void) hipStreamSynchronize (c->stream);
     if (c->frame)
       (void) hipFree (c->frame);
     c->frame = nullptr;
@@ -1245,23 +1218,23 @@ extern "C" int flutl_frame_submit (flutl_ctx *c, flutl_frame *f,
   const flutl_prim *pd = reinterpret_cast<const flutl_prim *> (static_cast<uint8_t *> (sl.dev) + rb);
   if (!c->delta_segments) {
     if (!hip_ok (hipMalloc (reinterpret_cast<void **> (&c->delta_segments), sizeof (uint64_t))) ||
-        !hip_ok (hipMemsetAsync (c->delta_segments, 0, sizeof (uint64_t), main_stream (c))))
+        !hip_ok (hipMemsetAsync (c->delta_segments, 0, sizeof (uint64_t), c->stream)))
       rc = FLUTL_ENOMEM;
   }
   // one launch: composite those rows, compare with the twin, write what differs
   // into the twin and the host block (flutl_launch_frame_delta)
   if (rc == FLUTL_OK && n_order)
-    rc = flutl_launch_frame_delta (main_stream (c), width, height, f->twin, f->host_dev, c->frame,
+    rc = flutl_launch_frame_delta (c->stream, width, height, f->twin, f->host_dev, c->frame,
         (size_t) width * 4, rd, n_regions, pd, c->atlas, y0, y1,
         reinterpret_cast<const uint16_t *> (static_cast<uint8_t *> (sl.dev) + rb + pb),
         c->delta_segments);
-  ok = rc == FLUTL_OK && hip_ok (hipEventRecord (sl.done, main_stream (c))) &&
-      hip_ok (hipEventRecord (f->done, main_stream (c)));
+  ok = rc == FLUTL_OK && hip_ok (hipEventRecord (sl.done, c->stream)) &&
+      hip_ok (hipEventRecord (f->done, c->stream));
   sl.busy = true;
   f->pending = true;
   if (!ok) {
     // whatever was queued: the frame's content is unknown from here on
-    (void) hipStreamSynchronize (main_stream (c));
+    (void) hipStreamSynchronize (c->stream);
     f->error = rc ? rc : FLUTL_ENODEV;
     return f->error;
   }

@@ -24,7 +24,6 @@
  * (nothing the reference can render in a sane time; what is beyond a limit fails the buffer).
  */
 #ifdef HAVE_CONFIG_H
-#include <libxml/parser.h>
 #include "config.h"
 #endif
 
@@ -36,6 +35,7 @@
 #include <gst/video/video.h>
 #include <gst/video/video-overlay-composition.h>
 #include <pango/pangocairo.h>
+#include <libxml/parser.h>      /* xmlInitParser (gst_ttmlrender_class_init) */
 
 #include "gstttmlbase.h"
 #include "gstttmlrender.h"

@@ -59,7 +59,7 @@ EXPORTS = [
     "flutl_frame_create", "flutl_frame_destroy", "flutl_frame_host",
     "flutl_frame_device", "flutl_frame_submit", "flutl_frame_wait", "flutl_ctx_delta_bytes",
     "flutl_atlas_put_polygon", "flutl_polygon_entry_bytes", "flutl_ctx_scan_fallbacks",
-    "flutl_scan_scratch_bytes", "flutl_launch_scan", "flutl_scan_status",
+    "flutl_scan_scratch_bytes", "flutl_scan_zero_bytes", "flutl_launch_scan", "flutl_scan_status",
 ]
 
 
@@ -120,6 +120,8 @@ def lib():
         L.flutl_ctx_scan_fallbacks.restype = u32
         L.flutl_scan_scratch_bytes.argtypes = [u32, u32, u32]
         L.flutl_scan_scratch_bytes.restype = sz
+        L.flutl_scan_zero_bytes.argtypes = []
+        L.flutl_scan_zero_bytes.restype = sz
         L.flutl_launch_scan.argtypes = [vp, vp, u32, vp, ctypes.c_int, vp, vp, sz, ctypes.c_int]
         L.flutl_scan_status.argtypes = [vp, vp, u32, u32, ctypes.POINTER(u32)]
         L.flutl_launch_rotate_cw.argtypes = [vp, vp, vp, u32, u32, sz, sz, vp]
@@ -285,6 +287,13 @@ def launch_blur(stream, src, dst, w, h, kernel_dev, radius, stride=None):
 
 def scan_scratch_bytes(n_edges, width, height):
     return int(lib().flutl_scan_scratch_bytes(n_edges, width, height))
+
+
+SCAN_CLEAN = 16     # mode flag: the scratch's first scan_zero_bytes() are zero (include/flutl.h)
+
+
+def scan_zero_bytes():
+    return int(lib().flutl_scan_zero_bytes())
 
 
 def launch_scan(stream, edges_dev, n_edges, box, even_odd, scratch, dst, stride, mode=0):

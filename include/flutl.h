@@ -344,8 +344,13 @@ uint32_t flutl_ctx_scan_fallbacks (flutl_ctx *ctx);
  * dst: (x1 - x0) x (y1 - y0) bytes at dst_stride.  mode 0: one workgroup per pixel row,
  * and the sequential converter behind it for a polygon the rows flagged; 1: rows only
  * (flutl_scan_status then says whether they flagged: bit 0 an undecided tie, bit 1 too
- * many edges in a row); 2: the sequential converter alone. */
+ * many edges in a row); 2: the sequential converter alone.
+ * | FLUTL_SCAN_CLEAN: the caller has zeroed the first flutl_scan_zero_bytes () bytes of
+ * `scratch` once; every conversion leaves them zero, so a scratch buffer that serves one
+ * conversion after the other (as the context's does) needs no memset in front of each. */
+#define FLUTL_SCAN_CLEAN 16
 size_t flutl_scan_scratch_bytes (uint32_t n_edges, uint32_t width, uint32_t height);
+size_t flutl_scan_zero_bytes (void);
 int  flutl_launch_scan (void *stream, const int32_t *edges_dev, uint32_t n_edges,
     const int32_t box[4], int even_odd, void *scratch, void *dst, size_t dst_stride, int mode);
 int  flutl_scan_status (void *stream, const void *scratch, uint32_t n_edges, uint32_t height,

@@ -48,7 +48,8 @@ def test_profiled_traffic_of_the_default_command_is_committed():
     import re
     batch = int(re.search(r'"--batch", type=int, default=(\d+)', src).group(1))
     t = b.profiled_traffic("cfg2_2160p_8regions_outline", batch)
-    assert t is not None and t > batch * 3840 * 2160 * 4 * 0.99
+    assert t is not None and t[0] > batch * 3840 * 2160 * 4 * 0.99
+    assert t[1].startswith("profiles/") and os.path.exists(os.path.join(ROOT, t[1]))
 
 
 def test_every_stream_of_config3_has_reference_hashes():

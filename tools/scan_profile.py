@@ -41,7 +41,8 @@ ed = torch.from_numpy(np.ascontiguousarray(edges, np.int32).view(np.uint8).resha
 scratch = torch.empty(F.scan_scratch_bytes(len(edges), w, h) + 256, dtype=torch.uint8, device="cuda")
 dst = torch.empty(h * (w + 4), dtype=torch.uint8, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
+scratch[:F.scan_zero_bytes()].zero_()
 for _ in range(50):
-    F.launch_scan(stream, ed, len(edges), box, 0, scratch, dst, w + 4, 0)
+    F.launch_scan(stream, ed, len(edges), box, 0, scratch, dst, w + 4, F.SCAN_CLEAN)
 torch.cuda.synchronize()
 print(f"{len(edges)} edges, box {w}x{h}")

@@ -14,7 +14,10 @@ import pyflutl as F  # noqa: E402
 z = np.load(os.path.join(ROOT, "tests", "golden", "polygons.npz"))
 meta = z["meta"]
 which = sys.argv[1] if len(sys.argv) > 1 else "big"
-if which == "big":
+if which == "bench":
+    b = np.load(os.path.join(ROOT, "bench_data", "outline_4k.npz"))
+    edges, box = b["edges0"], tuple(int(v) for v in b["meta"][0][1:5])
+elif which == "big":
     text = [i for i in range(len(meta)) if meta[i][0] == 2]
     parts, x = [], 0
     for i in text:
