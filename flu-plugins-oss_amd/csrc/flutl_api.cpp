@@ -53,7 +53,11 @@ struct list_slot {
   hipEvent_t done;     // recorded after the last kernel that reads `dev`
   bool busy;
 };
-constexpr int kListSlots = 4;    // submissions in flight per context
+constexpr int kListSlots = 8;    // submissions in flight per context
+constexpr int kEdgeBlocks = 32;          // page-locked blocks for outlines' edges ...
+constexpr size_t kEdgeBlockBytes = (size_t) 1 << 20;     // ... of 37 000 edges each
+constexpr int kEdgeEpochEvents = 16;
+constexpr uint32_t kEdgeEpochPolygons = 4;       // an event behind every so many polygons
 
 struct flutl_ctx {
   int device;
@@ -76,18 +80,22 @@ struct flutl_ctx {
   // (ONE stream per context.  Outlines had a stream of their own for a while: a wait of the
   // main stream for another queue's kernel costs 10-15 us each time, tools/stream_trace.py;
   // DESIGN 5.7.)
-  uint8_t *stage2;
-  size_t stage2_cap;
   // An outline's edges stay in page-locked host memory: scan_prepare_kernel reads them from
   // there over PCIe (7 us more than from HBM for a 12 000-edge outline) -- no upload on
-  // another queue and no wait for it (12 + 13 us of a 73 us cycle, tools/stream_trace.py).
-  // `stage2` is used in two halves; a half is written again only after `half_done` of its
-  // last use (recorded behind the last kernel that read it) has been waited for on the host,
-  // some twenty outlines later.
-  hipEvent_t half_done[2];
-  bool half_set[2];
-  int cur_half;
-  size_t half_used;
+  // another queue and no wait for it.  The memory is an arena of blocks
+  // (flutl_ctx_edge_block_acquire: the element's stroke workers write their polygon's edges
+  // straight into one, so nobody copies them on the thread that feeds the device;
+  // flutl_atlas_put_polygon takes a block of its own for edges that come from elsewhere).
+  // A block is free again when the kernels that read it are done: every few polygons an
+  // event is recorded behind them (an "epoch"), looked at only when blocks run short.
+  uint8_t *edge_arena;
+  std::mutex *edge_lock;        // block states (workers acquire / release; the device's owner queues)
+  int8_t edge_state[kEdgeBlocks];       // 0 free, 1 out with a caller, 2 queued (edge_epoch)
+  uint32_t edge_epoch[kEdgeBlocks];
+  hipEvent_t epoch_done[kEdgeEpochEvents];
+  uint32_t epoch_cur;           // epoch of the polygons being queued now
+  uint32_t epoch_known;         // epochs below this one are known complete
+  uint32_t epoch_uses;          // polygons queued in epoch_cur
 };
 
 struct flutl_frame {
@@ -302,23 +310,22 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
   c->scan = nullptr;
   c->scan_cap = 0;
   c->scan_counters = nullptr;
-  c->stage2 = nullptr;
-  c->stage2_cap = 0;
-  c->half_done[0] = c->half_done[1] = nullptr;
-  c->half_set[0] = c->half_set[1] = false;
-  c->cur_half = 0;
-  c->half_used = 0;
-  // (without both events an outline's edges are uploaded and waited for instead:
-  // flutl_atlas_put_polygon checks for them)
-  for (int k = 0; k < 2; k++)
-    if (!hip_ok (hipEventCreateWithFlags (&c->half_done[k], hipEventDisableTiming)))
-      c->half_done[k] = nullptr;
+  c->edge_arena = nullptr;
+  c->edge_lock = new (std::nothrow) std::mutex ();
+  memset (c->edge_state, 0, sizeof c->edge_state);
+  memset (c->edge_epoch, 0, sizeof c->edge_epoch);
+  c->epoch_cur = c->epoch_known = 1;
+  c->epoch_uses = 0;
+  for (auto &e : c->epoch_done)
+    e = nullptr;
   {
-    constexpr size_t kStage2Bytes = (size_t) 8 << 20;
-    if (hip_ok (hipHostMalloc (reinterpret_cast<void **> (&c->stage2), kStage2Bytes, hipHostMallocDefault)))
-      c->stage2_cap = kStage2Bytes;
-    else
-      c->stage2 = nullptr;
+    bool ok = c->edge_lock != nullptr;
+    for (auto &e : c->epoch_done)
+      ok = ok && hip_ok (hipEventCreateWithFlags (&e, hipEventDisableTiming));
+    // (without the arena an outline's edges are uploaded and waited for instead)
+    if (!ok || !hip_ok (hipHostMalloc (reinterpret_cast<void **> (&c->edge_arena),
+            kEdgeBlocks * kEdgeBlockBytes, hipHostMallocDefault)))
+      c->edge_arena = nullptr;
   }
   // The first masks of a stream come with its first frame, and the caller's
   // recording thread may be waiting on whoever uploads them: the atlas and the
@@ -335,11 +342,9 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
   }
   // (... and so is the scan converter's scratch: the first cue of a stream brings the
   // outlines of all its regions)
-  // (64 MB: the outline of a 4K cue of two lines needs 35 -- each of its 240 pixel rows a
-  // block of up to 2 048 edge records of 64 bytes)
-  if (hip_ok (hipMalloc (&c->scan, (size_t) 64 << 20)) &&
+  if (hip_ok (hipMalloc (&c->scan, (size_t) 8 << 20)) &&
       hip_ok (hipMemsetAsync (c->scan, 0, flutl_scan_zero_bytes (), c->stream)))    // (the converter's status words, the rows' counts)
-    c->scan_cap = (size_t) 64 << 20;
+    c->scan_cap = (size_t) 8 << 20;
   else {
     if (c->scan)
       (void) hipFree (c->scan);
@@ -394,11 +399,12 @@ extern "C" void flutl_ctx_destroy (flutl_ctx *c)
     (void) hipFree (c->scan);
   if (c->scan_counters)
     (void) hipFree (c->scan_counters);
-  for (int k = 0; k < 2; k++)
-    if (c->half_done[k])
-      (void) hipEventDestroy (c->half_done[k]);
-  if (c->stage2)
-    (void) hipHostFree (c->stage2);
+  for (auto &e : c->epoch_done)
+    if (e)
+      (void) hipEventDestroy (e);
+  if (c->edge_arena)
+    (void) hipHostFree (c->edge_arena);
+  delete c->edge_lock;
   (void) hipStreamDestroy (c->stream);
   delete c;
 }
@@ -410,8 +416,17 @@ extern "C" int flutl_ctx_sync (flutl_ctx *c)
   if (!hip_ok (hipStreamSynchronize (c->stream)))
     return FLUTL_ENODEV;
   c->stage_used = 0;       // every staged upload has landed
-  c->half_used = 0;        // (... and every outline's edges have been read)
-  c->half_set[0] = c->half_set[1] = false;
+  if (c->edge_lock) {      // (... and every outline's edges have been read)
+    std::lock_guard<std::mutex> g (*c->edge_lock);
+    for (int k = 0; k < kEdgeBlocks; k++)
+      if (c->edge_state[k] == 2)
+        c->edge_state[k] = 0;
+    if (c->epoch_uses) {
+      c->epoch_cur++;
+      c->epoch_uses = 0;
+    }
+    c->epoch_known = c->epoch_cur;
+  }
   return FLUTL_OK;
 }
 
@@ -501,6 +516,75 @@ extern "C" int flutl_atlas_put (flutl_ctx *c, const void *src, size_t bytes,
 static int upload_list (flutl_ctx *c, const flutl_region *regions, uint32_t n_regions,
     const flutl_prim *prims, uint32_t n_prims, flutl_region **rd, flutl_prim **pd);
 
+// ---- the arena of page-locked edge blocks (see flutl_ctx) ---------------------------------
+// epochs known complete -> their blocks free.  wait: block until at least the oldest
+// outstanding epoch is done (its event is recorded first if it is the current one).
+static void edge_blocks_reclaim (flutl_ctx *c, bool wait)
+{
+  // (the caller holds edge_lock)
+  if (wait && c->epoch_known == c->epoch_cur && c->epoch_uses) {
+    if (hip_ok (hipEventRecord (c->epoch_done[c->epoch_cur % kEdgeEpochEvents], c->stream))) {
+      c->epoch_cur++;
+      c->epoch_uses = 0;
+    }
+  }
+  while (c->epoch_known < c->epoch_cur) {
+    hipEvent_t ev = c->epoch_done[c->epoch_known % kEdgeEpochEvents];
+    if (wait) {
+      if (!hip_ok (hipEventSynchronize (ev)))
+        break;
+      wait = false;             // (one epoch waited for; the rest only if they are done already)
+    } else if (hipEventQuery (ev) != hipSuccess) {
+      break;
+    }
+    c->epoch_known++;
+  }
+  for (int k = 0; k < kEdgeBlocks; k++)
+    if (c->edge_state[k] == 2 && c->edge_epoch[k] < c->epoch_known)
+      c->edge_state[k] = 0;
+}
+
+static void *edge_block_take (flutl_ctx *c, bool may_wait)
+{
+  for (int pass = 0; pass < 3; pass++) {
+    for (int k = 0; k < kEdgeBlocks; k++)
+      if (c->edge_state[k] == 0) {
+        c->edge_state[k] = 1;
+        return c->edge_arena + (size_t) k * kEdgeBlockBytes;
+      }
+    if (pass == 2 || (pass == 1 && !may_wait))
+      break;
+    edge_blocks_reclaim (c, pass == 1);
+  }
+  return nullptr;
+}
+
+extern "C" int flutl_ctx_edge_block_acquire (flutl_ctx *c, size_t bytes, void **block_out)
+{
+  if (!c || !block_out)
+    return FLUTL_EINVAL;
+  *block_out = nullptr;
+  if (!c->edge_arena || bytes > kEdgeBlockBytes)
+    return FLUTL_ENOMEM;
+  std::lock_guard<std::mutex> g (*c->edge_lock);
+  // (a worker thread never waits for the device: without a free block its edges stay where
+  // they are and are copied by flutl_atlas_put_polygon)
+  *block_out = edge_block_take (c, false);
+  return *block_out ? FLUTL_OK : FLUTL_ENOMEM;
+}
+
+extern "C" void flutl_ctx_edge_block_release (flutl_ctx *c, void *block)
+{
+  if (!c || !block || !c->edge_arena)
+    return;
+  const size_t off = static_cast<uint8_t *> (block) - c->edge_arena;
+  if (off >= kEdgeBlocks * kEdgeBlockBytes || off % kEdgeBlockBytes)
+    return;
+  std::lock_guard<std::mutex> g (*c->edge_lock);
+  if (c->edge_state[off / kEdgeBlockBytes] == 1)
+    c->edge_state[off / kEdgeBlockBytes] = 0;
+}
+
 extern "C" size_t flutl_polygon_entry_bytes (uint32_t w, uint32_t h)
 {
   return 4 + ((size_t) w + 4) * h;
@@ -513,6 +597,13 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
       box[0] < 0 || box[1] < 0 || box[2] - box[0] > 32767 || box[3] - box[1] > 32767)
     return FLUTL_EINVAL;
   (void) hipSetDevice (c->device);
+  // (a block of the arena is the context's from here on, whatever happens: one that never
+  // gets queued goes back at once)
+  struct BlockGuard {
+    flutl_ctx *c;
+    const void *p;
+    ~BlockGuard () { flutl_ctx_edge_block_release (c, const_cast<void *> (p)); }
+  } guard { c, edges };
   const uint32_t w = (uint32_t) (box[2] - box[0]), h = (uint32_t) (box[3] - box[1]);
   const size_t bytes = flutl_polygon_entry_bytes (w, h);
   const size_t off = (c->atlas_used + kAtlasAlign - 1) & ~(kAtlasAlign - 1);
@@ -542,8 +633,8 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
       c->scan_cap = 0;
     }
     size_t cap = need + need / 2;
-    if (cap < ((size_t) 64 << 20))
-      cap = (size_t) 64 << 20;  // (an outline of two 4K lines needs about 35 MB)
+    if (cap < ((size_t) 8 << 20))
+      cap = (size_t) 8 << 20;   // (an outline of two 4K lines needs about 3 MB)
     if (!hip_ok (hipMalloc (&c->scan, cap)))
       return FLUTL_ENOMEM;
     if (!hip_ok (hipMemsetAsync (c->scan, 0, flutl_scan_zero_bytes (), ms))) {
@@ -564,28 +655,34 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
   int32_t *raw_copy = nullptr;
   if (n_edges) {
     const size_t eb = (size_t) n_edges * 7 * sizeof (int32_t);
-    const size_t half_cap = c->stage2 ? c->stage2_cap / 2 : 0;
-    if (c->half_done[0] && c->half_done[1] && eb <= half_cap) {
-      if (c->half_used + eb > half_cap) {
-        // this half is full: it may be written again behind everything queued so far
-        if (!hip_ok (hipEventRecord (c->half_done[c->cur_half], ms)))
-          return FLUTL_ENODEV;
-        c->half_set[c->cur_half] = true;
-        c->cur_half ^= 1;
-        c->half_used = 0;
-        if (c->half_set[c->cur_half]) {
-          if (!hip_ok (hipEventSynchronize (c->half_done[c->cur_half])))
-            return FLUTL_ENODEV;
-          c->half_set[c->cur_half] = false;
+    // edges in a block of the arena already (the caller's worker wrote them there), or
+    // copied into one now
+    int block = -1;
+    if (c->edge_arena) {
+      const uint8_t *e8 = reinterpret_cast<const uint8_t *> (edges);
+      std::lock_guard<std::mutex> g (*c->edge_lock);
+      if (e8 >= c->edge_arena && e8 < c->edge_arena + kEdgeBlocks * kEdgeBlockBytes) {
+        block = (int) ((e8 - c->edge_arena) / kEdgeBlockBytes);
+        if ((size_t) (e8 - c->edge_arena) % kEdgeBlockBytes || eb > kEdgeBlockBytes ||
+            c->edge_state[block] != 1)
+          return FLUTL_EINVAL;
+        edges_src = edges;
+      } else if (eb <= kEdgeBlockBytes) {
+        uint8_t *at = static_cast<uint8_t *> (edge_block_take (c, true));
+        if (at) {
+          block = (int) ((at - c->edge_arena) / kEdgeBlockBytes);
+          memcpy (at, edges, eb);
+          edges_src = reinterpret_cast<const int32_t *> (at);
         }
       }
-      uint8_t *at = c->stage2 + (size_t) c->cur_half * half_cap + c->half_used;
-      memcpy (at, edges, eb);
-      c->half_used += (eb + 255) & ~(size_t) 255;
-      edges_src = reinterpret_cast<const int32_t *> (at);
-      raw_copy = edges_dev;
-    } else {
-      // (more edges than half the staging memory holds: uploaded, and waited for)
+      if (block >= 0) {
+        raw_copy = edges_dev;
+        c->edge_state[block] = 2;
+        c->edge_epoch[block] = c->epoch_cur;
+      }
+    }
+    if (block < 0) {
+      // (more edges than a block holds, or no arena: uploaded, and waited for)
       if (!hip_ok (hipMemcpyAsync (edges_dev, edges, eb, hipMemcpyHostToDevice, ms)) ||
           !hip_ok (hipStreamSynchronize (ms)))
         return FLUTL_ENODEV;
@@ -607,6 +704,20 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
       rc = flutl_launch_scan_hosted (ms, x == 0 ? edges_src : edges_dev, x == 0 ? raw_copy : nullptr,
           n_edges, wbox, even_odd, c->scan, c->atlas + off + 4 + x, (size_t) w + 4, 0 | pad | 16,
           c->scan_counters);
+    }
+  }
+  if (n_edges && c->edge_arena && edges_src != edges_dev) {
+    // an event behind every few polygons: what frees their blocks (edge_blocks_reclaim)
+    std::lock_guard<std::mutex> g (*c->edge_lock);
+    if (++c->epoch_uses >= kEdgeEpochPolygons) {
+      // (the event's slot comes round every kEdgeEpochEvents epochs: 64 polygons, twice
+      // what the arena holds -- its earlier use has been seen complete long since)
+      if (c->epoch_cur - c->epoch_known >= (uint32_t) kEdgeEpochEvents - 1)
+        edge_blocks_reclaim (c, true);
+      if (hip_ok (hipEventRecord (c->epoch_done[c->epoch_cur % kEdgeEpochEvents], ms))) {
+        c->epoch_cur++;
+        c->epoch_uses = 0;
+      }
     }
   }
   if (rc)

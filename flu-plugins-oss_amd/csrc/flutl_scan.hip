@@ -43,6 +43,7 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "flutl.h"
 
 namespace {
@@ -135,18 +136,39 @@ __device__ inline void normalise (int32_t &q, int64_t &r, int64_t D)
   }
 }
 
+// a / d and a % d as C has them (towards zero), d > 0.  A 64-bit integer division is some
+// four hundred instructions here and the prepare kernel makes four per edge (5 us of it): where
+// the quotient's estimate in floating point is off by one at most (|a| < 2^62, quotient below
+// 2^51) it is settled in integers.
+__device__ inline void trunc_divmod (int64_t a, int64_t d, int64_t &q, int64_t &r)
+{
+  if (a > -(1ll << 62) && a < (1ll << 62) && d < (1ll << 51)) {
+    const double est = trunc ((double) a / (double) d);
+    if (est > -4.5e15 && est < 4.5e15) {
+      q = (int64_t) est;
+      r = a - q * d;
+      // floor / ceiling towards the right side of zero
+      if (a >= 0) {
+        if (r < 0) { q--; r += d; } else if (r >= d) { q++; r -= d; }
+      } else {
+        if (r > 0) { q++; r -= d; } else if (r <= -d) { q--; r += d; }
+      }
+      return;
+    }
+  }
+  q = a / d;
+  r = a % d;
+}
+
 // ---- edges: cairo_edge_t -> ScanEdge (glitter_scan_converter_add_edge) ----------------
 // (raw_copy: where `edges` is page-locked HOST memory read over PCIe -- the element's
 // outlines, flutl_atlas_put_polygon -- a copy in device memory for the sequential sweep)
-__global__ void scan_prepare_kernel (const int32_t *__restrict__ edges, uint32_t n,
-    int ymin, int ymax, ScanEdge *__restrict__ out, int2 *__restrict__ spans,
-    uint32_t *__restrict__ status, int32_t *__restrict__ raw_copy)
+// By a kernel of its own, or (FLUTL_SCAN_FUSED) by the row kernel's first workgroups before the
+// rows begin: one launch less for the thread that feeds the device.
+__device__ __forceinline__ void
+prepare_edge (uint32_t i, const int32_t *__restrict__ edges, int ymin, int ymax,
+    ScanEdge *__restrict__ out, int2 *__restrict__ spans, int32_t *__restrict__ raw_copy)
 {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0)
-    status[0] = 0;              // (the rows run behind this kernel in stream order)
-  if (i >= n)
-    return;
   int32_t in[7];
 #pragma unroll
   for (int k = 0; k < 7; k++)
@@ -194,11 +216,12 @@ __global__ void scan_prepare_kernel (const int32_t *__restrict__ edges, uint32_t
     const int64_t dx = (int64_t) p2x - p1x;
     const int64_t Dy = ((int64_t) p2y - p1y) * kGridY * 512;
     const int64_t Ex = dx * 256;
-    e.dq = (int32_t) ((dx * 131072) / Dy);
-    e.dr = (dx * 131072) % Dy;
+    int64_t dq64, nq64, r;
+    trunc_divmod (dx * 131072, Dy, dq64, e.dr);
+    e.dq = (int32_t) dq64;
     const int64_t num = ((int64_t) (2 * ytop + 1) * 256 - 2 * (int64_t) kGridY * p1y) * Ex;
-    int32_t q = (int32_t) (num / Dy) + p1x;
-    int64_t r = num % Dy;
+    trunc_divmod (num, Dy, nq64, r);
+    int32_t q = (int32_t) nq64 + p1x;
     normalise (q, r, Dy);
     e.xq0 = q;
     e.xr0 = r;
@@ -208,208 +231,14 @@ __global__ void scan_prepare_kernel (const int32_t *__restrict__ edges, uint32_t
   spans[i] = make_int2 (ytop, ybot);    // (what the rows look through for their edges)
 }
 
-// ---- edges -> ScanEdge, and every pixel row's own list of edge records ------------------------
-// (round 4) A pixel row used to look through ALL spans for its edges (8 B x edges x rows of L2
-// reads, 4.5 us at the head of every row) and then gather each edge's state and step it to its
-// 15 cells (a dependent 48-byte gather + a 64-bit division, 7.4 us).  Now the prepare kernel
-// deals every (edge, pixel row) pair its RECORD: the edge's cell on each of the row's 15 sample
-// rows, clamped and counted from the box's left catch-all column as the rows want them
-// (0xffffffff: the edge is not on that sample row, or beyond the box's right side), and the
-// edge's index and direction -- 64 bytes, written once, read once, side by side in the row's
-// own block of `cap` records.  A row knows how many it has from row_info[row] (bit 31: an edge
-// starts or ends inside the row, so it is converted by sample rows whatever its order).
-// row_info is zero between conversions: every row clears its word when it is done.
-//
-// One workgroup = 64 consecutive edges of the polygon (they are neighbours on the page: a
-// handful of pixel rows); its 256 threads share the edges' (edge, row) pairs out evenly
-// (load-balanced search over the prefix sums of the edges' row counts: a stem of 80 rows does
-// not keep one lane busy 80 times over).  Places in a row's block: counted per workgroup in
-// LDS first, ONE global atomic per (workgroup, row).
-constexpr int kBucketEdges = 64;
-constexpr int kBucketThreads = 256;
-constexpr int kBucketRows = 512;        // pixel rows one workgroup's edges may span for the LDS count
-constexpr uint32_t kRowInside = 0x80000000u;
-constexpr uint32_t kRecordWords = 16;
-
-__device__ inline int wave_inclusive_scan (int v, int lane);
-
-__global__ void __launch_bounds__ (kBucketThreads)
-scan_bucket_kernel (const int32_t *__restrict__ edges, uint32_t n, int xmin, int ymin, int xmax,
-    int ymax, ScanEdge *__restrict__ out, int2 *__restrict__ spans, uint32_t *__restrict__ status,
-    int32_t *__restrict__ raw_copy, uint32_t *__restrict__ row_info, uint4 *__restrict__ rec, uint32_t cap)
+// (the same as a kernel of its own: the default; FLUTL_SCAN_FUSED=1 is the other arm of the
+// A/B of DESIGN 5.7)
+__global__ void scan_prepare_kernel (const int32_t *__restrict__ edges, uint32_t n, int ymin, int ymax,
+    ScanEdge *__restrict__ out, int2 *__restrict__ spans, int32_t *__restrict__ raw_copy)
 {
-  __shared__ ScanEdge s_e[kBucketEdges];
-  __shared__ int s_off[kBucketEdges + 1];
-  __shared__ int s_r0[kBucketEdges];
-  __shared__ int s_cnt[kBucketRows], s_base[kBucketRows], s_in[kBucketRows];
-  __shared__ int s_rmin, s_rmax;
-  const int tid = threadIdx.x;
-  const uint32_t i = blockIdx.x * kBucketEdges + tid;
-  if (blockIdx.x == 0 && tid == 0)
-    status[0] = 0;              // (the rows run behind this kernel in stream order)
-  for (int k = tid; k < kBucketRows; k += kBucketThreads) {
-    s_cnt[k] = 0;
-    s_in[k] = 0;
-  }
-  if (tid == 0) {
-    s_rmin = INT_MAX;
-    s_rmax = INT_MIN;
-    s_off[0] = 0;
-  }
-  __syncthreads ();
-  if (tid < kBucketEdges) {
-    int rows = 0, r0 = 0;
-    if (i < n) {
-      int32_t in[7];
-#pragma unroll
-      for (int k = 0; k < 7; k++)
-        in[k] = edges[(size_t) i * 7 + k];
-      if (raw_copy) {
-#pragma unroll
-        for (int k = 0; k < 7; k++)
-          raw_copy[(size_t) i * 7 + k] = in[k];
-      }
-      ScanEdge e;
-      int ytop = (int) (((int64_t) in[4] * kGridY + 128) >> 8);
-      int ybot = (int) (((int64_t) in[5] * kGridY + 128) >> 8);
-      if (ytop < ymin * kGridY)
-        ytop = ymin * kGridY;
-      if (ybot > ymax * kGridY)
-        ybot = ymax * kGridY;
-      e.pad = 0;
-      if (ybot <= ytop) {
-        e.ytop = INT_MAX;
-        e.ybot = INT_MIN;
-        e.dir = 0;
-        e.xq0 = 0;
-        e.xr0 = e.dr = e.D = 0;
-        e.dq = 0;
-        out[i] = e;
-        spans[i] = make_int2 (INT_MAX, INT_MIN);
-      } else {
-        int32_t p1x = in[0], p1y = in[1], p2x = in[2], p2y = in[3];
-        e.dir = in[6];
-        if (!(p2y > p1y)) {
-          int32_t t = p1x; p1x = p2x; p2x = t;
-          t = p1y; p1y = p2y; p2y = t;
-          e.dir = -e.dir;
-        }
-        e.ytop = ytop;
-        e.ybot = ybot;
-        if (p2x == p1x) {
-          e.xq0 = p1x;
-          e.xr0 = 0;
-          e.dq = 0;
-          e.dr = 0;
-          e.D = 0;
-        } else {
-          const int64_t dx = (int64_t) p2x - p1x;
-          const int64_t Dy = ((int64_t) p2y - p1y) * kGridY * 512;
-          const int64_t Ex = dx * 256;
-          e.dq = (int32_t) ((dx * 131072) / Dy);
-          e.dr = (dx * 131072) % Dy;
-          const int64_t num = ((int64_t) (2 * ytop + 1) * 256 - 2 * (int64_t) kGridY * p1y) * Ex;
-          int32_t q = (int32_t) (num / Dy) + p1x;
-          int64_t r = num % Dy;
-          normalise (q, r, Dy);
-          e.xq0 = q;
-          e.xr0 = r;
-          e.D = Dy;
-        }
-        out[i] = e;
-        spans[i] = make_int2 (ytop, ybot);
-        s_e[tid] = e;
-        r0 = ytop / kGridY - ymin;              // (ytop >= ymin * 15 >= 0)
-        rows = (ybot - 1) / kGridY - ymin - r0 + 1;
-        atomicMin (&s_rmin, r0);
-        atomicMax (&s_rmax, r0 + rows - 1);
-      }
-    }
-    s_r0[tid] = r0;
-    s_off[tid + 1] = wave_inclusive_scan (rows, tid);
-  }
-  __syncthreads ();
-  const int total = s_off[kBucketEdges];
-  if (total == 0)
-    return;
-  const int rmin = s_rmin, nrows = s_rmax - rmin + 1;
-  const bool agg = nrows <= kBucketRows;
-  const int width = xmax - xmin;
-  const int lo_cell = (xmin - 1) * 256, hi_cell = (xmax + 1) * 256 - 1;
-  for (int p0 = 0; p0 < total; p0 += kBucketThreads) {
-    const int p = p0 + tid;
-    const bool valid = p < total;
-    uint32_t w[kRecordWords];
-    int row = 0, local = 0;
-    uint32_t slot = 0;
-    if (valid) {
-      // the edge this pair belongs to: the last j with s_off[j] <= p
-      int j = 0;
-#pragma unroll
-      for (int step = kBucketEdges / 2; step > 0; step >>= 1)
-        if (s_off[j + step] <= p)
-          j += step;
-      row = s_r0[j] + (p - s_off[j]);
-      const ScanEdge e = s_e[j];
-      const int s0 = (ymin + row) * kGridY, s1 = s0 + kGridY;
-      const int esa = e.ytop > s0 ? e.ytop : s0, esb = e.ybot < s1 ? e.ybot : s1;
-      int32_t q;
-      int64_t r;
-      edge_x_at (e, esa, q, r);
-#pragma unroll
-      for (int k = 0; k < kGridY; k++) {
-        const int sr = s0 + k;
-        w[k] = 0xffffffffu;
-        if (sr >= esa && sr < esb) {
-          int cell = cell_of (q, r, e.D);
-          cell = cell < lo_cell ? lo_cell : (cell > hi_cell ? hi_cell : cell);
-          cell -= lo_cell;
-          if ((cell >> 8) <= width)
-            w[k] = (uint32_t) cell;
-          if (e.D) {
-            q += e.dq;
-            r += e.dr;
-            normalise (q, r, e.D);
-          }
-        }
-      }
-      const uint32_t idx = blockIdx.x * kBucketEdges + (uint32_t) j;
-      w[15] = idx | (e.dir > 0 ? 0x40000000u : 0xc0000000u);
-      const bool inside = esa > s0 || esb < s1;
-      if (agg) {
-        local = atomicAdd (&s_cnt[row - rmin], 1);
-        if (inside)
-          s_in[row - rmin] = 1;
-      } else {
-        slot = atomicAdd (&row_info[row], 1u) & ~kRowInside;
-        if (inside)
-          atomicOr (&row_info[row], kRowInside);
-      }
-    }
-    if (agg) {
-      __syncthreads ();
-      for (int k = tid; k < nrows; k += kBucketThreads) {
-        const int c = s_cnt[k];
-        if (c) {
-          s_base[k] = (int) (atomicAdd (&row_info[rmin + k], (uint32_t) c) & ~kRowInside);
-          if (s_in[k])
-            atomicOr (&row_info[rmin + k], kRowInside);
-          s_cnt[k] = 0;
-          s_in[k] = 0;
-        }
-      }
-      __syncthreads ();
-      if (valid)
-        slot = (uint32_t) (s_base[row - rmin] + local);
-    }
-    if (valid && slot < cap) {
-      uint4 *dst = rec + ((size_t) row * cap + slot) * (kRecordWords / 4);
-      dst[0] = make_uint4 (w[0], w[1], w[2], w[3]);
-      dst[1] = make_uint4 (w[4], w[5], w[6], w[7]);
-      dst[2] = make_uint4 (w[8], w[9], w[10], w[11]);
-      dst[3] = make_uint4 (w[12], w[13], w[14], w[15]);
-    }
-  }
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    prepare_edge (i, edges, ymin, ymax, out, spans, raw_copy);
 }
 
 // ---- workgroup helpers ------------------------------------------------------------------
@@ -1258,6 +1087,30 @@ __device__ inline int wave_inclusive_scan (int v, int lane)
   return v;
 }
 
+// minimum / maximum over the wave's 64 lanes on the same path: the result is lane 63's
+// (a lane without a source takes the identity)
+__device__ inline int wave_min_to_last (int v)
+{
+  v = min (v, __builtin_amdgcn_update_dpp (INT_MAX, v, 0x111, 0xf, 0xf, false));
+  v = min (v, __builtin_amdgcn_update_dpp (INT_MAX, v, 0x112, 0xf, 0xf, false));
+  v = min (v, __builtin_amdgcn_update_dpp (INT_MAX, v, 0x114, 0xf, 0xf, false));
+  v = min (v, __builtin_amdgcn_update_dpp (INT_MAX, v, 0x118, 0xf, 0xf, false));
+  v = min (v, __builtin_amdgcn_update_dpp (INT_MAX, v, 0x142, 0xa, 0xf, false));
+  v = min (v, __builtin_amdgcn_update_dpp (INT_MAX, v, 0x143, 0xc, 0xf, false));
+  return v;
+}
+
+__device__ inline int wave_max_to_last (int v)
+{
+  v = max (v, __builtin_amdgcn_update_dpp (INT_MIN, v, 0x111, 0xf, 0xf, false));
+  v = max (v, __builtin_amdgcn_update_dpp (INT_MIN, v, 0x112, 0xf, 0xf, false));
+  v = max (v, __builtin_amdgcn_update_dpp (INT_MIN, v, 0x114, 0xf, 0xf, false));
+  v = max (v, __builtin_amdgcn_update_dpp (INT_MIN, v, 0x118, 0xf, 0xf, false));
+  v = max (v, __builtin_amdgcn_update_dpp (INT_MIN, v, 0x142, 0xa, 0xf, false));
+  v = max (v, __builtin_amdgcn_update_dpp (INT_MIN, v, 0x143, 0xc, 0xf, false));
+  return v;
+}
+
 // exclusive prefix sum of v over the workgroup's 1024 threads (part: 16 words of LDS, 16-byte
 // aligned).  `part` may be written again only behind a barrier of the caller's.
 __device__ inline int block_exclusive_scan_open (int v, int tid, int *part)
@@ -1320,7 +1173,7 @@ __device__ __forceinline__ void together_clear (RowShared &S, int tid)
 }
 
 __device__ __forceinline__ void
-sample_rows_together (RowShared &S, const uint4 *__restrict__ row_rec, int n, int s0, int xmin,
+sample_rows_together (RowShared &S, const ScanEdge *__restrict__ edges, int n, int s0, int xmin,
     int xmax, unsigned mask, int tid, bool dirty, bool debug, uint32_t *dbg_ph, uint64_t &dbg_t)
 {
 #define DBG_PHASE_T(k) do { if (debug) { const uint64_t now_ = wall_clock64 (); dbg_ph[k] += (uint32_t) (now_ - dbg_t); dbg_t = now_; } } while (0)
@@ -1330,44 +1183,62 @@ sample_rows_together (RowShared &S, const uint4 *__restrict__ row_rec, int n, in
   int *rowbase = leftw + kGridY;                        // [15] the prefix sum at a sample row's start
   uint32_t *seg = reinterpret_cast<uint32_t *> (bins + kGridY * kBinsT + 32);   // [15 * kThreads] by
                                                         // bin: cell in the bin << 16 | direction (two bits, signed) << 14 | bin
-  (void) s0;
-  (void) xmin;
-  (void) xmax;
+  const int width = xmax - xmin, s1 = s0 + kGridY;
+  const int lo_cell = (xmin - 1) * 256, hi_cell = (xmax + 1) * 256 - 1;
   // (the bins were cleared when the row began -- under the latency of its first reads --
   // unless the attempt at an analytic row has had its sort keys there since)
   if (dirty) {
     together_clear (S, tid);
     __syncthreads ();
   }
-  // this thread's edge: its record, made by scan_bucket_kernel -- the cells of the row's 15
-  // sample rows (from lo_cell; -1: the edge is not there), one 64-byte read
+  // this thread's edge: x at its first sample row in this pixel row, then Cairo's steps to
+  // the cells of the row's 15 sample rows (from lo_cell; -1: the edge is not there)
   int cellk[kGridY];
   int dir = 0;
   {
-    uint4 r0 = make_uint4 (~0u, ~0u, ~0u, ~0u), r1 = r0, r2 = r0, r3 = r0;
+    int32_t eq = 0, edq = 0;
+    int64_t er = 0, edr = 0, eD = 0;
+    int esa = 0, esb = 0;
     if (tid < n) {
-      const uint4 *r = row_rec + (size_t) tid * (kRecordWords / 4);
-      r0 = r[0];
-      r1 = r[1];
-      r2 = r[2];
-      r3 = r[3];
-      dir = (int) r3.w >> 30;
-      r3.w = ~0u;
+      const ScanEdge e = edges[S.idx[tid]];
+      esa = e.ytop > s0 ? e.ytop : s0;
+      esb = e.ybot < s1 ? e.ybot : s1;
+      dir = e.dir;
+      edge_x_at (e, esa, eq, er);
+      edq = e.dq;
+      edr = e.dr;
+      eD = e.D;
     }
-    const uint32_t wv[16] = { r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w,
-                              r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w };
     int pmin = INT_MAX, pmax = INT_MIN;
 #pragma unroll
     for (int k = 0; k < kGridY; k++) {
-      cellk[k] = (int) wv[k];
-      if (cellk[k] >= 256) {
-        const int px = cellk[k] >> 8;
-        pmin = px < pmin ? px : pmin;
-        pmax = px > pmax ? px : pmax;
+      const int s = s0 + k;
+      cellk[k] = -1;
+      if (s >= esa && s < esb) {
+        int cell = cell_of (eq, er, eD);
+        cell = cell < lo_cell ? lo_cell : (cell > hi_cell ? hi_cell : cell);
+        cell -= lo_cell;
+        const int px = cell >> 8;
+        if (px <= width) {
+          cellk[k] = cell;
+          if (px >= 1) {
+            pmin = px < pmin ? px : pmin;
+            pmax = px > pmax ? px : pmax;
+          }
+        }
+        if (eD) {
+          eq += edq;
+          er += edr;
+          normalise (eq, er, eD);
+        }
       }
     }
-    if (pmin <= pmax) {
-      atomicMin (&S.sc[8], pmin);       // the pixels the row's edges stay within
+    // the pixels the row's edges stay within (one atomic per wave: a thousand lanes on one
+    // LDS word take their turns -- 4 us of a row, found in round 4)
+    pmin = wave_min_to_last (pmin);
+    pmax = wave_max_to_last (pmax);
+    if ((tid & 63) == 63 && pmin <= pmax) {
+      atomicMin (&S.sc[8], pmin);
       atomicMax (&S.sc[9], pmax);
     }
   }
@@ -1528,8 +1399,7 @@ __device__ __forceinline__ void
 scan_row (const ScanEdge *__restrict__ edges, const int2 *__restrict__ spans,
     uint32_t n_edges, int xmin, int ymin, int xmax, int ymax, int even_odd,
     uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ status, int lds_bytes,
-    uint32_t *__restrict__ debug, uint32_t *__restrict__ row_info, const uint4 *__restrict__ rec,
-    uint32_t cap)
+    uint32_t *__restrict__ debug)
 {
   // (static: a workgroup may have more than 64 KB of a CU's 160 only as a static array)
   __shared__ __align__ (16) uint8_t lds[kRowLdsBytes];
@@ -1543,23 +1413,6 @@ scan_row (const ScanEdge *__restrict__ edges, const int2 *__restrict__ spans,
   const int width = xmax - xmin;
   const int s0 = (ymin + row) * kGridY, s1 = s0 + kGridY;
   const unsigned mask = even_odd ? 1u : ~0u;
-  // the row's edges: counted and laid out by scan_bucket_kernel.  (The word is cleared for
-  // the next conversion here, by the one workgroup that reads it.)
-  const uint32_t info = row_info[row];
-  const int n = (int) (info & ~kRowInside);
-  const bool inside = (info & kRowInside) != 0;
-  const uint4 *row_rec = rec + (size_t) row * cap * (kRecordWords / 4);
-  uint8_t *out = dst + (size_t) row * dst_stride;
-  __syncthreads ();             // (every wave has read the word)
-  if (info && tid == 0)
-    row_info[row] = 0;
-  if (n == 0 || (uint32_t) n > cap || n > kMaxActive) {
-    if (n != 0 && tid == 0)
-      atomicOr (status, kStatusOverflow);
-    for (int i = tid; i < width; i += kThreads)
-      out[i] = 0;
-    return;
-  }
   RowShared S;
   {
     uint8_t *p = lds;
@@ -1579,23 +1432,89 @@ scan_row (const ScanEdge *__restrict__ edges, const int2 *__restrict__ spans,
     S.dir = reinterpret_cast<int8_t *> (p);
   }
 
+  // the edges that cross this row; and whether one of them starts or ends inside it (the
+  // row is then converted by sample rows whatever the order of its edges)
+  bool inside = false;
+  // (two spans to a read, six reads in flight: 12 288 edges per round of the workgroup; the
+  // first round's reads are asked for before the accumulators and bins are cleared)
+  int4 tb[6];
+  auto read_spans = [&] (uint32_t base) {
+#pragma unroll
+    for (int u = 0; u < 6; u++) {
+      const uint32_t i = base + (u * kThreads + tid) * 2;
+      tb[u] = i < n_edges ? *reinterpret_cast<const int4 *> (spans + i)
+                          : make_int4 (INT_MAX, INT_MIN, INT_MAX, INT_MIN);
+      if (i + 1 >= n_edges) {       // (beyond the last edge: the scratch buffer's padding)
+        tb[u].z = INT_MAX;
+        tb[u].w = INT_MIN;
+      }
+    }
+  };
+  read_spans (0);
   for (int i = tid; i < width + 2; i += kThreads) {
     if (i < (width + 3) / 2)
       S.cov[i] = 0;
     S.unc[i] = 0;
   }
   if (tid == 0) {
-    S.sc[0] = n;
+    S.sc[0] = 0;
     S.sc[1] = 0;
-    S.sc[13] = inside;
+    S.sc[13] = 0;
   }
   together_clear (S, tid);
-  // slot -> edge index: what the analytic attempt, the tie rules and the rows of more than
-  // kThreads edges go by (the usual row -- sample rows together -- reads its records only)
-  if (!inside || n > kThreads)
-    for (int i = tid; i < n; i += kThreads)
-      S.idx[i] = reinterpret_cast<const uint32_t *> (row_rec)[(size_t) i * kRecordWords + 15] & 0x3fffffffu;
   __syncthreads ();
+  for (uint32_t base = 0; base < n_edges; base += kThreads * 12) {
+    if (base)
+      read_spans (base);
+    // (ONE atomic per wave and round: its first lane takes places for all the wave's hits of
+    // the twelve spans each lane looked at -- twelve atomics, each waiting for its answer,
+    // were a microsecond of every row)
+    uint64_t hits[12];
+    int total = 0;
+#pragma unroll
+    for (int u = 0; u < 12; u++) {
+      const int top = (u & 1) ? tb[u >> 1].z : tb[u >> 1].x;
+      const int bot = (u & 1) ? tb[u >> 1].w : tb[u >> 1].y;
+      const bool hit = top < s1 && bot > s0;
+      hits[u] = __ballot (hit);
+      total += __popcll (hits[u]);
+      if (hit)
+        inside |= top > s0 || bot < s1;
+    }
+    if (total) {
+      int k0 = 0;
+      if ((tid & 63) == 0)
+        k0 = atomicAdd (&S.sc[0], total);
+      k0 = __builtin_amdgcn_readfirstlane (k0);
+      const uint64_t below = (1ull << (tid & 63)) - 1ull;
+#pragma unroll
+      for (int u = 0; u < 12; u++) {
+        if ((hits[u] >> (tid & 63)) & 1ull) {
+          const int k = k0 + __popcll (hits[u] & below);
+          if (k < kMaxActive)
+            S.idx[k] = base + ((u >> 1) * kThreads + tid) * 2 + (u & 1);
+        }
+        k0 += __popcll (hits[u]);
+      }
+    }
+  }
+  if (inside)
+    S.sc[13] = 1;
+  __syncthreads ();
+  const int n = S.sc[0];
+  uint8_t *out = dst + (size_t) row * dst_stride;
+  if (n > kMaxActive) {
+    if (tid == 0)
+      atomicOr (status, kStatusOverflow);
+    for (int i = tid; i < width; i += kThreads)
+      out[i] = 0;
+    return;
+  }
+  if (n == 0) {
+    for (int i = tid; i < width; i += kThreads)
+      out[i] = 0;
+    return;
+  }
   int npad = 2;
   while (npad < n)
     npad <<= 1;
@@ -1702,7 +1621,7 @@ scan_row (const ScanEdge *__restrict__ edges, const int2 *__restrict__ spans,
   } else if (n <= kThreads) {
     if (debug)
       dbg_t = wall_clock64 ();
-    sample_rows_together (S, row_rec, n, s0, xmin, xmax, mask, tid, (dbg_mode & 1) != 0, debug != nullptr,
+    sample_rows_together (S, edges, n, s0, xmin, xmax, mask, tid, (dbg_mode & 1) != 0, debug != nullptr,
         dbg_ph, dbg_t);
   } else {
     // More than kThreads edges in the row: one sample row after the other (the same idea
@@ -1936,14 +1855,66 @@ scan_row (const ScanEdge *__restrict__ edges, const int2 *__restrict__ spans,
 }
 
 __global__ void __launch_bounds__ (kThreads)
-scan_rows_kernel (const ScanEdge *__restrict__ edges, const int2 *__restrict__ spans,
+scan_rows_kernel (ScanEdge *edges, int2 *spans,
     uint32_t n_edges, int xmin, int ymin, int xmax, int ymax, int even_odd,
     uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ status, int lds_bytes,
     uint32_t *__restrict__ debug, int pad_zero, int with_sequential, SeqArgs seq,
-    uint32_t *__restrict__ row_info, const uint4 *__restrict__ rec, uint32_t cap)
+    const int32_t *__restrict__ raw_edges, int32_t *__restrict__ raw_copy)
 {
-  scan_row (edges, spans, n_edges, xmin, ymin, xmax, ymax, even_odd, dst, dst_stride, status,
-      lds_bytes, debug, row_info, rec, cap);
+  // The edges are prepared here, by the first workgroups: workgroup b takes the slices of
+  // kThreads edges b, b + grid, ...; every workgroup then waits until all slices are done.
+  // Workgroups are handed out in the order of their numbers, so the ones that are waited
+  // for run before (or beside) the ones that wait; should that ever not hold, the wait
+  // gives up after a bounded number of polls and the polygon goes to the sequential sweep
+  // (which reads the raw edges).  status[5]: slices done; reset by the last workgroup.
+  {
+    const int tid = threadIdx.x;
+    __shared__ int s_ready;
+    if (raw_edges) {
+      const uint32_t n_slices = (n_edges + kThreads - 1) / kThreads;
+      bool did = false;
+      for (uint32_t t = blockIdx.x; t < n_slices; t += gridDim.x) {
+        const uint32_t i = t * kThreads + tid;
+        if (i < n_edges)
+          prepare_edge (i, raw_edges, ymin, ymax, edges, spans, raw_copy);
+        did = true;
+      }
+      if (did) {
+        __syncthreads ();         // (every wave's stores are out)
+        if (tid == 0) {
+          __builtin_amdgcn_fence (__ATOMIC_RELEASE, "agent");     // (... and written back from this XCD's L2)
+          const uint32_t mine = (n_slices - blockIdx.x + gridDim.x - 1) / gridDim.x;
+          atomicAdd (&status[5], mine);
+        }
+      }
+      if (tid == 0) {
+        int ok = 1;
+        uint32_t polls = 0;
+        while (__hip_atomic_load (&status[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_slices) {
+          __builtin_amdgcn_s_sleep (2);
+          if (++polls > (1u << 22)) {     // (seconds: never seen; see above)
+            ok = 0;
+            break;
+          }
+        }
+        __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "agent");     // (this CU's L1 holds nothing stale of the edges)
+        s_ready = ok;
+      }
+    } else if (tid == 0) {
+      s_ready = 1;              // (a kernel of its own has prepared the edges)
+    }
+    __syncthreads ();
+    if (!s_ready) {
+      if (tid == 0)
+        atomicOr (status, kStatusOverflow);
+      uint8_t *out = dst + (size_t) blockIdx.x * dst_stride;
+      for (int i = tid; i < xmax - xmin; i += kThreads)
+        out[i] = 0;
+    } else {
+      scan_row (edges, spans, n_edges, xmin, ymin, xmax, ymax, even_odd, dst, dst_stride, status,
+          lds_bytes, debug);
+    }
+  }
   const int tid = threadIdx.x, width = xmax - xmin;
   if (pad_zero && tid < 4) {
     // the MASK layout's zero bytes: 4 after every row, 4 in front of the first
@@ -1951,10 +1922,9 @@ scan_rows_kernel (const ScanEdge *__restrict__ edges, const int2 *__restrict__ s
     if (blockIdx.x == 0 && pad_zero == 1)
       *(dst - 4 + tid) = 0;
   }
-  if (!with_sequential)
-    return;
-  // The workgroup that finishes last looks whether any row raised a flag, and if so
-  // converts the polygon again by the sequential sweep (one lane; exact by construction).
+  // The workgroup that finishes last puts the counters back to zero for the next conversion,
+  // looks whether any row raised a flag, and if so converts the polygon again by the
+  // sequential sweep (one lane; exact by construction).
   __shared__ int s_last;
   __syncthreads ();
   if (tid == 0) {
@@ -1967,7 +1937,8 @@ scan_rows_kernel (const ScanEdge *__restrict__ edges, const int2 *__restrict__ s
   if (tid == 0) {
     __threadfence ();
     status[2] = 0;
-    if (atomicOr (&status[0], 0u) & (kStatusTie | kStatusOverflow)) {
+    status[5] = 0;
+    if (with_sequential && (atomicOr (&status[0], 0u) & (kStatusTie | kStatusOverflow))) {
       sequential_sweep (seq.in_edges, n_edges, xmin, ymin, xmax, ymax, even_odd, dst, dst_stride,
           seq.sedges, seq.y_buckets, seq.cells);
       status[0] = 0;
@@ -1989,31 +1960,20 @@ extern "C" void flutl_scan_set_debug (void *dev)
   g_scan_debug = static_cast<uint32_t *> (dev);
 }
 
-// The scratch buffer: [0, 256) status words, [256, 256 + 4 * 65536) the rows' counts
-// (row_info, both zero between conversions: a fixed place whatever the polygon), then the
-// prepared edges, their spans, the sequential sweep's state and the rows' records.
-constexpr size_t kScanRowInfoBytes = (size_t) 65536 * sizeof (uint32_t);
-constexpr size_t kScanZeroBytes = 256 + kScanRowInfoBytes;
-
-static inline uint32_t scan_row_cap (uint32_t n_edges)
-{
-  return n_edges < (uint32_t) kMaxActive ? (n_edges ? n_edges : 1u) : (uint32_t) kMaxActive;
-}
-
+// (FLUTL_SCAN_CLEAN: the status words at the scratch's start, zero between conversions)
 extern "C" size_t flutl_scan_zero_bytes (void)
 {
-  return kScanZeroBytes;
+  return 256;
 }
 
 extern "C" size_t flutl_scan_scratch_bytes (uint32_t n_edges, uint32_t width, uint32_t height)
 {
-  size_t b = kScanZeroBytes;                          // status, row_info
+  size_t b = 256;                                     // status
   b += ((size_t) n_edges * sizeof (ScanEdge) + 255) & ~(size_t) 255;
   b += ((size_t) n_edges * sizeof (int2) + 255) & ~(size_t) 255;
   b += ((size_t) (n_edges + 2) * sizeof (SeqEdge) + 255) & ~(size_t) 255;
   b += ((size_t) height * sizeof (SeqEdge *) + 255) & ~(size_t) 255;
   b += ((size_t) 2 * (width + 2) * sizeof (int) + 255) & ~(size_t) 255;
-  b += (size_t) height * scan_row_cap (n_edges) * kRecordWords * sizeof (uint32_t);   // records
   return b;
 }
 
@@ -2051,7 +2011,7 @@ extern "C" int flutl_launch_scan_hosted (void *stream_, const int32_t *edges_dev
   const int xmin = box[0], ymin = box[1], xmax = box[2], ymax = box[3];
   if (!dst || xmax <= xmin || ymax <= ymin || xmin < 0 || xmax > (1 << 22) || ymin < 0 ||
       ymax > (1 << 22) || (n_edges && (!edges_dev || !scratch)) ||
-      dst_stride < (size_t) (xmax - xmin) || mode < 0 || (mode & 7) > 2 || mode > 63)
+      dst_stride < (size_t) (xmax - xmin) || mode < 0 || (mode & 7) > 2 || mode > 127)
     return FLUTL_EINVAL;
   const uint32_t width = (uint32_t) (xmax - xmin), height = (uint32_t) (ymax - ymin);
   if (width > (uint32_t) kMaxWidth || height > 65535u || n_edges > (1u << 24))
@@ -2064,8 +2024,6 @@ extern "C" int flutl_launch_scan_hosted (void *stream_, const int32_t *edges_dev
   uint8_t *p = static_cast<uint8_t *> (scratch);
   uint32_t *status = reinterpret_cast<uint32_t *> (p);  // 0 flags, 2 rows done (last one resets)
   p += 256;
-  uint32_t *row_info = reinterpret_cast<uint32_t *> (p);
-  p += kScanRowInfoBytes;
   ScanEdge *prepared = reinterpret_cast<ScanEdge *> (p);
   p += ((size_t) n_edges * sizeof (ScanEdge) + 255) & ~(size_t) 255;
   int2 *spans = reinterpret_cast<int2 *> (p);
@@ -2077,26 +2035,27 @@ extern "C" int flutl_launch_scan_hosted (void *stream_, const int32_t *edges_dev
   seq.y_buckets = reinterpret_cast<SeqEdge **> (p);
   p += ((size_t) height * sizeof (SeqEdge *) + 255) & ~(size_t) 255;
   seq.cells = reinterpret_cast<int *> (p);
-  p += ((size_t) 2 * (width + 2) * sizeof (int) + 255) & ~(size_t) 255;
-  uint4 *rec = reinterpret_cast<uint4 *> (p);
-  const uint32_t cap = scan_row_cap (n_edges);
   seq.counters = counters_dev;
   // (library internal, flutl_atlas_put_polygon: 8 = the MASK layout's zero bytes are the
-  // rows' to write, 16 = the scratch's status words and row counts are zero -- made so once,
-  // and left so by every conversion)
+  // rows' to write, 16 = the scratch's first 16 bytes are zero -- made so once, and left so
+  // by every conversion)
   // (... 32 = only the zero bytes after every row: the last of the column windows a wide
   // entry is converted in)
   const int pad_zero = mode & 8 ? 1 : (mode & 32 ? 2 : 0), clean = mode & 16 ? 1 : 0;
+  // (64, or FLUTL_SCAN_FUSED=1 in the environment: the edges prepared by the row kernel's
+  // first workgroups instead of by a kernel of their own -- one launch less for the thread that
+  // feeds the device, 3 us more on the device: the A/B of DESIGN 5.7)
+  static const bool env_fused = getenv ("FLUTL_SCAN_FUSED") != nullptr;
+  const bool separate = !((mode & 64) != 0 || env_fused);
   mode &= 7;
   (void) hipGetLastError ();    // (a stale error of an earlier, unrelated call is not this launch's)
   if (mode != 2) {
-    // (the "rows done" counter and the rows' counts must start at zero: a scratch buffer
-    // of unknown content)
-    if (!clean && hipMemsetAsync (status, 0, 256 + (size_t) height * sizeof (uint32_t), stream) != hipSuccess)
+    // (the "rows done" counter must start at zero: a scratch buffer of unknown content)
+    if (!clean && hipMemsetAsync (status, 0, 32, stream) != hipSuccess)
       return FLUTL_ENODEV;
-    scan_bucket_kernel<<<(n_edges + kBucketEdges - 1) / kBucketEdges, kBucketThreads, 0, stream>>> (
-        edges_dev, n_edges, xmin, ymin, xmax, ymax, prepared, spans, status, raw_copy_dev, row_info,
-        rec, cap);
+    if (separate)
+      scan_prepare_kernel<<<(n_edges + 255) / 256, 256, 0, stream>>> (edges_dev, n_edges, ymin, ymax,
+          prepared, spans, raw_copy_dev);
     // LDS: the accumulators by the box width; a region that holds the sort keys of an
     // eligible row's order and then the bins of the sample rows
     const size_t fixed = row_shared_fixed_bytes ((int) width);
@@ -2105,7 +2064,7 @@ extern "C" int flutl_launch_scan_hosted (void *stream_, const int32_t *edges_dev
       return FLUTL_ERANGE;
     scan_rows_kernel<<<height, kThreads, 0, stream>>> (prepared, spans, n_edges, xmin, ymin,
         xmax, ymax, even_odd, static_cast<uint8_t *> (dst), dst_stride, status, (int) lds,
-        g_scan_debug, pad_zero, mode == 0, seq, row_info, rec, cap);
+        g_scan_debug, pad_zero, mode == 0, seq, separate ? nullptr : edges_dev, raw_copy_dev);
   } else {
     scan_sequential_kernel<<<1, 64, 0, stream>>> (edges_dev, n_edges, xmin, ymin, xmax, ymax,
         even_odd, static_cast<uint8_t *> (dst), dst_stride, seq.sedges, seq.y_buckets, seq.cells);

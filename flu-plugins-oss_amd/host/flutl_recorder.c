@@ -131,6 +131,9 @@ struct FlutlRecorder
   uint32_t n_new, cap_new;
   FlutlPolygonEntry **new_poly;      /* per new entry: NULL, or the polygon the DEVICE makes it of */
   int device_strokes;                /* outlines leave the workers as polygons (see stroke_job_run) */
+  void *(*edge_acquire) (void *user, size_t bytes);    /* flutl_recorder_set_edge_blocks */
+  void (*edge_release) (void *user, void *block);
+  void *edge_user;
 
   GlyphEntry *glyphs;
   uint32_t glyph_cap, glyph_count;
@@ -2193,6 +2196,9 @@ typedef struct StrokeJob
                                   * the exact ones (rb becomes exact before the stroke) */
   gint64 t_pushed;
   int to_polygon;                /* the device makes the mask: the result is the polygon */
+  void *(*edge_acquire) (void *user, size_t bytes);    /* (the recorder's, when the job was made) */
+  void (*edge_release) (void *user, void *block);
+  void *edge_user;
   FlutlPolygonEntry *poly;       /* result (to_polygon): the stroke's polygon, or NULL */
   uint8_t *tight;                /* result: w x h coverage at (x, y), or NULL */
   uint8_t *padded;               /* ... in the atlas's layout, and its hash: made here so */
@@ -2305,6 +2311,20 @@ stroke_job_polygon (StrokeJob *j)
       abort ();
     pe->edges = pg.edges;
     pe->n_edges = pg.n_edges;
+    if (j->edge_acquire) {
+      /* straight into page-locked memory the device reads: nobody copies the edges on the
+       * thread that feeds the device (330 KB per cue of a 4K stream) */
+      const size_t bytes = (size_t) pg.n_edges * 7 * sizeof (int32_t);
+      void *blk = j->edge_acquire (j->edge_user, bytes);
+      if (blk) {
+        memcpy (blk, pg.edges, bytes);
+        free (pg.edges);
+        pe->edges = blk;
+        pe->in_block = 1;
+        pe->release = j->edge_release;
+        pe->release_user = j->edge_user;
+      }
+    }
     memcpy (pe->box, pg.box, sizeof pe->box);
     pe->w = pg.box[2] - pg.box[0];
     pe->h = pg.box[3] - pg.box[1];
@@ -2915,6 +2935,9 @@ stroke_defer_prepare (FlutlRecorder *rec, RasterBox *rb, int *exact)
   j->sw = rec->sw;
   j->sh = rec->sh;
   j->to_polygon = root_of (rec)->device_strokes;
+  j->edge_acquire = root_of (rec)->edge_acquire;
+  j->edge_release = root_of (rec)->edge_release;
+  j->edge_user = root_of (rec)->edge_user;
   return j;
 }
 
@@ -3614,8 +3637,21 @@ flutl_polygon_entry_free (FlutlPolygonEntry *pe)
 {
   if (!pe)
     return;
-  free (pe->edges);
+  if (!pe->in_block)
+    free (pe->edges);
+  else if (!pe->submitted && pe->release)
+    pe->release (pe->release_user, pe->edges);
   free (pe);
+}
+
+void
+flutl_recorder_set_edge_blocks (FlutlRecorder *rec, void *(*acquire) (void *user, size_t bytes),
+    void (*release) (void *user, void *block), void *user)
+{
+  rec = root_of (rec);
+  rec->edge_acquire = acquire;
+  rec->edge_release = release;
+  rec->edge_user = user;
 }
 
 void

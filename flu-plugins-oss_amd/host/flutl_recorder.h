@@ -126,8 +126,20 @@ typedef struct
   uint32_t n_edges;
   int32_t box[4];
   int w, h;
+  /* edges in a block of the device context's page-locked arena (see
+   * flutl_recorder_set_edge_blocks): not free()d; given back through `release` unless
+   * `submitted` (flutl_atlas_put_polygon has taken the block) */
+  int in_block, submitted;
+  void (*release) (void *user, void *block);
+  void *release_user;
 } FlutlPolygonEntry;
 void flutl_polygon_entry_free (FlutlPolygonEntry *pe);
+/* Where the stroke workers put a polygon's edges: acquire (user, bytes) returns a block the
+ * device can read in place (flutl_ctx_edge_block_acquire) or NULL (the edges then stay in
+ * ordinary memory and are copied when the entry is made).  NULL functions: never.  The
+ * functions must stay callable until every polygon entry made under them is freed. */
+void flutl_recorder_set_edge_blocks (FlutlRecorder *rec, void *(*acquire) (void *user, size_t bytes),
+    void (*release) (void *user, void *block), void *user);
 /* Outlines without a mask leave the worker threads as polygons for the device instead
  * of as coverage rasterised by Cairo (only where strokes are deferred, set_defer). */
 void flutl_recorder_set_device_strokes (FlutlRecorder *rec, int on);

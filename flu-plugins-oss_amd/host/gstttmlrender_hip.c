@@ -442,6 +442,7 @@ typedef struct
   GHashTable *blurred;       /* key (checksum) -> BlurredImage, per document */
   flutl_ctx *ctx;            /* NULL until first use; stays NULL without a GPU */
   gboolean ctx_failed;
+  gboolean edge_blocks_set;     /* the recorder's stroke workers write edges into the context's blocks */
   FlutlPackWriter *dump;     /* FLUTL_DUMP_PACK=<file>: scene-pack dump */
   gboolean dump_only;        /* FLUTL_DUMP_ONLY=1: record, do not render */
   gboolean dump_discard;     /* the pack goes to /dev/null: not written at all */
@@ -2590,6 +2591,20 @@ record_region (HipRegion *r, GstTTMLRender *render)
 }
 
 /* ---- device side -------------------------------------------------------------- */
+/* (flutl_recorder_set_edge_blocks: user = the context) */
+static void *
+edge_block_acquire (void *user, size_t bytes)
+{
+  void *blk = NULL;
+  return flutl_ctx_edge_block_acquire (user, bytes, &blk) == FLUTL_OK ? blk : NULL;
+}
+
+static void
+edge_block_release (void *user, void *block)
+{
+  flutl_ctx_edge_block_release (user, block);
+}
+
 static gboolean
 ensure_ctx (GstTTMLRender *render)
 {
@@ -2642,6 +2657,7 @@ flush_atlas (GstTTMLRender *render)
     if (poly[i]) {
       /* an outline as the polygon a worker's stroker made of it: the device scan
        * converts it straight into the entry (no coverage in host memory, no upload) */
+      poly[i]->submitted = 1;   /* (a block of the context's arena is its own again, whatever comes back) */
       rc = flutl_atlas_put_polygon (priv->ctx, poly[i]->edges, poly[i]->n_edges, poly[i]->box,
           0, &dev_off);
       priv->n_polygons++;
@@ -2921,6 +2937,11 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
   /* ... as polygons for the device to scan convert (not when the frame is dumped: a
    * scene pack holds the masks' bytes) */
   flutl_recorder_set_device_strokes (rec, !priv->dump && !priv->host_strokes);
+  /* ... whose edges the workers write straight into page-locked blocks of the context */
+  if (priv->ctx && !priv->edge_blocks_set && !g_getenv ("FLUTL_NO_EDGE_BLOCKS")) {
+    flutl_recorder_set_edge_blocks (rec, edge_block_acquire, edge_block_release, priv->ctx);
+    priv->edge_blocks_set = TRUE;
+  }
   flutl_recorder_begin_frame (rec, width, height);
   if (base->state.saved_region_attr_stacks) {
     gpointer ctx[2] = { render, &regions };
@@ -3330,10 +3351,8 @@ gst_ttmlrender_dispose (GObject *object)
     flutl_pack_writer_free (priv->dump);
     priv->dump = NULL;
   }
-  if (priv->ctx) {
-    flutl_ctx_destroy (priv->ctx);
-    priv->ctx = NULL;
-  }
+  /* (the recorders first: a polygon entry they still hold gives its block of page-locked
+   * memory back to the context) */
   if (priv->sub) {
     flutl_recorder_free (priv->sub);
     priv->sub = NULL;
@@ -3341,6 +3360,10 @@ gst_ttmlrender_dispose (GObject *object)
   if (priv->rec) {
     flutl_recorder_free (priv->rec);
     priv->rec = NULL;
+  }
+  if (priv->ctx) {
+    flutl_ctx_destroy (priv->ctx);
+    priv->ctx = NULL;
   }
   if (priv->pool) {
     frame_pool_unref (priv->pool);

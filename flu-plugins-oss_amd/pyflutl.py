@@ -59,7 +59,8 @@ EXPORTS = [
     "flutl_frame_create", "flutl_frame_destroy", "flutl_frame_host",
     "flutl_frame_device", "flutl_frame_submit", "flutl_frame_wait", "flutl_ctx_delta_bytes",
     "flutl_atlas_put_polygon", "flutl_polygon_entry_bytes", "flutl_ctx_scan_fallbacks",
-    "flutl_scan_scratch_bytes", "flutl_scan_zero_bytes", "flutl_launch_scan", "flutl_scan_status",
+    "flutl_scan_scratch_bytes", "flutl_scan_zero_bytes", "flutl_ctx_edge_block_acquire",
+    "flutl_ctx_edge_block_release", "flutl_launch_scan", "flutl_scan_status",
 ]
 
 
@@ -120,6 +121,9 @@ def lib():
         L.flutl_ctx_scan_fallbacks.restype = u32
         L.flutl_scan_scratch_bytes.argtypes = [u32, u32, u32]
         L.flutl_scan_scratch_bytes.restype = sz
+        L.flutl_ctx_edge_block_acquire.argtypes = [vp, sz, ctypes.POINTER(vp)]
+        L.flutl_ctx_edge_block_release.argtypes = [vp, vp]
+        L.flutl_ctx_edge_block_release.restype = None
         L.flutl_scan_zero_bytes.argtypes = []
         L.flutl_scan_zero_bytes.restype = sz
         L.flutl_launch_scan.argtypes = [vp, vp, u32, vp, ctypes.c_int, vp, vp, sz, ctypes.c_int]
@@ -347,13 +351,29 @@ class Context:
                                      ctypes.byref(off)), "flutl_atlas_put")
         return off.value
 
-    def atlas_put_polygon(self, edges, box, even_odd=False):
+    def atlas_put_polygon(self, edges, box, even_odd=False, via_block=False):
         """scan converts the polygon on the device into a new atlas entry (MASK layout:
         pixel (0,0) of the box at offset + 4, stride width + 4); returns the offset"""
         edges = np.ascontiguousarray(edges, np.int32).reshape(-1, 7)
         b = (ctypes.c_int32 * 4)(*[int(v) for v in box])
         off = ctypes.c_uint32()
-        _check(lib().flutl_atlas_put_polygon(self._h, _np_ptr(edges), len(edges), b,
+        src = _np_ptr(edges)
+        if via_block:
+            # as the element's stroke workers do: the edges written straight into one of the
+            # context's page-locked blocks, which the device reads
+            blk = ctypes.c_void_p()
+            rc = lib().flutl_ctx_edge_block_acquire(self._h, edges.nbytes, ctypes.byref(blk))
+            if rc == 0:
+                ctypes.memmove(blk, src, edges.nbytes)
+                src = blk
+            elif via_block == "must":
+                # (acquire never waits for the device; a caller that insists does)
+                self.sync()
+                _check(lib().flutl_ctx_edge_block_acquire(self._h, edges.nbytes, ctypes.byref(blk)),
+                       "flutl_ctx_edge_block_acquire")
+                ctypes.memmove(blk, src, edges.nbytes)
+                src = blk
+        _check(lib().flutl_atlas_put_polygon(self._h, src, len(edges), b,
                                              int(even_odd), ctypes.byref(off)),
                "flutl_atlas_put_polygon")
         return off.value

@@ -333,6 +333,15 @@ int  flutl_atlas_put_blurred (flutl_ctx *ctx, uint32_t w, uint32_t h,
  * where Cairo's result depends on the order its sort left equal keys in. */
 int  flutl_atlas_put_polygon (flutl_ctx *ctx, const int32_t *edges, uint32_t n_edges,
     const int32_t box[4], int even_odd, uint32_t *offset_out);
+/* Page-locked memory the device reads an outline's edges from (flutl_atlas_put_polygon
+ * copies edges that lie elsewhere into such a block; a caller that lets its stroke workers
+ * write them there directly saves that copy on the thread that feeds the device).
+ * acquire: thread safe, never waits for the device; FLUTL_ENOMEM when `bytes` exceed a block
+ * (1 MiB) or none is free right now -- the caller then keeps its edges in ordinary memory.
+ * A block passed to flutl_atlas_put_polygon (at its first byte) belongs to the context again
+ * whatever that call returns; release is for a block that never got there. */
+int  flutl_ctx_edge_block_acquire (flutl_ctx *ctx, size_t bytes, void **block_out);
+void flutl_ctx_edge_block_release (flutl_ctx *ctx, void *block);
 /* Reserve the space such an entry takes WITHOUT making it (the caller keeps offsets in
  * step with a host-side atlas): bytes = 4 + (w + 4) * h. */
 size_t flutl_polygon_entry_bytes (uint32_t w, uint32_t h);

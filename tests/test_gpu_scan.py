@@ -289,3 +289,83 @@ def test_entries_survive_the_growing_of_the_atlas(gpu):
     P2["a"] = F.ATLAS_SLACK + 4
     want = gpu_util.hip_render(W, H, R, P2, atlas)
     assert np.array_equal(got[0], want) and np.array_equal(got[1], want)
+
+
+def test_edges_written_into_the_contexts_blocks_and_blocks_coming_round(gpu):
+    """The element's stroke workers write a polygon's edges straight into one of the
+    context's page-locked blocks (flutl_ctx_edge_block_acquire) and the device reads them in
+    place.  Same entries as with edges copied by flutl_atlas_put_polygon; 100 polygons in a row
+    pass through the 32 blocks three times over (a block is free again behind the event of its
+    epoch); blocks held by a caller run out without anybody waiting, and come back on release."""
+    import ctypes
+    import gpu_util
+    polys = [p for p in _polygons() if p[1] == 2][:5]
+    W = max(p[2][2] for p in polys) + 8
+    H = max(p[2][3] for p in polys) + 8
+
+    def masks(ctx, via):
+        out = []
+        for rep in range(20):
+            for (i, kind, box, eo, edges, cov) in polys:
+                out.append((ctx.atlas_put_polygon(edges, box, eo, via_block=via), box, cov))
+        return out
+
+    def composite(ctx, entries):
+        frames = []
+        fr = ctx.frame(W, H)
+        try:
+            for off, box, cov in entries[::7]:
+                h, w = cov.shape
+                R = np.zeros(1, F.REGION_DTYPE)
+                R["x0"], R["y0"], R["x1"], R["y1"], R["first"], R["count"] = box[0], box[1], box[2], box[3], 0, 1
+                P = np.zeros(1, F.PRIM_DTYPE)
+                P["op"], P["rule"] = F.OP_MASK, F.RULE_LERP
+                P["cx0"], P["cy0"], P["cx1"], P["cy1"] = box[0], box[1], box[2], box[3]
+                P["color"] = 0xFF000000
+                P["a"], P["b"], P["c"], P["d"] = off + 4, w + 4, box[0], box[1]
+                fr.submit(R, P)
+                fr.wait()
+                frames.append(fr.host().copy())
+        finally:
+            fr.close()
+        return frames
+
+    with F.Context(0) as ctx:
+        a = composite(ctx, masks(ctx, "must"))
+    with F.Context(0) as ctx:
+        b = composite(ctx, masks(ctx, False))
+        # blocks a caller holds: 32, then none (nobody waits), then one again after a release
+        L = F.lib()
+        held = []
+        for _ in range(40):
+            blk = ctypes.c_void_p()
+            if L.flutl_ctx_edge_block_acquire(ctx._h, 4096, ctypes.byref(blk)) == 0:
+                held.append(blk)
+        assert len(held) == 32
+        assert L.flutl_ctx_edge_block_acquire(ctx._h, (1 << 20) + 1, ctypes.byref(ctypes.c_void_p())) != 0
+        L.flutl_ctx_edge_block_release(ctx._h, held.pop())
+        blk = ctypes.c_void_p()
+        assert L.flutl_ctx_edge_block_acquire(ctx._h, 4096, ctypes.byref(blk)) == 0
+        # (a polygon put while every block is out: copied by an upload instead, still right)
+        i, kind, box, eo, edges, cov = polys[0]
+        off = ctx.atlas_put_polygon(edges, box, eo)
+        c = composite(ctx, [(off, box, cov)])
+        for h_ in held + [blk]:
+            L.flutl_ctx_edge_block_release(ctx._h, h_)
+    assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert np.array_equal(c[0], a[0])
+
+
+def test_edges_prepared_inside_the_row_kernel(gpu):
+    """mode | 64 (FLUTL_SCAN_FUSED): the row kernel's first workgroups prepare the edges and
+    every workgroup waits for them -- the same coverage, for polygons of more slices than rows
+    and of more rows than slices."""
+    torch = gpu
+    done = 0
+    for i, kind, box, eo, edges, cov in _polygons():
+        if i % 9:
+            continue
+        got, _ = hip_scan(torch, edges, box, eo, mode=64)
+        assert np.array_equal(got, cov), (i, kind)
+        done += 1
+    assert done >= 30
