@@ -68,6 +68,8 @@ typedef struct
   unsigned long sglyph;
   double hscale;
   double x, y, w, h;
+  int npoly;                 /* ... or, if set, a closed polygon of npoly points (x, y, w, h: its box) */
+  double poly[24];
   cairo_matrix_t m;
 } PathOp;
 
@@ -1502,16 +1504,60 @@ hexbox_info (PangoFont *font)
   return hb;
 }
 
-/* Code points Pango 1.45 does NOT draw as a hex box when they come as unknown
- * glyphs: spaces (a centred dot), default ignorables (a short name), tab and
- * line breaks.  Not reproduced: the buffer fails instead (flutl_recorder_unsupported). */
+/* Code points Pango 1.45 does NOT draw as a hex box when they come as unknown glyphs
+ * (_pango_cairo_renderer_draw_unknown_glyph's other branches): line breaks and tabs (an
+ * arrow: a filled polygon), spaces (a centred dot: cairo_arc + fill), default ignorables (a
+ * short name in a box).  What reaches them through the reference on this stack -- settled by
+ * cairo-traces of the reference over 31 such code points in the three DejaVu families
+ * (oracle/hexbox_trace.md, "the other branches"): U+2028 LINE SEPARATOR in a font without
+ * it (DejaVu Serif, Sans Mono); HarfBuzz gives every unknown space the font's space glyph and
+ * hides default ignorables, Pango lays tabs out itself, so the dot and the name boxes only
+ * come under PANGO_ATTR_SHOW, which the reference never sets.  The arrows and the dot are
+ * restated below; a name box still fails the buffer (flutl_recorder_unsupported). */
 static int
-hexbox_is_special (gunichar ch)
+hexbox_is_named (gunichar ch)
 {
-  return ch == 0x2423 || g_unichar_type (ch) == G_UNICODE_SPACE_SEPARATOR || ch == '\t' ||
-      ch == '\n' || ch == 0x2028 || ch == 0x2029 || ch == 0x00ad || ch == 0x034f ||
-      ch == 0x061c || (ch >= 0x200b && ch <= 0x200f) || (ch >= 0x202a && ch <= 0x202e) ||
-      (ch >= 0x2060 && ch <= 0x2069) || ch == 0xfeff;
+  return ch == 0x00ad || ch == 0x034f || ch == 0x061c || (ch >= 0x200b && ch <= 0x200f) ||
+      (ch >= 0x202a && ch <= 0x202e) || (ch >= 0x2060 && ch <= 0x2069) || ch == 0xfeff;
+}
+
+/* The arrow like U+21B5 Pango draws for a line break no font has a glyph for ('\n', U+2028,
+ * U+2029): nine points, filled.  Pinned point for point by cairo-traces of the reference at
+ * nine font sizes in two families (oracle/hexbox_trace.md; scene k21). */
+static int
+line_break_arrow (const HexBox *hb, const PangoGlyphInfo *gi, double *pts)
+{
+  const double cx = (double) gi->geometry.x_offset / PANGO_SCALE;
+  const double cy = gi->geometry.y_offset == 0
+      ? 0.0 : (double) gi->geometry.y_offset / PANGO_SCALE;
+  const double gw = (double) gi->geometry.width / PANGO_SCALE;
+  const double offset = 0.2 * gw, al = gw - 2 * offset;         /* arrow length */
+  const double tl = MIN (hb->digit_width, 0.75 * al);            /* tip length */
+  const double ah = al - 0.5 * tl;                                /* arrow height */
+  const double tw2 = 2.5 * hb->line_width, lw2 = 0.5 * hb->line_width;
+  const double x = cx + offset;
+  const double y = cy - (hb->box_height - al) / 2;               /* centre of the tip */
+  int n = 0;
+#define PT(px, py) do { pts[2 * n] = (px); pts[2 * n + 1] = (py); n++; } while (0)
+  PT (x, y);
+  PT (x + tl, y - tw2);
+  PT (x + tl, y - lw2);
+  PT (x + al - lw2, y - lw2);
+  PT (x + al - lw2, y - ah);
+  PT (x + al + lw2, y - ah);
+  PT (x + al + lw2, y + lw2);
+  PT (x + tl, y + lw2);
+  PT (x + tl, y + tw2);
+#undef PT
+  return n;
+}
+
+static int
+glyph_is_line_break_arrow (const PangoGlyphInfo *gi)
+{
+  const gunichar ch = gi->glyph & ~PANGO_GLYPH_UNKNOWN_FLAG;
+  return (gi->glyph & PANGO_GLYPH_UNKNOWN_FLAG) && gi->glyph != PANGO_GLYPH_INVALID_INPUT &&
+      (ch == '\n' || ch == 0x2028 || ch == 0x2029);
 }
 
 static void
@@ -1525,13 +1571,31 @@ hexbox_show (FlutlRecorder *rec, PangoFont *font, const PangoGlyphInfo *gi)
   HexBox *hb;
   if (gi->glyph == (0x20 | PANGO_GLYPH_UNKNOWN_FLAG))
     return;                     /* "no hex boxes for space, please" */
-  if (gi->glyph == PANGO_GLYPH_INVALID_INPUT || ch > 0x10FFFF || hexbox_is_special (ch) ||
+  if (gi->glyph == PANGO_GLYPH_INVALID_INPUT || ch > 0x10FFFF || hexbox_is_named (ch) ||
       !(hb = hexbox_info (font))) {
     rec->unsupported++;
     return;
   }
   if (rec->color_clear)
     return;
+  if (ch == 0x2423 || g_unichar_type (ch) == G_UNICODE_SPACE_SEPARATOR) {
+    /* "a centered dot": cairo_new_sub_path, cairo_arc (x, y, 1.5 line widths, 0, 2 pi),
+     * cairo_close_path, cairo_fill -- the arc as Cairo flattens it is not restated */
+    rec->unsupported++;
+    return;
+  }
+  if (ch == '\t') {
+    /* (an arrow like U+21A6.  Pango lays tabs out itself: no tab glyph reaches the
+     * reference's show call, so there is no trace to pin a restatement on) */
+    rec->unsupported++;
+    return;
+  }
+  if (ch == '\n' || ch == 0x2028 || ch == 0x2029) {
+    double pts[24];
+    flutl_recorder_path_polygon (rec, pts, line_break_arrow (hb, gi, pts));
+    flutl_recorder_fill (rec);
+    return;
+  }
   cairo_scaled_font_t *smini = pango_cairo_font_get_scaled_font ((PangoCairoFont *) hb->mini);
   const int rows = hb->rows, cols = (ch > 0xffff ? 6 : 4) / rows;
   char buf[8];
@@ -1657,6 +1721,19 @@ void
 flutl_recorder_path_glyph (FlutlRecorder *rec, PangoFont *font,
     const PangoGlyphInfo *gi)
 {
+  HexBox *hb;
+  if (glyph_is_line_break_arrow (gi) && (hb = hexbox_info (font))) {
+    /* reference (Pango 1.45): the arrow's branch of the unknown-glyph renderer ends in
+     * cairo_fill whether it was asked to show or only to add to the path -- under
+     * pango_cairo_glyph_string_path (gstttmlrender.c:1153-1154) that fills THE WHOLE PENDING
+     * PATH, every glyph outline gathered for the stroke so far, in the outline's colour, and
+     * leaves the path empty: the text before a line separator gets a filled outline instead
+     * of a stroked one.  Reproduced (scene k21; found by comparing with the reference). */
+    double pts[24];
+    flutl_recorder_path_polygon (rec, pts, line_break_arrow (hb, gi, pts));
+    flutl_recorder_fill (rec);
+    return;
+  }
   PathOp *op = path_op_push (rec);
   op->font = g_object_ref (font);
   op->gi = *gi;
@@ -1680,6 +1757,31 @@ flutl_recorder_path_rect (FlutlRecorder *rec, double x, double y, double w, doub
   op->y = y;
   op->w = w;
   op->h = h;
+}
+
+/* cairo_move_to + cairo_line_to ... + cairo_close_path (the arrows Pango draws for a tab
+ * or a line separator no font has, hexbox_show) */
+void
+flutl_recorder_path_polygon (FlutlRecorder *rec, const double *pts, int n)
+{
+  if (n < 3 || n > 12) {
+    rec->unsupported++;
+    return;
+  }
+  PathOp *op = path_op_push (rec);
+  double x0 = pts[0], y0 = pts[1], x1 = pts[0], y1 = pts[1];
+  op->npoly = n;
+  memcpy (op->poly, pts, (size_t) n * 2 * sizeof (double));
+  for (int i = 1; i < n; i++) {
+    x0 = MIN (x0, pts[2 * i]);
+    x1 = MAX (x1, pts[2 * i]);
+    y0 = MIN (y0, pts[2 * i + 1]);
+    y1 = MAX (y1, pts[2 * i + 1]);
+  }
+  op->x = x0;
+  op->y = y0;
+  op->w = x1 - x0;
+  op->h = y1 - y0;
 }
 
 static void
@@ -1742,6 +1844,14 @@ stroke_key (FlutlRecorder *rec, double line_width, int base_x, int base_y,
           (uint64_t) (uint32_t) op->gi.geometry.y_offset;
       d[4] = op->gi.geometry.x_offset;
       d[5] = op->gi.geometry.y_offset;
+    } else if (op->npoly) {
+      /* (its points, hashed: the box alone does not say which polygon) */
+      uint64_t hsh = 1469598103934665603ull;
+      const uint8_t *b = (const uint8_t *) op->poly;
+      for (size_t q = 0; q < (size_t) op->npoly * 2 * sizeof (double); q++)
+        hsh = (hsh ^ b[q]) * 1099511628211ull;
+      u[0] = hsh;
+      u[1] = 0xa5a5000000000000ull | (uint64_t) op->npoly;
     }
     memcpy (p, d, sizeof d);
     p += sizeof d;
@@ -1929,6 +2039,11 @@ raster_build_path (FlutlRecorder *rec, RasterBox *rb)
       PangoGlyphInfo gi = op->gi;
       PangoGlyphString one = { 1, &gi, NULL, 1 };
       pango_cairo_glyph_string_path (cr, op->font, &one);
+    } else if (op->npoly) {
+      cairo_move_to (cr, op->poly[0], op->poly[1]);
+      for (int q = 1; q < op->npoly; q++)
+        cairo_line_to (cr, op->poly[2 * q], op->poly[2 * q + 1]);
+      cairo_close_path (cr);
     } else {
       cairo_rectangle (cr, op->x, op->y, op->w, op->h);
     }

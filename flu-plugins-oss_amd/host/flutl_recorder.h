@@ -79,6 +79,7 @@ void flutl_recorder_show_glyph (FlutlRecorder *rec, PangoFont *font,
  * into a real Cairo path if the stroke-mask cache misses. */
 void flutl_recorder_path_glyph (FlutlRecorder *rec, PangoFont *font,
     const PangoGlyphInfo *gi);
+void flutl_recorder_path_polygon (FlutlRecorder *rec, const double *pts, int n);
 void flutl_recorder_path_rect (FlutlRecorder *rec, double x, double y, double w,
     double h);
 /* anamorphic glyph (:1105-1112): cairo_scale (hscale, 1) + cairo_set_scaled_font

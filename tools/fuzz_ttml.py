@@ -18,7 +18,12 @@ WORDS = ("subtitle overlay Glyph MAVERICK jumpy quiz, fix & go; Why? 12:45 Ã¶Ã¤Ã
          "Test_under line Ã†Ã˜ x y z").split()
 # FUZZ_UNKNOWN=1: words no font of this image covers (Pango's hex boxes)
 if os.environ.get("FUZZ_UNKNOWN"):
-    WORDS += ["å­—å¹•", "í•œê¸€", "ãƒ†", "\U00020000x", "ä¸­"]
+    WORDS += ["å­—å¹•", "í•œê¸€", "ãƒ†", "\U00020000x", "ä¸­",
+              # (round 4: code points Pango's unknown-glyph renderer has branches of their own
+              # for -- the line separator's arrow where the font has no glyph -- and the ones
+              # HarfBuzz / Pango take care of before they get there)
+              "li\u2028ne", "\u2028", "a\u00a0b", "z\u200bw", "s\u00adhy", "\ufeffbom", "i\u3000d",
+              "l\u200er", "\u2060j"]
 FAMS = ["DejaVu Sans", "DejaVu Serif", "DejaVu Sans Mono", "sansSerif", "serif", "monospace",
         "default"]
 

@@ -18,3 +18,7 @@ for t in $TAGS; do
   esac
 done
 python3 tools/collect_profiles.py r04 $TAGS
+# (what gpurun brings back is gpurun_out/, at most 64 MiB: the summaries go there too, the
+# raw per-dispatch traces stay behind)
+mkdir -p gpurun_out/profiles_r04 && cp profiles/r04_* gpurun_out/profiles_r04/
+rm -rf gpurun_out/prof_*
