@@ -454,6 +454,87 @@ def e2e_block(W, H, cpu_baseline, gpu_warm=None, defer_cfg2_ref=False):
     return out
 
 
+def e2e_streams_leg(rank, local_rank, world, W, H):
+    """--gpus N: the ELEMENT on every GPU at once -- rank r runs BASELINE config 3's stream r
+    (cfg2 with seed 20 + r, 2400 scene states) through a child `gst-launch filesrc !
+    ttmlrender ! caps ! fakesink` with FLUTL_DEVICE=<its GPU>, all ranks side by side on the
+    node's host cores (which is where this path is bound: the kernel figure of the headline
+    scales trivially).  Started BEFORE this process touches the GPU (fresh child processes
+    only); the ranks meet through files under /tmp (no collective: nothing is initialised
+    yet).  Returns this rank's figures; rank 0 collects them in e2e_streams_collect()."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import tempfile
+    import e2e_timing
+    import gen_config_ttml
+    import gstenv
+    out = {"rank": rank}
+    meet = os.path.join(tempfile.gettempdir(), "flutl_bench_%s" % os.environ.get("MASTER_PORT", "0"))
+    os.makedirs(meet, exist_ok=True)
+
+    def leave(name, obj):
+        tmp = os.path.join(meet, name + ".tmp%d" % rank)
+        with open(tmp, "w") as f:
+            json.dump(obj, f)
+        os.replace(tmp, os.path.join(meet, name))
+
+    def wait_for(names, limit):
+        t0 = time.time()
+        while time.time() - t0 < limit:
+            if all(os.path.exists(os.path.join(meet, n)) for n in names):
+                return True
+            time.sleep(0.01)
+        return False
+
+    try:
+        if not gstenv.available(gstenv.HIP_PLUGIN_DIR):
+            raise RuntimeError("GStreamer runtime or the element plugin not present")
+        dev = 0 if os.environ.get("FLUTL_BENCH_REHEARSAL") else local_rank
+        env = {"FLUTL_DEVICE": str(dev)}
+        doc = os.path.join(meet, "cfg2_seed%d.ttml" % (20 + rank))
+        with open(doc, "w") as f:
+            f.write(gen_config_ttml.gen("cfg2", 20 + rank, n_states=2400))
+        e2e_timing.measure(os.path.join(ROOT, "bench_data", "cfg2.ttml"), W, H, extra_env=env)   # warm-up
+        leave("ready_%d" % rank, {})
+        if not wait_for(["ready_%d" % r for r in range(world)], 180):
+            raise RuntimeError("the other ranks' warm-up runs did not finish within 180 s")
+        r = e2e_timing.measure(doc, W, H, extra_env=env)
+        out.update(frames_per_s=r["frames_per_s"], buffers=r["buffers"], device=dev,
+                   t_first_us=r.get("t_first_us"), t_end_us=r.get("t_end_us"),
+                   host_record_us=r["record_us_per_buffer"])
+    except Exception as e:      # noqa: BLE001
+        out["error"] = repr(e)[:300]
+    leave("result_%d" % rank, out)
+    return meet
+
+
+def e2e_streams_collect(meet, world):
+    """rank 0: the ranks' figures (e2e_streams_leg) as one block -- frames of all streams over
+    the span from the earliest first buffer to the latest last frame (the elements' stamps
+    are CLOCK_MONOTONIC: comparable across the processes of one box)."""
+    import shutil
+    res, t0 = [], time.time()
+    for r in range(world):
+        p = os.path.join(meet, "result_%d" % r)
+        while not os.path.exists(p) and time.time() - t0 < 300:
+            time.sleep(0.05)
+        res.append(json.load(open(p)) if os.path.exists(p) else {"rank": r, "error": "no result within 300 s"})
+    shutil.rmtree(meet, ignore_errors=True)
+    ok = [x for x in res if "error" not in x and x.get("t_first_us") and x.get("t_end_us")]
+    out = {"what": "the element end to end on every GPU at once: stream r = cfg2 with seed 20 + r, 2400 "
+                   "scene states, filesrc ! ttmlrender ! caps ! fakesink in a child process per rank with "
+                   "FLUTL_DEVICE = its GPU; frames complete in host memory",
+           "streams": world, "host_cores": os.cpu_count(),
+           "per_stream": [x.get("frames_per_s") for x in res],
+           "errors": [x["error"] for x in res if "error" in x]}
+    if ok:
+        span = (max(x["t_end_us"] for x in ok) - min(x["t_first_us"] for x in ok)) * 1e-6
+        out["frames_per_s_total"] = round(sum(x["buffers"] - 1 for x in ok) / span, 1)
+        out["span_s"] = round(span, 4)
+        out["in_span"] = [round((x["t_end_us"] - x["t_first_us"]) * 1e-6 / span, 2) for x in ok]
+        out["unit"] = "frames/s"
+    return out
+
+
 def outline_block(with_cpu):
     """The outline rasteriser: the stroke polygon of one cue of a typical 4K stream (two
     lines of 96 px text, 3 px outline; bench_data/outline_4k.npz, made by the product's
@@ -545,15 +626,21 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE="
                          f"{os.environ.get('WORLD_SIZE')}: refusing to report a wrong n_gpus")
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # N > 1: the element's pipelines first, one per rank and GPU, before anything here touches
+    # the GPU (child processes; SURVEY 8e: one stream per GPU)
+    e2e_meet = None
+    if world > 1 and not args.no_e2e and CONFIGS[args.config][1] == 2160:
+        e2e_meet = e2e_streams_leg(rank, local_rank, world, *CONFIGS[args.config][:2])
+
     import torch
     import torch.distributed as dist
     import pyflutl as F
     import scenes
     import streams
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
     # FLUTL_BENCH_REHEARSAL=1: walk the N>1 control flow on a box with fewer GPUs
@@ -721,7 +808,21 @@ def main():
                 "p10": float(np.percentile(ms, 10)), "p90": float(np.percentile(ms, 90)),
                 "n": n_ev}
     kern_ms = kern["mean"] if kern else None
+    # the one collective the path can need (a single ordered output), exercised once over
+    # RCCL whatever --gather says: every rank's newest frame to rank 0, in rank order
+    gather_check = None
     if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got = streams.gather_frames(out[:frame_bytes])
+        torch.cuda.synchronize()
+        if rank == 0:
+            gather_check = {"ok": len(got) == world and bool(torch.equal(got[0], out[:frame_bytes])),
+                            "ms": round((time.perf_counter() - t0) * 1e3, 3),
+                            "bytes_per_rank": frame_bytes,
+                            "backend": "gloo (rehearsal)" if rehearsal else "nccl (RCCL)"}
+        del got
         dist.barrier()
 
     if rank == 0:
@@ -788,6 +889,10 @@ def main():
             while time.perf_counter() - t0 < 0.5:
                 step(0)
             torch.cuda.synchronize()
+        if gather_check:
+            res["gather_check"] = gather_check
+        if e2e_meet:
+            res["e2e_streams"] = e2e_streams_collect(e2e_meet, world)
         if world == 1 and not args.no_configs:
             # (beside the headline's own tensors, which gpu_warm still uses: cfg4's ring is 17 GB)
             res["configs"] = configs_block(skip=f"{args.config.split('_')[0]}_b{B}")

@@ -442,6 +442,7 @@ typedef struct
   GHashTable *blurred;       /* key (checksum) -> BlurredImage, per document */
   flutl_ctx *ctx;            /* NULL until first use; stays NULL without a GPU */
   gboolean ctx_failed;
+  int device;                   /* the HIP device of this instance (pick_device) */
   gboolean edge_blocks_set;     /* the recorder's stroke workers write edges into the context's blocks */
   FlutlPackWriter *dump;     /* FLUTL_DUMP_PACK=<file>: scene-pack dump */
   gboolean dump_only;        /* FLUTL_DUMP_ONLY=1: record, do not render */
@@ -2605,6 +2606,32 @@ edge_block_release (void *user, void *block)
   flutl_ctx_edge_block_release (user, block);
 }
 
+/* The HIP device of an instance.  FLUTL_DEVICE=<n>: that one, for every instance of the
+ * process (what a launcher with one process per GPU sets).  Else the instances of a process
+ * take the node's devices in turn -- the k-th ttmlrender to make its context gets device
+ * k mod flutl_device_count (), or the k-th entry of FLUTL_DEVICE_MAP="0,2,4,6" -- so that
+ * several streams in one pipeline process spread over the node's GPUs instead of sharing the
+ * first (streams are independent: SURVEY 8e, one per GPU). */
+static int
+pick_device (void)
+{
+  static gint next_instance = 0;
+  const gchar *dev = g_getenv ("FLUTL_DEVICE");
+  const gchar *map = g_getenv ("FLUTL_DEVICE_MAP");
+  if (dev && *dev)
+    return atoi (dev);
+  const int k = g_atomic_int_add (&next_instance, 1);
+  if (map && *map) {
+    gchar **v = g_strsplit (map, ",", -1);
+    const guint n = g_strv_length (v);
+    const int d = n ? atoi (v[k % n]) : 0;
+    g_strfreev (v);
+    return d;
+  }
+  const int n = flutl_device_count ();
+  return n > 0 ? k % n : 0;
+}
+
 static gboolean
 ensure_ctx (GstTTMLRender *render)
 {
@@ -2613,8 +2640,8 @@ ensure_ctx (GstTTMLRender *render)
     return TRUE;
   if (priv->ctx_failed)
     return FALSE;
-  const gchar *dev = g_getenv ("FLUTL_DEVICE");
-  int rc = flutl_ctx_create (dev ? atoi (dev) : 0, &priv->ctx);
+  priv->device = pick_device ();
+  int rc = flutl_ctx_create (priv->device, &priv->ctx);
   if (rc != FLUTL_OK) {
     priv->ctx_failed = TRUE;
     GST_ELEMENT_ERROR (render, LIBRARY, INIT,
@@ -3274,10 +3301,10 @@ timing_report (GstTTMLRender *render)
   } else {
     t_drained = priv->t_last_return;
   }
-  g_printerr ("ttmlrender-hip timing: buffers=%u record_us=%.1f device_us=%.1f "
+  g_printerr ("ttmlrender-hip timing: device=%d buffers=%u record_us=%.1f device_us=%.1f "
       "span_us=%" G_GINT64_FORMAT " drained_us=%" G_GINT64_FORMAT " delta_bytes=%.0f "
       "deferred=%u resolve_wait_us=%.1f atlas_upload_us=%.1f build_us=%.1f layout_us=%.1f region_hits=%u region_misses=%u strokes=%u stroke_us=%.0f stroke_queued_us=%.0f pure_wait_us=%.0f submit_us=%.1f push_block_us=%.1f runs_merged=%u runs_clashed=%u path_us=%.0f extents_us=%.0f miss_us=%.1f recoloured=%u worker_extents_us=%.0f worker_draw_us=%.0f worker_crop_us=%.0f polygons=%u polygon_edges=%" G_GUINT64_FORMAT " polygons_sequential=%u composed_paths=%" G_GUINT64_FORMAT " composed_checked=%" G_GUINT64_FORMAT " t_first_us=%" G_GINT64_FORMAT " t_end_us=%" G_GINT64_FORMAT "\n",
-      priv->n_timed, (double) priv->t_record / MAX (priv->n_timed - 1, 1),
+      priv->device, priv->n_timed, (double) priv->t_record / MAX (priv->n_timed - 1, 1),
       (double) (priv->t_device + priv->t_submit) / MAX (priv->n_timed - 1, 1),
       priv->t_last_return - priv->t_first_return,
       MAX (t_drained, priv->t_last_return) - priv->t_first_return,

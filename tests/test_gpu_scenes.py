@@ -208,6 +208,38 @@ def test_two_elements_in_one_process_and_a_thread_boundary_downstream(gpu, tmp_p
 
 @pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
                     reason="fluttml-hip plugin / GStreamer runtime not present")
+@pytest.mark.parametrize("knobs", [{}, {"FLUTL_DEVICE_MAP": "0,0,0"}, {"FLUTL_DEVICE": "0"}],
+                         ids=["round-robin", "map", "pinned"])
+def test_instances_of_one_process_take_the_nodes_devices_in_turn(gpu, tmp_path, knobs):
+    """Each ttmlrender picks its HIP device when it makes its context: the k-th instance of
+    the process takes device k mod the device count (FLUTL_DEVICE_MAP: the k-th entry of the
+    map; FLUTL_DEVICE: that one for all).  Three instances in one pipeline process: their
+    frames are the reference's, and their timing lines name the devices -- 0, 1, 2 where the
+    box has that many, all 0 on the one-GPU box (and under the map / the pinned device)."""
+    import re
+    names = ["k04_outline", "k06_animation", "k16_unknown_glyphs"]
+    outs = [str(tmp_path / (n + ".raw")) for n in names]
+    cmd = [os.path.join(gstenv.CONDA, "bin", "gst-launch-1.0"), "-q", "--no-fault"]
+    for n, o in zip(names, outs):
+        z = np.load(os.path.join(ROOT, "tests", "golden", "scenes", n + ".npz"))
+        cmd += ["filesrc", "location=" + os.path.join(ROOT, "tests", "golden", "scenes", n + ".ttml"),
+                "!", "ttmlrender", "!", f"video/x-raw,width={int(z['width'])},height={int(z['height'])}",
+                "!", "filesink", "location=" + o]
+    r = run_pipeline(cmd, gstenv.env_for(gstenv.HIP_PLUGIN_DIR, dict(knobs, FLUTL_TIMING="1")), str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    for n, o in zip(names, outs):
+        z = np.load(os.path.join(ROOT, "tests", "golden", "scenes", n + ".npz"))
+        got = np.fromfile(o, np.uint32).reshape(-1, int(z["height"]), int(z["width"]))
+        assert np.array_equal(got, z["frames"]), n
+    devs = sorted(int(d) for d in re.findall(r"ttmlrender-hip timing: device=(\d+) buffers=[1-9]", r.stderr))
+    assert len(devs) == 3, r.stderr[-1500:]
+    n_dev = F.lib().flutl_device_count()
+    want = sorted(k % n_dev for k in range(3)) if not knobs else [0, 0, 0]
+    assert devs == want, (devs, want, n_dev)
+
+
+@pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
+                    reason="fluttml-hip plugin / GStreamer runtime not present")
 @pytest.mark.parametrize("knobs", [{"FLUTL_SYNC": "1"}, {"FLUTL_NO_REGION_CACHE": "1"},
                                    {"FLUTL_MAX_AHEAD": "1", "FLUTL_STROKE_THREADS": "1"},
                                    {"FLUTL_FULL_D2H": "1"}, {"FLUTL_POOL_PREFILL": "0"},

@@ -113,3 +113,42 @@ def test_bench_gpus_n_starts_n_ranks_itself(tmp_path):
                        env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "refusing" in r.stderr
+
+
+def test_end_to_end_streams_leg_meets_and_adds_up(tmp_path):
+    """bench.py --gpus N runs the ELEMENT on every GPU at once before it touches the GPU
+    itself (e2e_streams_leg: one child pipeline per rank with FLUTL_DEVICE = its GPU; the
+    ranks meet through files).  Two ranks here, the pipeline run replaced by a stand-in that
+    reports the environment it was given: the ranks wait for each other's warm-up, each
+    measures its own stream of config 3 (seed 20 + rank) on its own device, and rank 0's
+    block is all frames over the common span."""
+    import json
+    import subprocess
+    fake = tmp_path / "fake"
+    fake.mkdir()
+    (fake / "e2e_timing.py").write_text(
+        "import os, time\n"
+        "def measure(ttml, W, H, extra_env=None, **kw):\n"
+        "    t0 = time.monotonic() * 1e6\n"
+        "    time.sleep(0.2)\n"
+        "    return {'buffers': 101, 'frames_per_s': 500.0, 'record_us_per_buffer': 1.0,\n"
+        "            'device_us_per_buffer': 1.0, 't_first_us': t0, 't_end_us': t0 + 2e5,\n"
+        "            'seen': [os.path.basename(ttml), extra_env.get('FLUTL_DEVICE')]}\n")
+    code = ("import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r); import e2e_timing;"
+            "assert 'fake' in e2e_timing.__file__; import importlib.util as u;"
+            "s = u.spec_from_file_location('b', %r); b = u.module_from_spec(s); s.loader.exec_module(b);"
+            "import gstenv; gstenv.available = lambda d: True;"
+            "rank = int(sys.argv[1]); meet = b.e2e_streams_leg(rank, rank, 2, 3840, 2160);"
+            "print(json.dumps(b.e2e_streams_collect(meet, 2)) if rank == 0 else '{}')"
+            % (os.path.join(ROOT, "tools"), str(fake), os.path.join(ROOT, "bench.py")))
+    env = dict(os.environ, MASTER_PORT="45%03d" % (os.getpid() % 1000), PYTHONPATH=str(fake))
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    block = json.loads(outs[0][0].strip().split("\n")[-1])
+    assert block["streams"] == 2 and block["errors"] == []
+    assert block["per_stream"] == [500.0, 500.0]
+    # 2 x 100 frames over a span of 0.2 s and whatever the two timed runs were apart
+    assert 0.2 <= block["span_s"] < 0.5
+    assert abs(block["frames_per_s_total"] - 200 / block["span_s"]) < 1.0       # (span_s is rounded)

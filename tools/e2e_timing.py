@@ -56,7 +56,8 @@ def measure(ttml, W, H, extra_env=None, log_path=None, sink="fakesink", props=()
     for k in ("delta_bytes", "deferred", "resolve_wait_us", "atlas_upload_us", "build_us",
               "layout_us", "strokes", "stroke_us", "stroke_queued_us", "pure_wait_us", "submit_us",
               "push_block_us", "miss_us", "region_hits", "region_misses", "recoloured",
-              "polygons", "polygon_edges", "polygons_sequential", "composed_paths", "composed_checked"):
+              "polygons", "polygon_edges", "polygons_sequential", "composed_paths", "composed_checked",
+              "t_first_us", "t_end_us", "device"):
         if k in kv:
             out[k] = kv[k]
     return out
