@@ -448,6 +448,18 @@ def e2e_block(W, H, cpu_baseline, gpu_warm=None, defer_cfg2_ref=False):
             "reference": ref, "reference_from": "typical_4k (120 cues of the same generator)"}
     except Exception as e:      # noqa: BLE001
         out["typical_4k_3000_cues"] = {"error": repr(e)[:300]}
+    # what a consumer pays for touching the buffers (tools/map_cost.py): the element's memory
+    # is READONLY (block and twin must stay equal), the reference's buffers are writable
+    # (gstttmlrender.c:1442-1444): an element that works in place copies each frame first,
+    # unless FLUTL_WRITABLE=1
+    try:
+        import map_cost
+        progress("consumers that map the buffers")
+        if gpu_warm:
+            gpu_warm()
+        out["consumers"] = map_cost.measure(1200, W, H)
+    except Exception as e:      # noqa: BLE001
+        out["consumers"] = {"error": repr(e)[:300]}
     # (one attempt per leg; a leg that failed -- or a pipeline killed at its time limit --
     # is counted here and keeps its error text: nothing is run again)
     out["errors"] = sum(1 for v in out.values() if isinstance(v, dict) and "error" in v)

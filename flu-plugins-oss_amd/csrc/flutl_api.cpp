@@ -109,6 +109,7 @@ struct flutl_frame {
   // shared sub-memory lets two threads wait for one frame at once)
   std::atomic<bool> pending;   // a submission has been queued since the last wait
   std::atomic<int> error;      // sticky: a submission failed, the content is undefined
+  std::atomic<bool> written;   // the host block was written into by its consumer (flutl_frame_mark_written)
   uint32_t ext[4];     // x0, y0, x1, y1: what the frame holds lies inside (empty: nothing)
 };
 
@@ -1161,6 +1162,7 @@ extern "C" int flutl_frame_create (flutl_ctx *c, uint32_t width, uint32_t height
   f->done = nullptr;
   f->pending = false;
   f->error = 0;
+  f->written = false;
   f->ext[0] = f->ext[1] = f->ext[2] = f->ext[3] = 0;
   bool ok = hip_ok (hipHostMalloc (&f->host, bytes, hipHostMallocPortable | hipHostMallocMapped));
   ok = ok && hip_ok (hipHostGetDevicePointer (&f->host_dev, f->host, 0));
@@ -1202,6 +1204,12 @@ extern "C" void flutl_frame_destroy (flutl_frame *f)
 }
 
 extern "C" void *flutl_frame_host (const flutl_frame *f) { return f ? f->host : nullptr; }
+
+extern "C" void flutl_frame_mark_written (flutl_frame *f)
+{
+  if (f)
+    f->written.store (true, std::memory_order_release);
+}
 
 extern "C" const void *flutl_frame_device (const flutl_frame *f)
 {
@@ -1292,6 +1300,17 @@ extern "C" int flutl_frame_submit (flutl_ctx *c, flutl_frame *f,
     memcpy (sl.host, regions, (size_t) n_regions * sizeof (flutl_region));
   if (n_prims)
     memcpy (static_cast<uint8_t *> (sl.host) + rb, prims, (size_t) n_prims * sizeof (flutl_prim));
+  // a frame its consumer wrote into: the twin is brought up to the host block (the whole
+  // frame up, in stream order) and every row is composited, so that the comparison below
+  // puts each pixel right again in both
+  if (f->written.exchange (false, std::memory_order_acq_rel)) {
+    if (!hip_ok (hipMemcpyAsync (f->twin, f->host, (size_t) width * 4 * height, hipMemcpyHostToDevice,
+            c->stream)))
+      return FLUTL_ENODEV;
+    f->ext[0] = f->ext[1] = 0;
+    f->ext[2] = width;
+    f->ext[3] = height;
+  }
   // rows of this submission: what the frame held before + what it holds now
   uint32_t y0 = now[1], y1 = now[3];
   if (f->ext[3] > f->ext[1]) {

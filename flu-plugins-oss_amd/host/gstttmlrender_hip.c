@@ -256,6 +256,10 @@ flutl_mem_map (GstMemory *mem, gsize maxsize, GstMapFlags flags)
     GST_ERROR ("ttmlrender: the frame behind this memory failed to render");
     return NULL;
   }
+  /* (FLUTL_WRITABLE: whoever maps for writing works in place in the block; block and twin
+   * are brought together again when the frame is next used) */
+  if (flags & GST_MAP_WRITE)
+    flutl_frame_mark_written (m->frame);
   return m->data;
 }
 
@@ -411,7 +415,19 @@ frame_pool_wrap (FramePool *p, FrameSlot *slot, gsize size, Ticket *ticket)
   g_atomic_int_inc (&p->refs);
   if (slot->frame) {
     FlutlMemory *m = g_new0 (FlutlMemory, 1);
-    gst_memory_init (GST_MEMORY_CAST (m), GST_MEMORY_FLAG_READONLY, flutl_allocator_get (),
+    /* READONLY, unless FLUTL_WRITABLE=1: the reference's buffers are writable
+     * (gstttmlrender.c:1442-1444), so an element that works in place on its input takes them as
+     * they are; READONLY memory makes it copy the frame first (33 MB at 4K: 8-9 ms per frame,
+     * tools/map_cost.py).  The price of writable: a frame that was written into costs its next
+     * user one copy of the frame up to the device and a composite of all its rows
+     * (flutl_frame_mark_written) instead of the rows of the regions. */
+    static gsize writable_once = 0;
+    static gboolean writable = FALSE;
+    if (g_once_init_enter (&writable_once)) {
+      writable = g_getenv ("FLUTL_WRITABLE") != NULL;
+      g_once_init_leave (&writable_once, 1);
+    }
+    gst_memory_init (GST_MEMORY_CAST (m), writable ? 0 : GST_MEMORY_FLAG_READONLY, flutl_allocator_get (),
         NULL, size, 0, 0, size);
     m->block = b;
     m->frame = slot->frame;

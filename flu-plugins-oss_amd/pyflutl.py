@@ -60,7 +60,7 @@ EXPORTS = [
     "flutl_frame_device", "flutl_frame_submit", "flutl_frame_wait", "flutl_ctx_delta_bytes",
     "flutl_atlas_put_polygon", "flutl_polygon_entry_bytes", "flutl_ctx_scan_fallbacks",
     "flutl_scan_scratch_bytes", "flutl_scan_zero_bytes", "flutl_ctx_edge_block_acquire",
-    "flutl_ctx_edge_block_release", "flutl_launch_scan", "flutl_scan_status",
+    "flutl_ctx_edge_block_release", "flutl_frame_mark_written", "flutl_launch_scan", "flutl_scan_status",
 ]
 
 
@@ -124,6 +124,8 @@ def lib():
         L.flutl_ctx_edge_block_acquire.argtypes = [vp, sz, ctypes.POINTER(vp)]
         L.flutl_ctx_edge_block_release.argtypes = [vp, vp]
         L.flutl_ctx_edge_block_release.restype = None
+        L.flutl_frame_mark_written.argtypes = [vp]
+        L.flutl_frame_mark_written.restype = None
         L.flutl_scan_zero_bytes.argtypes = []
         L.flutl_scan_zero_bytes.restype = sz
         L.flutl_launch_scan.argtypes = [vp, vp, u32, vp, ctypes.c_int, vp, vp, sz, ctypes.c_int]
@@ -506,6 +508,9 @@ class Frame:
         prims = np.ascontiguousarray(prims, PRIM_DTYPE)
         _check(lib().flutl_frame_submit(self.ctx._h, self._h, _np_ptr(regions), len(regions),
                                         _np_ptr(prims), len(prims)), "flutl_frame_submit")
+
+    def mark_written(self):
+        lib().flutl_frame_mark_written(self._h)
 
     def wait(self):
         _check(lib().flutl_frame_wait(self._h), "flutl_frame_wait")

@@ -446,6 +446,12 @@ int   flutl_frame_submit (flutl_ctx *ctx, flutl_frame *frame,
     const flutl_region *regions, uint32_t n_regions,
     const flutl_prim *prims, uint32_t n_prims);
 int   flutl_frame_wait (flutl_frame *frame);
+/* Somebody has WRITTEN into the frame's host block (a downstream element that works in
+ * place on writable memory, FLUTL_WRITABLE): block and twin no longer hold the same pixels.
+ * The next flutl_frame_submit brings the twin up to the block (one copy of the frame up, in
+ * stream order) and composites the whole frame, so that the delta read-back puts every pixel
+ * right again.  Any thread. */
+void  flutl_frame_mark_written (flutl_frame *frame);
 /* bytes all submissions on this context have written to host blocks so far
  * (drains the context's stream; statistics) */
 uint64_t flutl_ctx_delta_bytes (flutl_ctx *ctx);

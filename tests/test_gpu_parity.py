@@ -586,3 +586,39 @@ def test_fused_delta_launch_tracks_a_sequence_of_lists(gpu, size):
                 assert int(changed.item()) == before, "an unchanged frame wrote segments"
         prev = now
     assert 0 < int(changed.item()) * seg <= 7 * (W * 4 + seg) * H
+
+
+def test_a_frame_written_into_by_its_consumer_is_put_right_by_the_next_submission(gpu):
+    """FLUTL_WRITABLE: downstream may work in place in a frame's host block.  After
+    flutl_frame_mark_written the next submission copies the block up to the twin and composites
+    every row, so that block and twin both hold the new frame again -- wherever the consumer
+    scribbled (inside and outside the regions)."""
+    W, H = 640, 360
+    R, P, A = scenes.random_scene(77, W, H, n_regions=5)
+    R2, P2, A2 = scenes.random_scene(78, W, H, n_regions=3)
+    atlas = np.concatenate([A, A2[F.ATLAS_SLACK:]])
+    P2 = P2.copy()
+    mask = (P2["op"] == F.OP_MASK) | (P2["op"] == F.OP_IMAGE)
+    P2["a"][mask] += len(A) - F.ATLAS_SLACK
+    with F.Context(0) as ctx:
+        ctx.atlas_put(atlas[F.ATLAS_SLACK:])
+        fr = ctx.frame(W, H)
+        try:
+            fr.submit(R, P)
+            fr.wait()
+            assert np.array_equal(fr.host(), O.render(W, H, R, P, atlas))
+            host = fr.host()
+            host[::7, ::5] ^= 0x00ff00ff            # (the consumer's work, all over the frame)
+            host[H - 3:, :] = 0x12345678
+            fr.mark_written()
+            fr.submit(R2, P2)
+            fr.wait()
+            want = O.render(W, H, R2, P2, atlas)
+            assert np.array_equal(fr.host(), want)
+            # ... and the twin with it: a further submission of the same list writes nothing
+            before = ctx.delta_bytes()
+            fr.submit(R2, P2)
+            fr.wait()
+            assert ctx.delta_bytes() == before and np.array_equal(fr.host(), want)
+        finally:
+            fr.close()

@@ -8,6 +8,7 @@ import hashlib
 import json
 import os
 import sys
+import tempfile
 
 import numpy as np
 import pytest
@@ -69,6 +70,19 @@ def run_pipeline(cmd, env, cwd, limit=90):
     (rocgdb, if it may attach), is killed, and FAILS the test: a recurrence must show in the
     record, and its cause is then read from those backtraces."""
     import subprocess
+    # (a debugger that is not the pipeline's parent may attach only if the pipeline says so)
+    so = os.path.join(tempfile.gettempdir(), "flutl_ptracer_any.so")
+    if not os.path.exists(so):
+        src = so[:-3] + ".c"
+        with open(src, "w") as f:
+            f.write("#include <sys/prctl.h>\n__attribute__((constructor)) static void any(void)"
+                    "{ prctl(PR_SET_PTRACER, PR_SET_PTRACER_ANY, 0, 0, 0); }\n")
+        try:
+            subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", src, "-o", so])
+        except Exception:       # noqa: BLE001
+            so = None
+    if so:
+        env = dict(env, LD_PRELOAD=(env.get("LD_PRELOAD", "") + ":" + so).strip(":"))
     p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=cwd)
     try:
         out, err = p.communicate(timeout=limit)
@@ -247,10 +261,13 @@ def test_instances_of_one_process_take_the_nodes_devices_in_turn(gpu, tmp_path, 
                                    {"FLUTL_QUEUE_ALWAYS": "1", "FLUTL_NO_LAYOUT_CACHE": "1"},
                                    {"FLUTL_NO_RECOLOUR": "1"}, {"FLUTL_HOST_STROKES": "1"},
                                    {"FLUTL_NO_COMPOSED_PATHS": "1"},
-                                   {"FLUTL_CHECK_PATHS": "1", "FLUTL_MAX_AHEAD": "16"}],
+                                   {"FLUTL_CHECK_PATHS": "1", "FLUTL_MAX_AHEAD": "16"},
+                                   {"FLUTL_WRITABLE": "1"}, {"FLUTL_SCAN_FUSED": "1"},
+                                   {"FLUTL_NO_EDGE_BLOCKS": "1"}],
                          ids=["sync", "no-region-cache", "ahead1", "full-d2h", "no-prefill",
                               "no-plans-no-merge", "queue-always", "no-recolour", "host-strokes",
-                              "paths-by-cairo", "paths-checked-ahead16"])
+                              "paths-by-cairo", "paths-checked-ahead16", "writable", "scan-fused",
+                              "no-edge-blocks"])
 def test_element_modes_all_reproduce_the_reference(gpu, knobs):
     """The element's pipeline knobs change how a buffer is produced, never what it
     holds: an outlined, animated scene and a moving outline under each of them."""
@@ -354,3 +371,30 @@ def test_element_fused_over_video_at_full_size(gpu):
     assert len(oraw) == n * size and len(vraw) == n * size
     got = [hashlib.sha256(oraw[k * size:(k + 1) * size]).hexdigest() for k in range(n)]
     assert got == meta["sha256"], [k for k in range(n) if got[k] != meta["sha256"][k]]
+
+
+@pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
+                    reason="fluttml-hip plugin / GStreamer runtime not present")
+@pytest.mark.parametrize("mode,knobs", [("none", {}), ("read", {}), ("write", {}),
+                                        ("write", {"FLUTL_WRITABLE": "1"})],
+                         ids=["dropped", "read", "write-readonly", "write-writable"])
+def test_a_consumer_that_maps_the_buffers(gpu, tmp_path, mode, knobs):
+    """ttmlrender ! probe ! fakesink, the probe (tools/map_cost.c: a GstBaseTransform) passing on
+    / reading / working in place in every buffer.  READONLY memory (the default): GStreamer
+    copies each frame an in-place element touches; FLUTL_WRITABLE=1: it works in the frame's
+    own block, and the element puts block and twin together again when the frame is next
+    used.  Every buffer of the document arrives either way."""
+    import re
+    import map_cost
+    import gen_config_ttml
+    exe = map_cost.build()
+    doc = str(tmp_path / "cfg2_300.ttml")
+    with open(doc, "w") as f:
+        f.write(gen_config_ttml.gen("cfg2", 2, n_states=300))
+    r = run_pipeline([exe, doc, "3840", "2160", mode], gstenv.env_for(gstenv.HIP_PLUGIN_DIR, knobs),
+                     str(tmp_path), limit=60)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
+    m = re.search(r"buffers=(\d+) frames_per_s=([0-9.]+) memories_replaced_by_copies=(\d+)", r.stdout)
+    assert m and int(m.group(1)) == 601, r.stdout
+    if mode == "write":     # READONLY memory: GStreamer copies each frame; writable: none
+        assert (int(m.group(3)) == 0) == bool(knobs), r.stdout
