@@ -2174,6 +2174,8 @@ raster_crop (FlutlRecorder *rec, StrokeEntry *e, const RasterBox *rb)
 /* Build the pending path for real, stroke it and cut the coverage out of the
  * scratch surface.  Returns 0 if the stroke touched the surface borders (the
  * mask is then only valid at this very position). */
+static int stroke_draw (FlutlRecorder *rec, StrokeEntry *e, const RasterBox *rbp, int fill);
+
 static int
 stroke_rasterise (FlutlRecorder *rec, StrokeEntry *e, int fill)
 {
@@ -2186,6 +2188,15 @@ stroke_rasterise (FlutlRecorder *rec, StrokeEntry *e, int fill)
     cairo_new_path (cr);
     return rb.inside;
   }
+  return stroke_draw (rec, e, &rb, fill);
+}
+
+/* (the path is on the context, its box known: Cairo rasterises it) */
+static int
+stroke_draw (FlutlRecorder *rec, StrokeEntry *e, const RasterBox *rbp, int fill)
+{
+  cairo_t *cr = rec->cr;
+  const RasterBox rb = *rbp;
   /* coverage = what the stroker + scan converter hand to the span renderer */
   cairo_save (cr);
   cairo_set_source_rgba (cr, 1, 1, 1, 1);
@@ -2371,7 +2382,20 @@ stroke_job_wait (StrokeJob *j)
 }
 
 static gint64 stroke_jobs_done, stroke_jobs_us, stroke_jobs_queue_us;   /* statistics */
+static gint64 masks_by_cairo;           /* strokes / fills Cairo rasterised on the recording thread */
+static gint64 masks_by_cairo_on_workers;        /* ... and strokes Cairo drew on a worker thread */
+static gint64 fills_by_device;          /* fills that went to the device as polygons */
 static gint64 stroke_jobs_polygons;     /* ... of which left as polygons for the device */
+
+/* (process-wide) masks Cairo rasterised synchronously -- strokes the stroker declined, fills
+ * with the device route off -- and fills the device converted */
+void
+flutl_recorder_raster_stats (uint64_t *by_cairo, uint64_t *device_fills)
+{
+  *by_cairo = (uint64_t) __atomic_load_n (&masks_by_cairo, __ATOMIC_RELAXED) +
+      (uint64_t) __atomic_load_n (&masks_by_cairo_on_workers, __ATOMIC_RELAXED);
+  *device_fills = (uint64_t) __atomic_load_n (&fills_by_device, __ATOMIC_RELAXED);
+}
 
 uint64_t
 flutl_recorder_polygon_jobs (void)
@@ -2471,6 +2495,10 @@ stroke_job_run (gpointer data, gpointer user_data)
     stroke_job_unref (j);
     return;
   }
+  /* (a stroke the stroker declines -- a path of axis-aligned segments only, such as the frame
+   * of a hex box, which Cairo strokes as boxes with another rasteriser -- or the device route
+   * switched off: Cairo draws it, here on the worker) */
+  __atomic_fetch_add (&masks_by_cairo_on_workers, 1, __ATOMIC_RELAXED);
   WorkerSurface *ws = g_private_get (&worker_surface_key);
   if (!ws) {
     ws = calloc (1, sizeof *ws);
@@ -3278,6 +3306,63 @@ ops_get_mask (FlutlRecorder *rec, int fill, int *dx, int *dy)
   return e;
 }
 
+/* cairo_fill of the pending path with the mask made by the device: the path as the polygon
+ * Cairo makes of it (flutl_fill_to_polygon: every sub-path closed, curves flattened -- no
+ * stroker involved, some tens of microseconds on this thread), scan converted like an
+ * outline's.  What the reference fills: anamorphic glyphs (gstttmlrender.c:1109-1118) and,
+ * through Pango, the line-break arrow.  A path the polygon maker declines (axis-aligned
+ * segments only: Cairo fills those as boxes) is rasterised by Cairo as before. */
+static int
+fill_by_device (FlutlRecorder *rec, StrokeEntry *e)
+{
+  cairo_t *cr = rec->cr;
+  RasterBox rb;
+  raster_prepare (rec, 1, &rb);
+  e->w = e->h = 0;
+  memcpy (e->ext, rb.ext, sizeof e->ext);
+  if (rb.bx1 <= rb.bx0 || rb.by1 <= rb.by0) {
+    cairo_new_path (cr);
+    return rb.inside;
+  }
+  cairo_save (cr);
+  cairo_identity_matrix (cr);
+  cairo_path_t *pth = cairo_copy_path (cr);
+  cairo_restore (cr);
+  const int target[4] = { imax (rb.lim[0], 0), imax (rb.lim[1], 0), imin (rb.lim[2], rec->sw),
+    imin (rb.lim[3], rec->sh) };
+  FlutlPolygon pg;
+  flutl_polygon_init (&pg);
+  const int made = pth && pth->status == CAIRO_STATUS_SUCCESS &&
+      flutl_fill_to_polygon (pth, cairo_get_tolerance (cr), target, &pg) == FLUTL_STROKER_OK;
+  if (pth)
+    cairo_path_destroy (pth);
+  if (!made) {
+    flutl_polygon_fini (&pg);
+    return stroke_draw (rec, e, &rb, 1);
+  }
+  cairo_new_path (cr);
+  memcpy (e->lim, rb.lim, sizeof e->lim);
+  if (pg.box[2] > pg.box[0] && pg.box[3] > pg.box[1] && pg.n_edges) {
+    FlutlPolygonEntry *pe = calloc (1, sizeof *pe);
+    if (!pe)
+      abort ();
+    pe->edges = pg.edges;
+    pe->n_edges = pg.n_edges;
+    memcpy (pe->box, pg.box, sizeof pe->box);
+    pe->w = pg.box[2] - pg.box[0];
+    pe->h = pg.box[3] - pg.box[1];
+    pg.edges = NULL;
+    e->x = pe->box[0];
+    e->y = pe->box[1];
+    e->w = pe->w;
+    e->h = pe->h;
+    e->offset = atlas_reserve_polygon (rec, pe) + MASK_PAD;
+    __atomic_fetch_add (&fills_by_device, 1, __ATOMIC_RELAXED);
+  }
+  flutl_polygon_fini (&pg);
+  return rb.inside;
+}
+
 static void
 ops_to_mask (FlutlRecorder *rec, int fill)
 {
@@ -3311,6 +3396,7 @@ ops_to_mask (FlutlRecorder *rec, int fill)
       /* a stroke the stroker does not take: Cairo draws it (the ops are still pending) */
       stroke_job_unref (j);
       stroke_job_unref (j);
+      __atomic_fetch_add (&masks_by_cairo, 1, __ATOMIC_RELAXED);
       e->translatable = stroke_rasterise (rec, e, fill);
     } else {
       e->w = e->h = 0;
@@ -3330,7 +3416,10 @@ ops_to_mask (FlutlRecorder *rec, int fill)
         stroke_job_unref (j);
       }
     }
+  } else if (is_new && fill && root_of (rec)->device_strokes) {
+    e->translatable = fill_by_device (rec, e);
   } else if (is_new) {
+    __atomic_fetch_add (&masks_by_cairo, 1, __ATOMIC_RELAXED);
     e->translatable = stroke_rasterise (rec, e, fill);
   }
   stroke_emit (rec, e, dx, dy);

@@ -148,6 +148,7 @@ void flutl_recorder_set_device_strokes (FlutlRecorder *rec, int on);
  * out (process-wide); *checked: how many of them FLUTL_CHECK_PATHS compared with Cairo's */
 uint64_t flutl_recorder_composed_paths (uint64_t *checked);
 uint64_t flutl_recorder_polygon_jobs (void);
+void flutl_recorder_raster_stats (uint64_t *by_cairo, uint64_t *device_fills);
 
 /* atlas entries appended since the last call (for incremental upload);
  * returns the number of entries; entry i spans [offsets[i], offsets[i]+sizes[i]);

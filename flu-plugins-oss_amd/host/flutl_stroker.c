@@ -68,6 +68,7 @@ typedef struct
   Box bounds;
   Contour cw, ccw;
   int failed;
+  Pt fill_current, fill_last_move;      /* cairo_fill (flutl_fill_to_polygon): cairo_filler_t */
 } Stroker;
 
 /* ---- fixed point, slopes ------------------------------------------------------- */
@@ -928,6 +929,7 @@ typedef struct
   Knots knots;
   Slope initial_slope, final_slope;
   Pt last_point;
+  int filling;                  /* cairo_fill: the points go to filler_line_to */
 } Spline;
 
 static int
@@ -937,6 +939,7 @@ spline_init (Spline *s, Stroker *st, const Pt *a, const Pt *b, const Pt *c, cons
   if (a->x == b->x && a->y == b->y && c->x == d->x && c->y == d->y)
     return 0;
   s->st = st;
+  s->filling = 0;
   s->knots.a = *a;
   s->knots.b = *b;
   s->knots.c = *c;
@@ -958,6 +961,16 @@ spline_init (Spline *s, Stroker *st, const Pt *a, const Pt *b, const Pt *c, cons
   return 1;
 }
 
+static void polygon_add_edge (Stroker *st, const Pt *p1, const Pt *p2, int dir);
+
+/* _cairo_filler_line_to (cairo-path-fill.c): _cairo_polygon_add_external_edge */
+static void
+filler_line_to (Stroker *st, const Pt *point)
+{
+  polygon_add_edge (st, &st->fill_current, point, 1);
+  st->fill_current = *point;
+}
+
 static void
 spline_add_point (Spline *s, const Pt *point, const Pt *knot)
 {
@@ -967,7 +980,10 @@ spline_add_point (Spline *s, const Pt *point, const Pt *knot)
     return;
   slope_init (&slope, point, knot);
   s->last_point = *point;
-  spline_to (s->st, point, &slope);
+  if (s->filling)
+    filler_line_to (s->st, point);
+  else
+    spline_to (s->st, point, &slope);
 }
 
 static inline void
@@ -1405,10 +1421,38 @@ flutl_polygon_fini (FlutlPolygon *pg)
   pg->n_edges = pg->cap = 0;
 }
 
+static int path_to_polygon (const cairo_path_t *path, const cairo_matrix_t *ctm, double line_width,
+    double miter_limit, cairo_line_join_t line_join, double tolerance, const int target[4],
+    FlutlPolygon *polygon, int fill);
+
 int
 flutl_stroke_to_polygon (const cairo_path_t *path, const cairo_matrix_t *ctm, double line_width,
     double miter_limit, cairo_line_join_t line_join, double tolerance, const int target[4],
     FlutlPolygon *polygon)
+{
+  return path_to_polygon (path, ctm, line_width, miter_limit, line_join, tolerance, target, polygon, 0);
+}
+
+/* cairo_fill of the path (in device coordinates) as the polygon Cairo makes of it
+ * (cairo-path-fill.c: _cairo_path_fixed_fill_to_polygon; cairo-spans-compositor.c:
+ * _cairo_spans_compositor_fill): every sub-path closed, curves flattened to `tolerance`,
+ * edges cut to the composite's box where the path's extents reach beyond the target.
+ * FLUTL_STROKER_RECTILINEAR: a path of axis-aligned segments only, which Cairo fills as
+ * boxes (another rasteriser).  Pinned against the real cairo_fill: oracle/stroke_check.c
+ * modes 4-7. */
+int
+flutl_fill_to_polygon (const cairo_path_t *path, double tolerance, const int target[4],
+    FlutlPolygon *polygon)
+{
+  cairo_matrix_t id;
+  cairo_matrix_init_identity (&id);
+  return path_to_polygon (path, &id, 1.0, 10.0, CAIRO_LINE_JOIN_MITER, tolerance, target, polygon, 1);
+}
+
+static int
+path_to_polygon (const cairo_path_t *path, const cairo_matrix_t *ctm, double line_width,
+    double miter_limit, cairo_line_join_t line_join, double tolerance, const int target[4],
+    FlutlPolygon *polygon, int fill)
 {
   Stroker st;
   PathFixed pf;
@@ -1505,6 +1549,8 @@ flutl_stroke_to_polygon (const cairo_path_t *path, const cairo_matrix_t *ctm, do
         style_expansion < M_SQRT2 * miter_limit)
       style_expansion = M_SQRT2 * miter_limit;
     style_expansion *= line_width;
+    if (fill)                   /* _cairo_path_fixed_approximate_fill_extents: the path's own */
+      style_expansion = 0.0;
     if (matrix_has_unity_scale (ctm)) {
       dx = dy = style_expansion;
     } else {
@@ -1535,7 +1581,46 @@ flutl_stroke_to_polygon (const cairo_path_t *path, const cairo_matrix_t *ctm, do
     }
   }
 
-  if (pf.has_curve_to || line_join == CAIRO_LINE_JOIN_ROUND) {
+  if (fill) {
+    /* _cairo_path_fixed_fill_to_polygon: move_to closes the sub-path before it, a curve
+     * that misses the limits is its chord, the end closes the last sub-path */
+    const Pt *p = pf.pts;
+    Box limit = { { polygon->limits[0], polygon->limits[1] }, { polygon->limits[2], polygon->limits[3] } };
+    st.fill_current.x = st.fill_current.y = 0;
+    st.fill_last_move = st.fill_current;
+    for (int i = 0; i < pf.n_ops; i++) {
+      switch (pf.ops[i]) {
+        case OP_MOVE_TO:
+          filler_line_to (&st, &st.fill_last_move);
+          st.fill_current = st.fill_last_move = p[0];
+          p += 1;
+          break;
+        case OP_LINE_TO:
+          filler_line_to (&st, &p[0]);
+          p += 1;
+          break;
+        case OP_CURVE_TO: {
+          Spline spline;
+          if ((polygon->has_limits && !spline_intersects (&st.fill_current, &p[0], &p[1], &p[2], &limit)) ||
+              !spline_init (&spline, &st, &st.fill_current, &p[0], &p[1], &p[2])) {
+            filler_line_to (&st, &p[2]);
+          } else {
+            Knots s1 = spline.knots;
+            spline.filling = 1;
+            spline.last_point = s1.a;
+            spline_decompose_into (&s1, tolerance * tolerance, &spline);
+            filler_line_to (&st, &spline.knots.d);
+          }
+          p += 3;
+          break;
+        }
+        case OP_CLOSE_PATH:
+          filler_line_to (&st, &st.fill_last_move);
+          break;
+      }
+    }
+    filler_line_to (&st, &st.fill_last_move);
+  } else if (pf.has_curve_to || line_join == CAIRO_LINE_JOIN_ROUND) {
     if (!pen_init (&st, st.half_line_width, tolerance, ctm)) {
       rc = FLUTL_STROKER_ENOMEM;
       goto out;
@@ -1545,7 +1630,7 @@ flutl_stroke_to_polygon (const cairo_path_t *path, const cairo_matrix_t *ctm, do
       goto out;
   }
 
-  {
+  if (!fill) {
     const Pt *p = pf.pts;
     for (int i = 0; i < pf.n_ops; i++) {
       switch (pf.ops[i]) {

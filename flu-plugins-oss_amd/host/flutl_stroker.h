@@ -42,6 +42,12 @@ int flutl_stroke_to_polygon (const cairo_path_t *path, const cairo_matrix_t *ctm
     double line_width, double miter_limit, cairo_line_join_t line_join, double tolerance,
     const int target[4], FlutlPolygon *polygon);
 
+/* cairo_fill (path in device coordinates, default fill rule: winding) as a polygon; target,
+ * tolerance and polygon->box as above.  FLUTL_STROKER_RECTILINEAR: Cairo fills such a path
+ * as boxes. */
+int flutl_fill_to_polygon (const cairo_path_t *path, double tolerance, const int target[4],
+    FlutlPolygon *polygon);
+
 /* The pixel box Cairo converts the polygon in (before surface and clip cut it):
  * extents rounded out.  0 for an empty polygon. */
 int flutl_polygon_box (const FlutlPolygon *pg, int box[4]);

@@ -3308,6 +3308,8 @@ timing_report (GstTTMLRender *render)
   flutl_recorder_stroke_split (&we, &wd, &wc);
   uint64_t composed_chk = 0;
   const uint64_t composed_n = flutl_recorder_composed_paths (&composed_chk);   /* (process-wide) */
+  uint64_t by_cairo = 0, dev_fills = 0;
+  flutl_recorder_raster_stats (&by_cairo, &dev_fills);                         /* (process-wide) */
   pipeline_drain (render);
   if (priv->ctx) {
     flutl_ctx_sync (priv->ctx);
@@ -3319,7 +3321,7 @@ timing_report (GstTTMLRender *render)
   }
   g_printerr ("ttmlrender-hip timing: device=%d buffers=%u record_us=%.1f device_us=%.1f "
       "span_us=%" G_GINT64_FORMAT " drained_us=%" G_GINT64_FORMAT " delta_bytes=%.0f "
-      "deferred=%u resolve_wait_us=%.1f atlas_upload_us=%.1f build_us=%.1f layout_us=%.1f region_hits=%u region_misses=%u strokes=%u stroke_us=%.0f stroke_queued_us=%.0f pure_wait_us=%.0f submit_us=%.1f push_block_us=%.1f runs_merged=%u runs_clashed=%u path_us=%.0f extents_us=%.0f miss_us=%.1f recoloured=%u worker_extents_us=%.0f worker_draw_us=%.0f worker_crop_us=%.0f polygons=%u polygon_edges=%" G_GUINT64_FORMAT " polygons_sequential=%u composed_paths=%" G_GUINT64_FORMAT " composed_checked=%" G_GUINT64_FORMAT " t_first_us=%" G_GINT64_FORMAT " t_end_us=%" G_GINT64_FORMAT "\n",
+      "deferred=%u resolve_wait_us=%.1f atlas_upload_us=%.1f build_us=%.1f layout_us=%.1f region_hits=%u region_misses=%u strokes=%u stroke_us=%.0f stroke_queued_us=%.0f pure_wait_us=%.0f submit_us=%.1f push_block_us=%.1f runs_merged=%u runs_clashed=%u path_us=%.0f extents_us=%.0f miss_us=%.1f recoloured=%u worker_extents_us=%.0f worker_draw_us=%.0f worker_crop_us=%.0f polygons=%u polygon_edges=%" G_GUINT64_FORMAT " polygons_sequential=%u composed_paths=%" G_GUINT64_FORMAT " composed_checked=%" G_GUINT64_FORMAT " masks_by_cairo=%" G_GUINT64_FORMAT " device_fills=%" G_GUINT64_FORMAT " t_first_us=%" G_GINT64_FORMAT " t_end_us=%" G_GINT64_FORMAT "\n",
       priv->device, priv->n_timed, (double) priv->t_record / MAX (priv->n_timed - 1, 1),
       (double) (priv->t_device + priv->t_submit) / MAX (priv->n_timed - 1, 1),
       priv->t_last_return - priv->t_first_return,
@@ -3337,7 +3339,7 @@ timing_report (GstTTMLRender *render)
       (double) priv->t_miss / MAX (priv->n_timed - 1, 1), priv->region_recoloured,
       sj ? (double) we / sj : 0.0, sj ? (double) wd / sj : 0.0, sj ? (double) wc / sj : 0.0,
       priv->n_polygons, priv->polygon_edges, priv->ctx ? flutl_ctx_scan_fallbacks (priv->ctx) : 0,
-      (guint64) composed_n, (guint64) composed_chk,
+      (guint64) composed_n, (guint64) composed_chk, (guint64) by_cairo, (guint64) dev_fills,
       /* (CLOCK_MONOTONIC: comparable across the elements and processes of one box) */
       priv->t_first_return, MAX (t_drained, priv->t_last_return));
   priv->t_push_block = 0;

@@ -7,7 +7,9 @@
  * through stroker + oracle/flutl_tor_oracle.c, byte for byte.
  *     stroke_check [n_paths] [seed] [mode]
  * mode: 0 random paths inside the surface, 1 crossing a clip box, 2 lines of text
- * (DejaVu glyph outlines, what the element strokes), 3 text crossing a clip box
+ * (DejaVu glyph outlines, what the element strokes), 3 text crossing a clip box;
+ * + 4: the same paths FILLED (cairo_fill against flutl_fill_to_polygon: what the reference
+ * does with anamorphic glyphs, gstttmlrender.c:1109-1118, and Pango with its line-break arrow)
  */
 #include <cairo.h>
 #include <math.h>
@@ -41,7 +43,8 @@ main (int argc, char **argv)
 {
   const int n_paths = argc > 1 ? atoi (argv[1]) : 2000;
   rng_state = argc > 2 ? strtoull (argv[2], NULL, 0) : 1;
-  const int mode = argc > 3 ? atoi (argv[3]) : 0;
+  const int fill = argc > 3 ? (atoi (argv[3]) & 4) != 0 : 0;
+  const int mode = argc > 3 ? atoi (argv[3]) & 3 : 0;
   const int text = mode >= 2;
   const int W = text ? 1000 : 200, H = text ? 320 : 150;
   cairo_surface_t *s = cairo_image_surface_create (CAIRO_FORMAT_A8, W, H);
@@ -148,14 +151,18 @@ main (int argc, char **argv)
     cairo_set_line_width (cr, lw);
     cairo_set_line_join (cr, join);
     cairo_set_miter_limit (cr, miter);
-    cairo_stroke (cr);
+    if (fill)
+      cairo_fill (cr);
+    else
+      cairo_stroke (cr);
     cairo_destroy (cr);
     cairo_surface_flush (s);
     const uint8_t *ref = cairo_image_surface_get_data (s);
 
     FlutlPolygon pg;
     flutl_polygon_init (&pg);
-    int rc = flutl_stroke_to_polygon (path, &ctm, lw, miter, join, 0.1, lim, &pg);
+    int rc = fill ? flutl_fill_to_polygon (path, 0.1, lim, &pg)
+                  : flutl_stroke_to_polygon (path, &ctm, lw, miter, join, 0.1, lim, &pg);
     cairo_path_destroy (path);
     if (rc != FLUTL_STROKER_OK) {
       skipped++;

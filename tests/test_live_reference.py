@@ -140,16 +140,19 @@ CAIRO_DEV = os.path.exists(os.path.join(gstenv.CONDA, "include", "cairo", "cairo
 
 @pytest.mark.skipif(not CAIRO_DEV, reason="cairo development files not present")
 @pytest.mark.parametrize("mode,what", [(0, "random paths"), (1, "random paths cut by a clip box"),
-                                       (2, "lines of text"), (3, "text cut by a clip box")])
+                                       (2, "lines of text"), (3, "text cut by a clip box"),
+                                       (4, "random paths, filled"), (5, "filled, cut by a clip box"),
+                                       (6, "lines of text, filled"), (7, "filled text cut by a clip box")])
 def test_stroker_and_scan_restatement_are_cairo_stroke(mode, what):
     """The product's host-side stroker (host/flutl_stroker.c: path -> the polygon Cairo
-    makes of a stroke) and the scan converter's restatement (oracle/flutl_tor_oracle.c)
-    against the REAL cairo_stroke of this image, byte for byte: oracle/stroke_check.c
-    (560 000 strokes when it was written; a few hundred per mode here)."""
+    makes of a stroke; modes 4-7: of a FILL, flutl_fill_to_polygon) and the scan converter's
+    restatement (oracle/flutl_tor_oracle.c) against the REAL cairo_stroke / cairo_fill of this
+    image, byte for byte: oracle/stroke_check.c (560 000 strokes and 172 000 fills when they
+    were written; a few hundred per mode here)."""
     import subprocess
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "_build/stroke_check"],
                           stdout=subprocess.DEVNULL)
-    n = 1500 if mode < 2 else 250
+    n = 1500 if (mode & 3) < 2 else 250
     r = subprocess.run([os.path.join(ROOT, "oracle", "_build", "stroke_check"), str(n),
                         str(4242 + mode), str(mode)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and f"{n} paths, 0 differ" in r.stdout, r.stdout[-1500:]
