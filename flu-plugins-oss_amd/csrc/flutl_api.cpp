@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
@@ -33,7 +35,7 @@ extern "C" int flutl_launch_scan_counted (void *stream_, const int32_t *edges_de
 extern "C" size_t flutl_scan_zero_bytes (void);     // (the scratch's leading words that are zero between conversions)
 extern "C" int flutl_launch_scan_hosted (void *stream_, const int32_t *edges, int32_t *raw_copy_dev,
     uint32_t n_edges, const int32_t box[4], int even_odd, void *scratch, void *dst, size_t dst_stride,
-    int mode, uint32_t *counters_dev);
+    int mode, uint32_t *counters_dev, const void *carry_src, void *carry_dst, size_t carry_bytes);
 
 struct flutl_list {
   uint32_t width, height;
@@ -96,6 +98,20 @@ struct flutl_ctx {
   uint32_t epoch_cur;           // epoch of the polygons being queued now
   uint32_t epoch_known;         // epochs below this one are known complete
   uint32_t epoch_uses;          // polygons queued in epoch_cur
+  // A staged submission (flutl_frame_stage): its list lies in the slot's page-locked half and
+  // is still to go up -- carried by the next scan conversion's launch (its last workgroup
+  // copies it: no copy operation of its own on the stream, 4.5 us + a gap per cue), or by a
+  // copy when flutl_frame_submit_staged finds it still pending.
+  struct Staged {
+    bool valid, copy_pending;
+    flutl_frame *frame;
+    int slot;
+    size_t rb, pb, ob, copy_bytes;
+    uint32_t n_regions, n_prims, n_order, y0, y1, now[4];
+  } staged;
+  // FLUTL_API_TIMING=1: where flutl_frame_submit's time goes on the calling thread (ns)
+  bool api_timing;
+  uint64_t t_sub[6], n_sub;
 };
 
 struct flutl_frame {
@@ -317,6 +333,10 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
   memset (c->edge_epoch, 0, sizeof c->edge_epoch);
   c->epoch_cur = c->epoch_known = 1;
   c->epoch_uses = 0;
+  memset (&c->staged, 0, sizeof c->staged);
+  c->api_timing = getenv ("FLUTL_API_TIMING") != nullptr;
+  memset (c->t_sub, 0, sizeof c->t_sub);
+  c->n_sub = 0;
   for (auto &e : c->epoch_done)
     e = nullptr;
   {
@@ -376,6 +396,11 @@ extern "C" void flutl_ctx_destroy (flutl_ctx *c)
 {
   if (!c)
     return;
+  if (c->api_timing && c->n_sub)
+    fprintf (stderr, "flutl api timing: %llu submits; per submit us: validate+order %.1f slot-wait %.1f "
+        "list-copy %.1f memcpyAsync %.1f launch %.1f events %.1f\n", (unsigned long long) c->n_sub,
+        c->t_sub[0] / 1e3 / c->n_sub, c->t_sub[1] / 1e3 / c->n_sub, c->t_sub[2] / 1e3 / c->n_sub,
+        c->t_sub[3] / 1e3 / c->n_sub, c->t_sub[4] / 1e3 / c->n_sub, c->t_sub[5] / 1e3 / c->n_sub);
   (void) hipSetDevice (c->device);
   (void) hipStreamSynchronize (c->stream);
   if (c->atlas)
@@ -702,9 +727,15 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
       // window are the next window's first pixels, written behind it in stream order)
       const int pad = x == 0 ? 8 : (x + ww == w ? 32 : 0);
       // (the first window's prepare kernel makes the device copy; the others read that)
+      // (a staged frame's list rides up with the first window's launch)
+      const bool carry = x == 0 && c->staged.valid && c->staged.copy_pending;
+      list_slot &csl = c->slots[c->staged.slot];
       rc = flutl_launch_scan_hosted (ms, x == 0 ? edges_src : edges_dev, x == 0 ? raw_copy : nullptr,
           n_edges, wbox, even_odd, c->scan, c->atlas + off + 4 + x, (size_t) w + 4, 0 | pad | 16,
-          c->scan_counters);
+          c->scan_counters, carry ? csl.host : nullptr, carry ? csl.dev : nullptr,
+          carry ? c->staged.copy_bytes : 0);
+      if (carry && rc == FLUTL_OK)
+        c->staged.copy_pending = false;
     }
   }
   if (n_edges && c->edge_arena && edges_src != edges_dev) {
@@ -1242,7 +1273,15 @@ extern "C" uint64_t flutl_ctx_delta_bytes (flutl_ctx *c)
   return n * flutl_delta_segment_bytes ();
 }
 
-extern "C" int flutl_frame_submit (flutl_ctx *c, flutl_frame *f,
+static inline uint64_t now_ns (void)
+{
+  struct timespec ts;
+  clock_gettime (CLOCK_MONOTONIC, &ts);
+  return (uint64_t) ts.tv_sec * 1000000000ull + (uint64_t) ts.tv_nsec;
+}
+#define SUB_MARK(k) do { if (c->api_timing) { const uint64_t n_ = now_ns (); c->t_sub[k] += n_ - t_mark; t_mark = n_; } } while (0)
+
+extern "C" int flutl_frame_stage (flutl_ctx *c, flutl_frame *f,
     const flutl_region *regions, uint32_t n_regions, const flutl_prim *prims,
     uint32_t n_prims)
 {
@@ -1250,9 +1289,13 @@ extern "C" int flutl_frame_submit (flutl_ctx *c, flutl_frame *f,
     return FLUTL_EINVAL;
   if (f->error)
     return f->error;
+  c->staged.valid = false;
   const uint32_t width = f->width, height = f->height;
-  int rc = flutl_list_validate (width, height, regions, n_regions, prims, n_prims,
-      c->atlas_used + kAtlasSlack);
+  uint64_t t_mark = c->api_timing ? now_ns () : 0;
+  // (masks the list names that are still to be made -- the outline polygons of this very
+  // frame, queued between stage and submit -- have their space in the atlas already: the
+  // caller keeps offsets in step with its host-side atlas; what is checked is the layout)
+  int rc = flutl_list_validate (width, height, regions, n_regions, prims, n_prims, 0x7fffffffu);
   if (rc)
     return rc;
   (void) hipSetDevice (c->device);
@@ -1269,13 +1312,16 @@ extern "C" int flutl_frame_submit (flutl_ctx *c, flutl_frame *f,
   if (now[2] <= now[0] || now[3] <= now[1])
     now[0] = now[1] = now[2] = now[3] = 0;
   // a list slot: the oldest submission must have finished with it
-  list_slot &sl = c->slots[c->next_slot];
+  const int slot = (int) c->next_slot;
+  list_slot &sl = c->slots[slot];
   c->next_slot = (c->next_slot + 1) % kListSlots;
+  SUB_MARK (0);
   if (sl.busy) {
     if (!hip_ok (hipEventSynchronize (sl.done)))
       return FLUTL_ENODEV;
     sl.busy = false;
   }
+  SUB_MARK (1);
   const size_t rb = ((size_t) n_regions * sizeof (flutl_region) + 31) & ~(size_t) 31;
   const size_t pb = ((size_t) n_prims * sizeof (flutl_prim) + 31) & ~(size_t) 31;
   const size_t ob = (((size_t) height + 15) / 16 * sizeof (uint16_t) + 31) & ~(size_t) 31;   // row order
@@ -1325,6 +1371,41 @@ extern "C" int flutl_frame_submit (flutl_ctx *c, flutl_frame *f,
   // their supertile rows, heaviest first (flutl_launch_frame_ordered)
   const uint32_t n_order = flutl_row_order (width, height, regions, n_regions, prims, n_prims,
       y0, y1, reinterpret_cast<uint16_t *> (static_cast<uint8_t *> (sl.host) + rb + pb));
+  SUB_MARK (2);
+  c->staged.frame = f;
+  c->staged.slot = slot;
+  c->staged.rb = rb;
+  c->staged.pb = pb;
+  c->staged.ob = ob;
+  c->staged.copy_bytes = rb + pb + (n_order ? ob : 0);
+  c->staged.copy_pending = c->staged.copy_bytes != 0;
+  c->staged.n_regions = n_regions;
+  c->staged.n_prims = n_prims;
+  c->staged.n_order = n_order;
+  c->staged.y0 = y0;
+  c->staged.y1 = y1;
+  memcpy (c->staged.now, now, sizeof now);
+  c->staged.valid = true;
+  return FLUTL_OK;
+}
+
+extern "C" int flutl_frame_submit_staged (flutl_ctx *c, flutl_frame *f)
+{
+  if (!c || !f || !c->staged.valid || c->staged.frame != f)
+    return FLUTL_EINVAL;
+  c->staged.valid = false;
+  (void) hipSetDevice (c->device);
+  uint64_t t_mark = c->api_timing ? now_ns () : 0;
+  const uint32_t width = f->width, height = f->height;
+  list_slot &sl = c->slots[c->staged.slot];
+  const size_t rb = c->staged.rb, pb = c->staged.pb;
+  const uint32_t n_order = c->staged.n_order;
+  // (now that the frame's atlas entries have been made: every primitive reads inside the atlas)
+  int rc = flutl_list_validate (width, height, static_cast<const flutl_region *> (sl.host),
+      c->staged.n_regions, reinterpret_cast<const flutl_prim *> (static_cast<uint8_t *> (sl.host) + rb),
+      c->staged.n_prims, c->atlas_used + kAtlasSlack);
+  if (rc)
+    return rc;
   // scratch frame of the context (here: where translucent groups park pixels)
   const size_t need = (size_t) width * 4 * height;
   if (need > c->frame_cap) {
@@ -1338,12 +1419,14 @@ extern "C" int flutl_frame_submit (flutl_ctx *c, flutl_frame *f,
     c->frame_cap = need;
   }
   bool ok = true;
-  if (rb + pb + (n_order ? ob : 0))
-    // (the list itself does not depend on the outlines: in front of the wait for them)
-    ok = hip_ok (hipMemcpyAsync (sl.dev, sl.host, rb + pb + (n_order ? ob : 0),
-        hipMemcpyHostToDevice, c->stream));
+  // (the list: up with a scan conversion's launch since it was staged, or by a copy now)
+  if (c->staged.copy_pending) {
+    ok = hip_ok (hipMemcpyAsync (sl.dev, sl.host, c->staged.copy_bytes, hipMemcpyHostToDevice, c->stream));
+    c->staged.copy_pending = false;
+  }
   if (!ok)
     return FLUTL_ENODEV;
+  SUB_MARK (3);
   const flutl_region *rd = static_cast<const flutl_region *> (sl.dev);
   const flutl_prim *pd = reinterpret_cast<const flutl_prim *> (static_cast<uint8_t *> (sl.dev) + rb);
   if (!c->delta_segments) {
@@ -1355,11 +1438,15 @@ extern "C" int flutl_frame_submit (flutl_ctx *c, flutl_frame *f,
   // into the twin and the host block (flutl_launch_frame_delta)
   if (rc == FLUTL_OK && n_order)
     rc = flutl_launch_frame_delta (c->stream, width, height, f->twin, f->host_dev, c->frame,
-        (size_t) width * 4, rd, n_regions, pd, c->atlas, y0, y1,
+        (size_t) width * 4, rd, c->staged.n_regions, pd, c->atlas, c->staged.y0, c->staged.y1,
         reinterpret_cast<const uint16_t *> (static_cast<uint8_t *> (sl.dev) + rb + pb),
         c->delta_segments);
+  SUB_MARK (4);
   ok = rc == FLUTL_OK && hip_ok (hipEventRecord (sl.done, c->stream)) &&
       hip_ok (hipEventRecord (f->done, c->stream));
+  SUB_MARK (5);
+  if (c->api_timing)
+    c->n_sub++;
   sl.busy = true;
   f->pending = true;
   if (!ok) {
@@ -1368,6 +1455,20 @@ extern "C" int flutl_frame_submit (flutl_ctx *c, flutl_frame *f,
     f->error = rc ? rc : FLUTL_ENODEV;
     return f->error;
   }
-  memcpy (f->ext, now, sizeof now);
+  memcpy (f->ext, c->staged.now, sizeof c->staged.now);
   return FLUTL_OK;
+}
+
+extern "C" int flutl_frame_submit (flutl_ctx *c, flutl_frame *f,
+    const flutl_region *regions, uint32_t n_regions, const flutl_prim *prims,
+    uint32_t n_prims)
+{
+  if (!c || !f || f->device != c->device)
+    return FLUTL_EINVAL;
+  // (everything the list names is in the atlas by now: checked against what is there)
+  int rc = flutl_list_validate (f->width, f->height, regions, n_regions, prims, n_prims,
+      c->atlas_used + kAtlasSlack);
+  if (rc == FLUTL_OK)
+    rc = flutl_frame_stage (c, f, regions, n_regions, prims, n_prims);
+  return rc == FLUTL_OK ? flutl_frame_submit_staged (c, f) : rc;
 }

@@ -1859,8 +1859,13 @@ scan_rows_kernel (ScanEdge *edges, int2 *spans,
     uint32_t n_edges, int xmin, int ymin, int xmax, int ymax, int even_odd,
     uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ status, int lds_bytes,
     uint32_t *__restrict__ debug, int pad_zero, int with_sequential, SeqArgs seq,
-    const int32_t *__restrict__ raw_edges, int32_t *__restrict__ raw_copy)
+    const int32_t *__restrict__ raw_edges, int32_t *__restrict__ raw_copy,
+    const uint32_t *__restrict__ carry_src, uint32_t *__restrict__ carry_dst, uint32_t carry_words)
 {
+  // (what rides along: see flutl_launch_scan_hosted.  The last row of a box is light.)
+  if (carry_words && blockIdx.x == gridDim.x - 1)
+    for (uint32_t i = threadIdx.x; i < carry_words; i += kThreads)
+      carry_dst[i] = carry_src[i];
   // The edges are prepared here, by the first workgroups: workgroup b takes the slices of
   // kThreads edges b, b + grid, ...; every workgroup then waits until all slices are done.
   // Workgroups are handed out in the order of their numbers, so the ones that are waited
@@ -1990,7 +1995,7 @@ extern "C" int flutl_launch_scan (void *stream_, const int32_t *edges_dev, uint3
 
 extern "C" int flutl_launch_scan_hosted (void *stream_, const int32_t *edges, int32_t *raw_copy_dev,
     uint32_t n_edges, const int32_t box[4], int even_odd, void *scratch, void *dst, size_t dst_stride,
-    int mode, uint32_t *counters_dev);
+    int mode, uint32_t *counters_dev, const void *carry_src, void *carry_dst, size_t carry_bytes);
 
 // (library internal: counters_dev[0] counts the polygons the sequential kernel converted)
 extern "C" int flutl_launch_scan_counted (void *stream_, const int32_t *edges_dev, uint32_t n_edges,
@@ -1998,14 +2003,17 @@ extern "C" int flutl_launch_scan_counted (void *stream_, const int32_t *edges_de
     uint32_t *counters_dev)
 {
   return flutl_launch_scan_hosted (stream_, edges_dev, nullptr, n_edges, box, even_odd, scratch, dst,
-      dst_stride, mode, counters_dev);
+      dst_stride, mode, counters_dev, nullptr, nullptr, 0);
 }
 
 // (library internal: `edges` may be page-locked host memory the device can read; then
 // raw_copy_dev, n_edges x 7 int32 of device memory, is where the sequential sweep finds them)
+// (carry_*: a small block of page-locked host memory the row kernel's last workgroup copies
+// into device memory before its row -- a frame's display list going up with its outline's
+// conversion instead of as a copy operation of its own, flutl_frame_stage)
 extern "C" int flutl_launch_scan_hosted (void *stream_, const int32_t *edges_dev, int32_t *raw_copy_dev,
     uint32_t n_edges, const int32_t box[4], int even_odd, void *scratch, void *dst, size_t dst_stride,
-    int mode, uint32_t *counters_dev)
+    int mode, uint32_t *counters_dev, const void *carry_src, void *carry_dst, size_t carry_bytes)
 {
   hipStream_t stream = static_cast<hipStream_t> (stream_);
   const int xmin = box[0], ymin = box[1], xmax = box[2], ymax = box[3];
@@ -2064,7 +2072,9 @@ extern "C" int flutl_launch_scan_hosted (void *stream_, const int32_t *edges_dev
       return FLUTL_ERANGE;
     scan_rows_kernel<<<height, kThreads, 0, stream>>> (prepared, spans, n_edges, xmin, ymin,
         xmax, ymax, even_odd, static_cast<uint8_t *> (dst), dst_stride, status, (int) lds,
-        g_scan_debug, pad_zero, mode == 0, seq, separate ? nullptr : edges_dev, raw_copy_dev);
+        g_scan_debug, pad_zero, mode == 0, seq, separate ? nullptr : edges_dev, raw_copy_dev,
+        static_cast<const uint32_t *> (carry_src), static_cast<uint32_t *> (carry_dst),
+        (uint32_t) ((carry_bytes + 3) / 4));
   } else {
     scan_sequential_kernel<<<1, 64, 0, stream>>> (edges_dev, n_edges, xmin, ymin, xmax, ymax,
         even_odd, static_cast<uint8_t *> (dst), dst_stride, seq.sedges, seq.y_buckets, seq.cells);

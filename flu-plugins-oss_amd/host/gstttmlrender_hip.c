@@ -85,7 +85,7 @@ enum
  * FLUTL_FULL_D2H=1 restores synchronous whole-frame copies into writable memory. */
 #define MAX_IN_FLIGHT 16           /* buffers handed out but not yet queued on the device */
 #define DEVICE_STROKES_AHEAD 6     /* ... with outlines made on the device (run_ahead) */
-#define DEVICE_STROKES_AHEAD_MAX 12
+#define DEVICE_STROKES_AHEAD_MAX 16
 #define VIDEO_CUES_AHEAD 64        /* fused over-video: cues the TTML side may be ahead of the video */
 #define POOL_MAX_FREE 24
 #define POOL_BUDGET_BYTES ((gsize) 640 << 20)   /* page-locked frames kept per element (+ twins in HBM) */
@@ -2779,15 +2779,19 @@ finisher_main (gpointer data)
       priv->t_resolve += t1 - t0;
       t0 = t1;
     }
-    rc = flush_atlas (render) ? FLUTL_OK : FLUTL_ENODEV;
+    /* the list is staged first: it goes up to the device with the conversion of the frame's
+     * first outline (flush_atlas), not as a copy operation of its own */
+    rc = flutl_frame_stage (priv->ctx, job->slot->frame, job->regions, job->n_rg, job->prims,
+        job->n_pr);
+    if (rc == FLUTL_OK)
+      rc = flush_atlas (render) ? FLUTL_OK : FLUTL_ENODEV;
     if (priv->timing) {
       gint64 t1 = g_get_monotonic_time ();
       priv->t_flush += t1 - t0;
       t0 = t1;
     }
     if (rc == FLUTL_OK)
-      rc = flutl_frame_submit (priv->ctx, job->slot->frame, job->regions, job->n_rg,
-          job->prims, job->n_pr);
+      rc = flutl_frame_submit_staged (priv->ctx, job->slot->frame);
     if (priv->timing)
       priv->t_submit += g_get_monotonic_time () - t0;
     if (rc != FLUTL_OK) {
@@ -2860,8 +2864,9 @@ run_ahead (GstTTMLRenderPrivate *priv, gint width, gint height)
    * (Outlines by Cairo on the workers, FLUTL_HOST_STROKES: the old depth.) */
   if (priv->host_strokes)
     return by_size;
-  /* ... and deeper as the stream goes on (a long one runs 15-20 % faster at 12 than at 6):
-   * one more frame every 64 buffers */
+  /* ... and deeper as the stream goes on (a long one runs 15-20 % faster at 12 than at 6, and --
+   * round 4, with the device at 66 us per cue -- 22 % faster at 16 than at 12: 15.0 k against
+   * 12.3 k frames/s, tools/r4_typical_once.sh): one more frame every 64 buffers */
   return MIN (by_size, MIN (DEVICE_STROKES_AHEAD + priv->n_pushed / 64, DEVICE_STROKES_AHEAD_MAX));
 }
 

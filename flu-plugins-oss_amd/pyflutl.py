@@ -60,7 +60,7 @@ EXPORTS = [
     "flutl_frame_device", "flutl_frame_submit", "flutl_frame_wait", "flutl_ctx_delta_bytes",
     "flutl_atlas_put_polygon", "flutl_polygon_entry_bytes", "flutl_ctx_scan_fallbacks",
     "flutl_scan_scratch_bytes", "flutl_scan_zero_bytes", "flutl_ctx_edge_block_acquire",
-    "flutl_ctx_edge_block_release", "flutl_frame_mark_written", "flutl_launch_scan", "flutl_scan_status",
+    "flutl_ctx_edge_block_release", "flutl_frame_mark_written", "flutl_frame_stage", "flutl_frame_submit_staged", "flutl_launch_scan", "flutl_scan_status",
 ]
 
 
@@ -124,6 +124,8 @@ def lib():
         L.flutl_ctx_edge_block_acquire.argtypes = [vp, sz, ctypes.POINTER(vp)]
         L.flutl_ctx_edge_block_release.argtypes = [vp, vp]
         L.flutl_ctx_edge_block_release.restype = None
+        L.flutl_frame_stage.argtypes = [vp, vp, vp, u32, vp, u32]
+        L.flutl_frame_submit_staged.argtypes = [vp, vp]
         L.flutl_frame_mark_written.argtypes = [vp]
         L.flutl_frame_mark_written.restype = None
         L.flutl_scan_zero_bytes.argtypes = []
@@ -508,6 +510,17 @@ class Frame:
         prims = np.ascontiguousarray(prims, PRIM_DTYPE)
         _check(lib().flutl_frame_submit(self.ctx._h, self._h, _np_ptr(regions), len(regions),
                                         _np_ptr(prims), len(prims)), "flutl_frame_submit")
+
+    def stage(self, regions, prims):
+        """submit in two steps: stage, then the caller makes the frame's atlas entries
+        (atlas_put_polygon ...), then submit_staged"""
+        regions = np.ascontiguousarray(regions, REGION_DTYPE)
+        prims = np.ascontiguousarray(prims, PRIM_DTYPE)
+        _check(lib().flutl_frame_stage(self.ctx._h, self._h, _np_ptr(regions), len(regions),
+                                       _np_ptr(prims), len(prims)), "flutl_frame_stage")
+
+    def submit_staged(self):
+        _check(lib().flutl_frame_submit_staged(self.ctx._h, self._h), "flutl_frame_submit_staged")
 
     def mark_written(self):
         lib().flutl_frame_mark_written(self._h)

@@ -445,6 +445,17 @@ const void *flutl_frame_device (const flutl_frame *frame);
 int   flutl_frame_submit (flutl_ctx *ctx, flutl_frame *frame,
     const flutl_region *regions, uint32_t n_regions,
     const flutl_prim *prims, uint32_t n_prims);
+/* flutl_frame_submit in two steps, for a frame that comes with NEW outlines: stage (the
+ * list is validated, copied to page-locked memory, its rows ordered), then the caller makes
+ * the frame's atlas entries (flutl_atlas_put_polygon ...), then submit_staged queues the
+ * composite.  The staged list goes up to the device with the first scan conversion launched
+ * in between (the conversion's kernel copies it) instead of as a copy operation of its own:
+ * one stream operation and its gap less per cue of a stream with new outlined text.  One
+ * staged frame per context at a time. */
+int   flutl_frame_stage (flutl_ctx *ctx, flutl_frame *frame,
+    const flutl_region *regions, uint32_t n_regions,
+    const flutl_prim *prims, uint32_t n_prims);
+int   flutl_frame_submit_staged (flutl_ctx *ctx, flutl_frame *frame);
 int   flutl_frame_wait (flutl_frame *frame);
 /* Somebody has WRITTEN into the frame's host block (a downstream element that works in
  * place on writable memory, FLUTL_WRITABLE): block and twin no longer hold the same pixels.

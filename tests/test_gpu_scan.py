@@ -369,3 +369,59 @@ def test_edges_prepared_inside_the_row_kernel(gpu):
         assert np.array_equal(got, cov), (i, kind)
         done += 1
     assert done >= 30
+
+
+def test_a_staged_frames_list_goes_up_with_its_outlines_conversion(gpu):
+    """flutl_frame_stage / flutl_frame_submit_staged: the frame's list is staged, THEN its
+    outline's polygon is converted into the atlas (the conversion's kernel carries the list up
+    to the device), then the composite is queued -- the same frame as with the polygon made
+    first and a plain submit; also with no conversion in between (the list goes up by a copy),
+    and twice in a row."""
+    polys = [p for p in _polygons() if p[1] == 2][:3]
+
+    def frame_of(ctx, fr, off, box, cov, colour):
+        h, w = cov.shape
+        R = np.zeros(1, F.REGION_DTYPE)
+        R["x0"], R["y0"], R["x1"], R["y1"], R["first"], R["count"] = box[0], box[1], box[2], box[3], 0, 1
+        P = np.zeros(1, F.PRIM_DTYPE)
+        P["op"], P["rule"] = F.OP_MASK, F.RULE_LERP
+        P["cx0"], P["cy0"], P["cx1"], P["cy1"] = box[0], box[1], box[2], box[3]
+        P["color"] = colour
+        P["a"], P["b"], P["c"], P["d"] = off + 4, w + 4, box[0], box[1]
+        return R, P
+
+    W = max(p[2][2] for p in polys) + 8
+    H = max(p[2][3] for p in polys) + 8
+    got, want = [], []
+    with F.Context(0) as ctx:
+        fr = ctx.frame(W, H)
+        try:
+            for k, (i, kind, box, eo, edges, cov) in enumerate(polys * 2):
+                # the entry's offset is known before it is made: the next free one
+                off = (ctx.atlas_size() - F.ATLAS_SLACK + 15) & ~15
+                R, P = frame_of(ctx, fr, off, box, cov, 0xFF000000 | (0x40 * (k + 1)))
+                fr.stage(R, P)
+                assert ctx.atlas_put_polygon(edges, box, eo) == off
+                fr.submit_staged()
+                fr.wait()
+                got.append(fr.host().copy())
+            # no conversion between stage and submit: an entry that exists already
+            fr.stage(R, P)
+            fr.submit_staged()
+            fr.wait()
+            got.append(fr.host().copy())
+        finally:
+            fr.close()
+    with F.Context(0) as ctx:
+        fr = ctx.frame(W, H)
+        try:
+            for k, (i, kind, box, eo, edges, cov) in enumerate(polys * 2):
+                off = ctx.atlas_put_polygon(edges, box, eo)
+                R, P = frame_of(ctx, fr, off, box, cov, 0xFF000000 | (0x40 * (k + 1)))
+                fr.submit(R, P)
+                fr.wait()
+                want.append(fr.host().copy())
+            want.append(want[-1])
+        finally:
+            fr.close()
+    assert len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want))

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 for n in $exps; do
   so=/tmp/libflutl_exp$n.so
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -DFLUTL_EXP=$n $FLUTL_CFLAGS \
-    -shared -o $so $SRC -x hip $ROOT/flu-plugins-oss_amd/csrc/flutl_api.cpp
+    -shared -o $so $SRC $ROOT/flu-plugins-oss_amd/csrc/flutl_scan.hip -x hip $ROOT/flu-plugins-oss_amd/csrc/flutl_api.cpp
   export FLUTL_LIB=$so
   OUT=$ROOT/gpurun_out/mixq_$n
   rm -rf "$OUT"; mkdir -p "$OUT"
