@@ -1175,7 +1175,19 @@ extern "C" int flutl_blend_over_host (flutl_ctx *c, uint32_t width, uint32_t hei
 
 // ---- pooled output frames, completed asynchronously ---------------------------
 
+extern "C" int flutl_frame_create_quiet (flutl_ctx *c, uint32_t width, uint32_t height, int quiet,
+    flutl_frame **out);
+
 extern "C" int flutl_frame_create (flutl_ctx *c, uint32_t width, uint32_t height,
+    flutl_frame **out)
+{
+  return flutl_frame_create_quiet (c, width, height, 0, out);
+}
+
+// (quiet: the host block is cleared by the calling thread, not by the device over PCIe in
+// stream order -- a frame made in the background while the stream is busy with cues must
+// not put 1.3 ms of clearing in front of them; the twin's clearing is microseconds)
+extern "C" int flutl_frame_create_quiet (flutl_ctx *c, uint32_t width, uint32_t height, int quiet,
     flutl_frame **out)
 {
   if (!c || !out || width == 0 || height == 0 || width > 32767 || height > 32767)
@@ -1205,8 +1217,10 @@ extern "C" int flutl_frame_create (flutl_ctx *c, uint32_t width, uint32_t height
   // the transparent frame, in both copies: cleared by the device in stream order
   // (the host block over PCIe: no 33 MB memset on the caller's thread, and no
   // wait -- whatever is submitted into the frame comes later on the same stream)
+  if (ok && quiet)
+    memset (f->host, 0, bytes);
   ok = ok && hip_ok (hipMemsetAsync (f->twin, 0, bytes, c->stream)) &&
-      hip_ok (hipMemsetAsync (f->host_dev, 0, bytes, c->stream)) &&
+      (quiet || hip_ok (hipMemsetAsync (f->host_dev, 0, bytes, c->stream))) &&
       hip_ok (hipEventRecord (f->done, c->stream));
   if (ok)
     f->pending = true;

@@ -329,11 +329,11 @@ flutl_allocator_get (void)
 }
 
 static FrameSlot *
-frame_slot_new (flutl_ctx *ctx, gint width, gint height, gboolean async)
+frame_slot_new_ex (flutl_ctx *ctx, gint width, gint height, gboolean async, gboolean quiet)
 {
   FrameSlot *slot = g_new0 (FrameSlot, 1);
   if (async) {
-    if (flutl_frame_create (ctx, width, height, &slot->frame) != FLUTL_OK) {
+    if (flutl_frame_create_quiet (ctx, width, height, quiet, &slot->frame) != FLUTL_OK) {
       g_free (slot);
       return NULL;
     }
@@ -344,6 +344,12 @@ frame_slot_new (flutl_ctx *ctx, gint width, gint height, gboolean async)
     }
   }
   return slot;
+}
+
+static FrameSlot *
+frame_slot_new (flutl_ctx *ctx, gint width, gint height, gboolean async)
+{
+  return frame_slot_new_ex (ctx, width, height, async, FALSE);
 }
 
 /* (pool lock held) frames of another size go */
@@ -394,7 +400,8 @@ frame_pool_prefill (FramePool *p, flutl_ctx *ctx, gint width, gint height, guint
   frame_pool_set_size (p, size);
   g_mutex_unlock (&p->lock);
   for (guint i = have; i < n; i++) {
-    FrameSlot *slot = frame_slot_new (ctx, width, height, TRUE);
+    /* (cleared by this thread, at start-up: not by the device in front of the first cues) */
+    FrameSlot *slot = frame_slot_new_ex (ctx, width, height, TRUE, TRUE);
     if (!slot)
       break;
     g_mutex_lock (&p->lock);
@@ -2864,10 +2871,19 @@ run_ahead (GstTTMLRenderPrivate *priv, gint width, gint height)
    * (Outlines by Cairo on the workers, FLUTL_HOST_STROKES: the old depth.) */
   if (priv->host_strokes)
     return by_size;
-  /* ... and deeper as the stream goes on (a long one runs 15-20 % faster at 12 than at 6, and --
-   * round 4, with the device at 66 us per cue -- 22 % faster at 16 than at 12: 15.0 k against
-   * 12.3 k frames/s, tools/r4_typical_once.sh): one more frame every 64 buffers */
-  return MIN (by_size, MIN (DEVICE_STROKES_AHEAD + priv->n_pushed / 64, DEVICE_STROKES_AHEAD_MAX));
+  /* ... as deep as the pool has frames for.  Round 4, with the device at 66 us per cue: a
+   * 3 000-cue stream runs 15.1 k frames/s at 16 ahead against 12.3 k at 12 and 11.7 k with the
+   * depth growing by a frame every 64 buffers as in round 3 -- a frame is 14 ms of page-locking
+   * on whoever makes it, and made while the stream runs (on this thread, or on one of their
+   * own: tried) it slows every thread of the process down; so all of them are made when the
+   * stream's first outline shows up (gen_buffer: prefill), cleared by the CPU so that their
+   * clearing is not 1.3 ms of device time each in front of the first cues. */
+  guint have = 0;
+  g_mutex_lock (&priv->pool->lock);
+  if (priv->pool->prefilled_size == (gsize) width * height * 4)
+    have = priv->pool->prefilled_count;
+  g_mutex_unlock (&priv->pool->lock);
+  return MIN (by_size, CLAMP (have > 2 ? have - 2 : 0, DEVICE_STROKES_AHEAD, DEVICE_STROKES_AHEAD_MAX));
 }
 
 /* Hand a recorded frame to the finisher.  The lists are copied: the recorder's
@@ -3094,8 +3110,14 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
        * page-locked memory and as much HBM at the first buffer) */
       const guint first = priv->pool_prefill_set ? priv->pool_prefill
           : MIN (priv->pool_prefill, pool_budget_frames (size));
+      /* (a stream with outlines: all the frames its run-ahead may use, now -- run_ahead) */
+      /* (two more than may be ahead: the one being handed out and one on its way back --
+       * a pool that runs dry makes frames in the middle of the stream, 14 ms each) */
+      const guint deep = priv->host_strokes ? ahead
+          : MIN ((priv->max_ahead ? priv->max_ahead : DEVICE_STROKES_AHEAD_MAX) + 2,
+              MAX (pool_budget_frames (size), 2) - 1);
       frame_pool_prefill (priv->pool, priv->ctx, width, height,
-          n_def && !priv->pool_prefill_set ? MAX (first, ahead) : first);
+          n_def && !priv->pool_prefill_set ? MAX (first, deep) : first);
     }
     FrameSlot *slot = frame_pool_take (priv->pool, priv->ctx, width, height, async);
     int rc = FLUTL_OK;

@@ -60,7 +60,7 @@ EXPORTS = [
     "flutl_frame_device", "flutl_frame_submit", "flutl_frame_wait", "flutl_ctx_delta_bytes",
     "flutl_atlas_put_polygon", "flutl_polygon_entry_bytes", "flutl_ctx_scan_fallbacks",
     "flutl_scan_scratch_bytes", "flutl_scan_zero_bytes", "flutl_ctx_edge_block_acquire",
-    "flutl_ctx_edge_block_release", "flutl_frame_mark_written", "flutl_frame_stage", "flutl_frame_submit_staged", "flutl_launch_scan", "flutl_scan_status",
+    "flutl_ctx_edge_block_release", "flutl_frame_mark_written", "flutl_frame_create_quiet", "flutl_frame_stage", "flutl_frame_submit_staged", "flutl_launch_scan", "flutl_scan_status",
 ]
 
 

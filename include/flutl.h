@@ -439,6 +439,10 @@ int  flutl_blend_over_host (flutl_ctx *ctx, uint32_t width, uint32_t height,
 typedef struct flutl_frame flutl_frame;
 int   flutl_frame_create (flutl_ctx *ctx, uint32_t width, uint32_t height,
     flutl_frame **out);
+/* ... with the host block cleared by the calling thread instead of by the device in stream
+ * order (quiet != 0): for frames made in the background of a running stream. */
+int   flutl_frame_create_quiet (flutl_ctx *ctx, uint32_t width, uint32_t height, int quiet,
+    flutl_frame **out);
 void  flutl_frame_destroy (flutl_frame *frame);
 void *flutl_frame_host (const flutl_frame *frame);
 const void *flutl_frame_device (const flutl_frame *frame);
