@@ -36,8 +36,11 @@
 //     span starts / ends add into per-pixel accumulators (LDS atomics).  Analytically:
 //     bitonic sort of the row's cells, the span-bounding edges add their exact trapezoid
 //     areas.  The row's alpha is a prefix sum over the accumulators.
-// Bound: latency (two thirds of a wave's cycles are waits: profiles/r03_scan_pmc.txt), not
-// HBM: the mask is written once, W * H bytes; DESIGN.md 5.7.
+// Bound: latency (two thirds of a wave's cycles are waits: profiles/r04_scan_summary.json), not
+// HBM: the mask is written once, W * H bytes; DESIGN.md 5.7, and 5.8 for round 4: what the
+// per-row clock readings showed (a thousand lanes taking turns on one LDS word: 4 us of a
+// row), what was tried and lost (every row its own block of edge records; the edges prepared
+// inside the row kernel, kept as FLUTL_SCAN_FUSED), 30 -> 25 us per 4K outline.
 // Pinned: tests/test_gpu_scan.py -- the real cairo_fill / cairo_stroke coverage of
 // committed polygons (tests/golden/polygons.npz) and oracle/flutl_tor_oracle.c.
 #include <hip/hip_runtime.h>
