@@ -6,6 +6,7 @@
 // There is deliberately no CPU rendering path here: if HIP is unusable every
 // compute entry point fails with FLUTL_ENODEV.
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -61,6 +62,8 @@ constexpr size_t kEdgeBlockBytes = (size_t) 1 << 20;     // ... of 37 000 edges 
 constexpr int kEdgeEpochEvents = 16;
 constexpr uint32_t kEdgeEpochPolygons = 4;       // an event behind every so many polygons
 
+struct FrameArena;
+
 struct flutl_ctx {
   int device;
   hipStream_t stream;
@@ -109,14 +112,57 @@ struct flutl_ctx {
     size_t rb, pb, ob, copy_bytes;
     uint32_t n_regions, n_prims, n_order, y0, y1, now[4];
   } staged;
+  std::vector<FrameArena *> frame_arenas;
+  // The outlines' scan conversions are queued on a stream of their own: they hang on nothing
+  // the compositor does -- an atlas entry is written once, into bytes nothing has read yet --
+  // so cue k + 1's conversion runs beside cue k's compositor launch, whose stores wait for
+  // PCIe (tools/overlap_bench.py: 48.7 us per pair in turn, 34.8 side by side).  scan_pending:
+  // entries queued there that `stream` has not been made to wait for yet (atlas_join).
+  // FLUTL_ONE_STREAM=1: everything on `stream`, as before round 4.
+  hipStream_t scan_stream;
+  hipEvent_t scan_ev, main_ev;
+  bool scan_pending;
   // FLUTL_API_TIMING=1: where flutl_frame_submit's time goes on the calling thread (ns)
   bool api_timing;
   uint64_t t_sub[6], n_sub;
 };
 
+// Frames made together (flutl_ctx_reserve_frames): ONE anonymous mapping advised to use huge
+// pages, populated and registered with the device in one go, and one device allocation for the
+// twins.  Page-locking a 4K frame of its own costs 5.5 ms (14 ms in a process whose other
+// threads contend for the address space lock); eighteen of them this way cost 35 ms together
+// (tools/microbench/pin_cost.cpp).  Counted: the frames may outlive the context.
+struct FrameArena {
+  std::atomic<int> refs;
+  std::mutex lock;
+  int device;
+  void *map;
+  size_t map_bytes;
+  char *host, *twin;
+  size_t block_bytes;
+  uint32_t count;
+  std::vector<uint8_t> state;   // per block: 0 free and zero, 1 free, 2 in a frame
+};
+
+static void frame_arena_unref (FrameArena *a)
+{
+  if (!a || a->refs.fetch_sub (1, std::memory_order_acq_rel) != 1)
+    return;
+  (void) hipSetDevice (a->device);
+  if (a->host)
+    (void) hipHostUnregister (a->host);
+  if (a->map)
+    munmap (a->map, a->map_bytes);
+  if (a->twin)
+    (void) hipFree (a->twin);
+  delete a;
+}
+
 struct flutl_frame {
   int device;
   uint32_t width, height;
+  FrameArena *arena;   // where host and twin come from (NULL: allocations of the frame's own)
+  uint32_t arena_block;
   void *host;          // page-locked, device mapped
   void *host_dev;      // its device address
   void *twin;          // device
@@ -311,6 +357,25 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
     delete c;
     return FLUTL_ENODEV;
   }
+  c->scan_stream = nullptr;
+  c->scan_ev = c->main_ev = nullptr;
+  c->scan_pending = false;
+  {
+    const char *one = getenv ("FLUTL_ONE_STREAM");
+    if (!(one && *one && *one != '0')) {
+      if (!hip_ok (hipStreamCreateWithFlags (&c->scan_stream, hipStreamNonBlocking)) ||
+          !hip_ok (hipEventCreateWithFlags (&c->scan_ev, hipEventDisableTiming)) ||
+          !hip_ok (hipEventCreateWithFlags (&c->main_ev, hipEventDisableTiming))) {
+        if (c->scan_ev)
+          (void) hipEventDestroy (c->scan_ev);
+        if (c->scan_stream)
+          (void) hipStreamDestroy (c->scan_stream);
+        (void) hipStreamDestroy (c->stream);
+        delete c;
+        return FLUTL_ENODEV;
+      }
+    }
+  }
   c->atlas = nullptr;
   c->atlas_cap = 0;
   c->atlas_used = kAtlasSlack;
@@ -392,6 +457,47 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
   return FLUTL_OK;
 }
 
+// the stream the scan conversions are queued on
+static inline hipStream_t scan_stream_of (flutl_ctx *c)
+{
+  return c->scan_stream ? c->scan_stream : c->stream;
+}
+
+// `stream` behind every atlas entry queued on the scan stream so far: before anything on
+// `stream` that reads the atlas (or writes where an entry was, or frees what a conversion uses)
+static bool atlas_join (flutl_ctx *c)
+{
+  if (!c->scan_stream || !c->scan_pending)
+    return true;
+  if (!hip_ok (hipEventRecord (c->scan_ev, c->scan_stream)) ||
+      !hip_ok (hipStreamWaitEvent (c->stream, c->scan_ev, 0)))
+    return hip_ok (hipStreamSynchronize (c->scan_stream));
+  c->scan_pending = false;
+  return true;
+}
+
+// ... and the scan stream behind everything queued on `stream` so far: before bytes of the
+// atlas are used again (flutl_atlas_reset)
+static bool scan_stream_follows (flutl_ctx *c)
+{
+  if (!c->scan_stream)
+    return true;
+  if (!hip_ok (hipEventRecord (c->main_ev, c->stream)) ||
+      !hip_ok (hipStreamWaitEvent (c->scan_stream, c->main_ev, 0)))
+    return hip_ok (hipStreamSynchronize (c->stream));
+  return true;
+}
+
+static bool sync_streams (flutl_ctx *c)
+{
+  bool ok = true;
+  if (c->scan_stream) {
+    ok = hip_ok (hipStreamSynchronize (c->scan_stream));
+    c->scan_pending = false;
+  }
+  return hip_ok (hipStreamSynchronize (c->stream)) && ok;
+}
+
 extern "C" void flutl_ctx_destroy (flutl_ctx *c)
 {
   if (!c)
@@ -402,7 +508,7 @@ extern "C" void flutl_ctx_destroy (flutl_ctx *c)
         c->t_sub[0] / 1e3 / c->n_sub, c->t_sub[1] / 1e3 / c->n_sub, c->t_sub[2] / 1e3 / c->n_sub,
         c->t_sub[3] / 1e3 / c->n_sub, c->t_sub[4] / 1e3 / c->n_sub, c->t_sub[5] / 1e3 / c->n_sub);
   (void) hipSetDevice (c->device);
-  (void) hipStreamSynchronize (c->stream);
+  (void) sync_streams (c);
   if (c->atlas)
     (void) hipFree (c->atlas);
   if (c->frame)
@@ -431,6 +537,13 @@ extern "C" void flutl_ctx_destroy (flutl_ctx *c)
   if (c->edge_arena)
     (void) hipHostFree (c->edge_arena);
   delete c->edge_lock;
+  for (FrameArena *a : c->frame_arenas)
+    frame_arena_unref (a);
+  if (c->scan_stream) {
+    (void) hipEventDestroy (c->scan_ev);
+    (void) hipEventDestroy (c->main_ev);
+    (void) hipStreamDestroy (c->scan_stream);
+  }
   (void) hipStreamDestroy (c->stream);
   delete c;
 }
@@ -439,7 +552,7 @@ extern "C" int flutl_ctx_sync (flutl_ctx *c)
 {
   if (!c)
     return FLUTL_EINVAL;
-  if (!hip_ok (hipStreamSynchronize (c->stream)))
+  if (!sync_streams (c))
     return FLUTL_ENODEV;
   c->stage_used = 0;       // every staged upload has landed
   if (c->edge_lock) {      // (... and every outline's edges have been read)
@@ -480,6 +593,11 @@ static int atlas_reserve (flutl_ctx *c, size_t need)
   uint8_t *n = nullptr;
   if (!hip_ok (hipMalloc (reinterpret_cast<void **> (&n), cap)))
     return FLUTL_ENOMEM;
+  // (conversions in flight write the old buffer)
+  if (c->scan_stream) {
+    (void) hipStreamSynchronize (c->scan_stream);
+    c->scan_pending = false;
+  }
   if (!hip_ok (hipMemsetAsync (n, 0, cap, c->stream))) {
     (void) hipFree (n);
     return FLUTL_ENODEV;
@@ -549,7 +667,7 @@ static void edge_blocks_reclaim (flutl_ctx *c, bool wait)
 {
   // (the caller holds edge_lock)
   if (wait && c->epoch_known == c->epoch_cur && c->epoch_uses) {
-    if (hip_ok (hipEventRecord (c->epoch_done[c->epoch_cur % kEdgeEpochEvents], c->stream))) {
+    if (hip_ok (hipEventRecord (c->epoch_done[c->epoch_cur % kEdgeEpochEvents], scan_stream_of (c)))) {
       c->epoch_cur++;
       c->epoch_uses = 0;
     }
@@ -648,7 +766,7 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
   constexpr uint32_t kWindow = 4096;
   const size_t own_bytes = flutl_scan_scratch_bytes (n_edges, w < kWindow ? w : kWindow, h);
   const size_t need = edge_bytes + own_bytes;
-  hipStream_t ms = c->stream;
+  hipStream_t ms = scan_stream_of (c);
   if (need > c->scan_cap) {
     // (whatever still reads the old one is ordered before the free by the sync)
     if (c->scan) {
@@ -716,6 +834,7 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
   }
   // the entry: the coverage, and the zero bytes around and between its rows (mode 8); the
   // converter's status words are the first of its scratch and stay zero between calls (16)
+  c->scan_pending = true;
   if (n_edges == 0) {
     if (!hip_ok (hipMemsetAsync (c->atlas + off, 0, bytes, ms)))
       return FLUTL_ENODEV;
@@ -765,6 +884,7 @@ extern "C" uint32_t flutl_ctx_scan_fallbacks (flutl_ctx *c)
   if (!c || !c->scan_counters)
     return 0;
   (void) hipSetDevice (c->device);
+  (void) atlas_join (c);
   if (!hip_ok (hipMemcpyAsync (&n, c->scan_counters, sizeof n, hipMemcpyDeviceToHost, c->stream)) ||
       !hip_ok (hipStreamSynchronize (c->stream)))
     return 0;
@@ -786,8 +906,7 @@ extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
   if (rc)
     return rc;
   (void) hipSetDevice (c->device);
-  // a fractional blit position: the entry is the blurred surface resampled by
-  // the constant bilinear weights, one pixel wider and higher
+  (void) atlas_join (c);
   // a fractional blit position: the entry is the blurred surface resampled by
   // the constant bilinear weights, one pixel wider and higher, IN the box's
   // edge coverage.  rotate_cw: the 90-degree CTM of the vertical writing
@@ -874,8 +993,14 @@ extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
 
 extern "C" void flutl_atlas_reset (flutl_ctx *c)
 {
-  if (c)
-    c->atlas_used = kAtlasSlack;
+  if (!c)
+    return;
+  // (the bytes are used again: whatever is written there next, on either stream, comes behind
+  // everything queued so far on both)
+  (void) hipSetDevice (c->device);
+  (void) atlas_join (c);
+  (void) scan_stream_follows (c);
+  c->atlas_used = kAtlasSlack;
 }
 
 extern "C" size_t flutl_atlas_size (const flutl_ctx *c)
@@ -965,6 +1090,7 @@ extern "C" int flutl_render (flutl_ctx *c, const flutl_list *l, void *dst_dev,
   if (!c || !l || !dst_dev)
     return FLUTL_EINVAL;
   (void) hipSetDevice (c->device);
+  (void) atlas_join (c);
   return flutl_launch_frame (c->stream, l->width, l->height, dst_dev,
       dst_stride_bytes, l->regions, l->n_regions, l->prims, c->atlas);
 }
@@ -1076,6 +1202,7 @@ static int render_lists_to_host (flutl_ctx *c, uint32_t width, uint32_t height,
   const auto *l = &lv;
   const size_t tight = (size_t) l->width * 4;
   const size_t need = tight * l->height;
+  (void) atlas_join (c);
   if (need > c->frame_cap) {
     if (c->frame) {
       (void) hipStreamSynchronize (c->stream);
@@ -1139,6 +1266,7 @@ extern "C" int flutl_blend_over_host (flutl_ctx *c, uint32_t width, uint32_t hei
   if (y1 <= y0)
     return FLUTL_OK;            // nothing to draw: the frame is the result
   (void) hipSetDevice (c->device);
+  (void) atlas_join (c);
   // whole supertiles of 16 rows: the kernel writes video OVER'd (or copied) there
   const uint32_t fy0 = y0 & ~15u, fy1 = ((y1 + 15u) & ~15u) < height ? ((y1 + 15u) & ~15u) : height;
   const size_t tight = (size_t) width * 4, frame_bytes = tight * height;
@@ -1184,6 +1312,91 @@ extern "C" int flutl_frame_create (flutl_ctx *c, uint32_t width, uint32_t height
   return flutl_frame_create_quiet (c, width, height, 0, out);
 }
 
+extern "C" int flutl_ctx_reserve_frames (flutl_ctx *c, uint32_t width, uint32_t height, uint32_t count)
+{
+  if (!c || width == 0 || height == 0 || width > 32767 || height > 32767 || count > 4096)
+    return FLUTL_EINVAL;
+  const size_t bytes = (size_t) width * height * 4;
+  const size_t block = (bytes + 4095) & ~(size_t) 4095;
+  uint32_t have = 0;
+  for (FrameArena *a : c->frame_arenas)
+    if (a->block_bytes == block) {
+      std::lock_guard<std::mutex> g (a->lock);
+      for (uint8_t st : a->state)
+        have += st != 2;
+    }
+  if (have >= count)
+    return FLUTL_OK;
+  count -= have;
+  (void) hipSetDevice (c->device);
+  FrameArena *a = new (std::nothrow) FrameArena ();
+  if (!a)
+    return FLUTL_ENOMEM;
+  const size_t huge = (size_t) 2 << 20;
+  a->refs.store (1);
+  a->device = c->device;
+  a->block_bytes = block;
+  a->count = count;
+  a->host = a->twin = nullptr;
+  const size_t total = (block * count + huge - 1) & ~(huge - 1);
+  a->map_bytes = total + huge;
+  a->map = mmap (nullptr, a->map_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (a->map == MAP_FAILED) {
+    delete a;
+    return FLUTL_ENOMEM;
+  }
+  char *base = reinterpret_cast<char *> ((reinterpret_cast<uintptr_t> (a->map) + huge - 1) & ~(uintptr_t) (huge - 1));
+  (void) madvise (base, total, MADV_HUGEPAGE);
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
+  // (the pages brought in zeroed by the kernel, once; a kernel without the advice: by writing)
+  if (madvise (base, total, MADV_POPULATE_WRITE) != 0)
+    memset (base, 0, total);
+  void *dev = nullptr;
+  bool ok = hip_ok (hipHostRegister (base, total, hipHostRegisterPortable | hipHostRegisterMapped));
+  if (ok)
+    a->host = base;
+  // (the frames' device address is taken per frame; it must be the host's for the kernels'
+  // sake nowhere -- they are handed host_dev -- but a mapping that fails shows here)
+  ok = ok && hip_ok (hipHostGetDevicePointer (&dev, base, 0));
+  ok = ok && hip_ok (hipMalloc (reinterpret_cast<void **> (&a->twin), block * count));
+  ok = ok && hip_ok (hipMemsetAsync (a->twin, 0, block * count, c->stream));
+  if (!ok) {
+    if (!a->host) {            // (never registered: unref would unregister it)
+      munmap (a->map, a->map_bytes);
+      a->map = nullptr;
+    }
+    frame_arena_unref (a);
+    return FLUTL_ENOMEM;
+  }
+  a->state.assign (count, 0);
+  c->frame_arenas.push_back (a);
+  return FLUTL_OK;
+}
+
+// A free block of a reservation for frames of `bytes`: a zero one first.  *clean: it is zero
+// (the host half; the twin is cleared by whoever takes it unless the block is fresh).
+static FrameArena *frame_arena_take (flutl_ctx *c, size_t bytes, uint32_t *index, bool *clean)
+{
+  const size_t block = (bytes + 4095) & ~(size_t) 4095;
+  for (int want = 0; want < 2; want++)
+    for (FrameArena *a : c->frame_arenas) {
+      if (a->block_bytes != block)
+        continue;
+      std::lock_guard<std::mutex> g (a->lock);
+      for (uint32_t i = 0; i < a->count; i++)
+        if (a->state[i] == want) {
+          a->state[i] = 2;
+          a->refs.fetch_add (1, std::memory_order_relaxed);
+          *index = i;
+          *clean = want == 0;
+          return a;
+        }
+    }
+  return nullptr;
+}
+
 // (quiet: the host block is cleared by the calling thread, not by the device over PCIe in
 // stream order -- a frame made in the background while the stream is busy with cues must
 // not put 1.3 ms of clearing in front of them; the twin's clearing is microseconds)
@@ -1207,9 +1420,16 @@ extern "C" int flutl_frame_create_quiet (flutl_ctx *c, uint32_t width, uint32_t 
   f->error = 0;
   f->written = false;
   f->ext[0] = f->ext[1] = f->ext[2] = f->ext[3] = 0;
-  bool ok = hip_ok (hipHostMalloc (&f->host, bytes, hipHostMallocPortable | hipHostMallocMapped));
+  bool ok = true, clean = false;
+  f->arena = frame_arena_take (c, bytes, &f->arena_block, &clean);
+  if (f->arena) {
+    f->host = f->arena->host + f->arena->block_bytes * f->arena_block;
+    f->twin = f->arena->twin + f->arena->block_bytes * f->arena_block;
+  } else {
+    ok = hip_ok (hipHostMalloc (&f->host, bytes, hipHostMallocPortable | hipHostMallocMapped));
+    ok = ok && hip_ok (hipMalloc (&f->twin, bytes));
+  }
   ok = ok && hip_ok (hipHostGetDevicePointer (&f->host_dev, f->host, 0));
-  ok = ok && hip_ok (hipMalloc (&f->twin, bytes));
   // (system-scope release: what the kernel wrote to the host block is visible to
   // the CPU once the event has been waited for)
   ok = ok && hip_ok (hipEventCreateWithFlags (&f->done,
@@ -1217,10 +1437,12 @@ extern "C" int flutl_frame_create_quiet (flutl_ctx *c, uint32_t width, uint32_t 
   // the transparent frame, in both copies: cleared by the device in stream order
   // (the host block over PCIe: no 33 MB memset on the caller's thread, and no
   // wait -- whatever is submitted into the frame comes later on the same stream)
-  if (ok && quiet)
+  // (a fresh block of a reservation is zero in both halves: the twins' clearing was queued
+  // on this stream when the reservation was made)
+  if (ok && quiet && !clean)
     memset (f->host, 0, bytes);
-  ok = ok && hip_ok (hipMemsetAsync (f->twin, 0, bytes, c->stream)) &&
-      (quiet || hip_ok (hipMemsetAsync (f->host_dev, 0, bytes, c->stream))) &&
+  ok = ok && (clean || hip_ok (hipMemsetAsync (f->twin, 0, bytes, c->stream))) &&
+      (quiet || clean || hip_ok (hipMemsetAsync (f->host_dev, 0, bytes, c->stream))) &&
       hip_ok (hipEventRecord (f->done, c->stream));
   if (ok)
     f->pending = true;
@@ -1241,10 +1463,18 @@ extern "C" void flutl_frame_destroy (flutl_frame *f)
       (void) hipEventSynchronize (f->done);
     (void) hipEventDestroy (f->done);
   }
-  if (f->twin)
-    (void) hipFree (f->twin);
-  if (f->host)
-    (void) hipHostFree (f->host);
+  if (f->arena) {
+    {
+      std::lock_guard<std::mutex> g (f->arena->lock);
+      f->arena->state[f->arena_block] = 1;
+    }
+    frame_arena_unref (f->arena);
+  } else {
+    if (f->twin)
+      (void) hipFree (f->twin);
+    if (f->host)
+      (void) hipHostFree (f->host);
+  }
   delete f;
 }
 
@@ -1432,7 +1662,7 @@ extern "C" int flutl_frame_submit_staged (flutl_ctx *c, flutl_frame *f)
       return FLUTL_ENOMEM;
     c->frame_cap = need;
   }
-  bool ok = true;
+  bool ok = atlas_join (c);
   // (the list: up with a scan conversion's launch since it was staged, or by a copy now)
   if (c->staged.copy_pending) {
     ok = hip_ok (hipMemcpyAsync (sl.dev, sl.host, c->staged.copy_bytes, hipMemcpyHostToDevice, c->stream));

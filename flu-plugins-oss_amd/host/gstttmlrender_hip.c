@@ -399,6 +399,9 @@ frame_pool_prefill (FramePool *p, flutl_ctx *ctx, gint width, gint height, guint
   p->prefilled_count = n;
   frame_pool_set_size (p, size);
   g_mutex_unlock (&p->lock);
+  /* (their memory in one piece: FLUTL_NO_FRAME_ARENA=1 makes each frame's own, as rounds 1-3) */
+  if (!g_getenv ("FLUTL_NO_FRAME_ARENA"))
+    (void) flutl_ctx_reserve_frames (ctx, width, height, n - have);
   for (guint i = have; i < n; i++) {
     /* (cleared by this thread, at start-up: not by the device in front of the first cues) */
     FrameSlot *slot = frame_slot_new_ex (ctx, width, height, TRUE, TRUE);

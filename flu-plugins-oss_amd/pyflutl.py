@@ -60,7 +60,7 @@ EXPORTS = [
     "flutl_frame_device", "flutl_frame_submit", "flutl_frame_wait", "flutl_ctx_delta_bytes",
     "flutl_atlas_put_polygon", "flutl_polygon_entry_bytes", "flutl_ctx_scan_fallbacks",
     "flutl_scan_scratch_bytes", "flutl_scan_zero_bytes", "flutl_ctx_edge_block_acquire",
-    "flutl_ctx_edge_block_release", "flutl_frame_mark_written", "flutl_frame_create_quiet", "flutl_frame_stage", "flutl_frame_submit_staged", "flutl_launch_scan", "flutl_scan_status",
+    "flutl_ctx_edge_block_release", "flutl_frame_mark_written", "flutl_frame_create_quiet", "flutl_ctx_reserve_frames", "flutl_frame_stage", "flutl_frame_submit_staged", "flutl_launch_scan", "flutl_scan_status",
 ]
 
 
@@ -95,6 +95,7 @@ def lib():
         L.flutl_ctx_destroy.argtypes = [vp]
         L.flutl_ctx_destroy.restype = None
         L.flutl_ctx_sync.argtypes = [vp]
+        L.flutl_ctx_reserve_frames.argtypes = [vp, u32, u32, u32]
         L.flutl_atlas_put.argtypes = [vp, vp, sz, ctypes.POINTER(u32)]
         L.flutl_atlas_reset.argtypes = [vp]
         L.flutl_atlas_reset.restype = None
@@ -485,6 +486,10 @@ class Context:
 
     def delta_bytes(self):
         return int(lib().flutl_ctx_delta_bytes(self._h))
+
+    def reserve_frames(self, width, height, count):
+        """flutl_ctx_reserve_frames: the memory of `count` frames in one piece"""
+        _check(lib().flutl_ctx_reserve_frames(self._h, width, height, count), "flutl_ctx_reserve_frames")
 
     def frame(self, width, height):
         return Frame(self, width, height)

@@ -443,6 +443,13 @@ int   flutl_frame_create (flutl_ctx *ctx, uint32_t width, uint32_t height,
  * order (quiet != 0): for frames made in the background of a running stream. */
 int   flutl_frame_create_quiet (flutl_ctx *ctx, uint32_t width, uint32_t height, int quiet,
     flutl_frame **out);
+/* Make the memory of `count` frames of width x height in one go: the frames created
+ * afterwards take their host block and twin from it (cleared already; a block is reused when
+ * its frame is destroyed) -- one huge-page mapping registered with the device instead of a
+ * page-locked allocation per frame, 2 ms per 4K frame instead of 5.5-14 ms.  Blocks already
+ * reserved and free count.  FLUTL_ENOMEM: nothing reserved, frames are made one by one as
+ * before.  The reservation lives until the context and the last frame made of it are gone. */
+int   flutl_ctx_reserve_frames (flutl_ctx *ctx, uint32_t width, uint32_t height, uint32_t count);
 void  flutl_frame_destroy (flutl_frame *frame);
 void *flutl_frame_host (const flutl_frame *frame);
 const void *flutl_frame_device (const flutl_frame *frame);

@@ -442,6 +442,58 @@ def test_frame_submit_delta_readback_tracks_every_state(gpu, size):
             fr.close()
 
 
+@pytest.mark.parametrize("size", [(320, 180), (333, 77)])
+def test_frames_of_a_reservation_behave_like_frames_of_their_own(gpu, size):
+    """flutl_ctx_reserve_frames: the frames created afterwards take their host block and
+    twin from one registered mapping.  They start transparent, track every state like a
+    frame of its own, a block comes back (cleared) when its frame is destroyed, a frame
+    beyond the reservation is made the old way, and a frame may outlive its context."""
+    W, H = size
+    lists = [scenes.random_scene(300 + i, W, H, n_regions=2 + i % 3) for i in range(4)]
+    Rm, Pm, A, _ = _concat_lists(lists, W, H)
+    ctx = F.Context(0)
+    ctx.atlas_put(A[F.ATLAS_SLACK:])
+    ctx.reserve_frames(W, H, 3)
+    ctx.reserve_frames(W, H, 2)          # (already there: nothing new)
+    frames = [ctx.frame(W, H) for _ in range(4)]     # the fourth: beyond the reservation
+    hosts = [f.host().ctypes.data for f in frames]
+    block = (W * H * 4 + 4095) & ~4095
+    assert abs(hosts[1] - hosts[0]) == block
+    assert abs(hosts[2] - hosts[1]) == block
+    def state(k):
+        lo = sum(len(l[0]) for l in lists[:k])
+        return Rm[lo:lo + len(lists[k][0])].copy()
+    try:
+        for f in frames:
+            assert not f.host().any()
+        for step in range(6):
+            for i, f in enumerate(frames):
+                f.submit(state((step + i) % 4), Pm)
+            for i, f in enumerate(frames):
+                f.wait()
+                exp = O.render(W, H, state((step + i) % 4), Pm, A)
+                assert np.array_equal(f.host(), exp), (step, i)
+                assert np.array_equal(_twin_of(f), exp), (step, i)
+        # a block given back is taken again, and is transparent again in both halves
+        frames[1].close()
+        again = ctx.frame(W, H)
+        assert again.host().ctypes.data == hosts[1]
+        again.wait()
+        assert not again.host().any() and not _twin_of(again).any()
+        again.submit(state(2), Pm)
+        again.wait()
+        assert np.array_equal(again.host(), O.render(W, H, state(2), Pm, A))
+        frames[1] = again
+    finally:
+        keep = frames[0]
+        for f in frames[1:]:
+            f.close()
+        ctx.close()
+    # the context is gone: the frame's memory is still there
+    assert np.array_equal(keep.host(), O.render(W, H, state(5 % 4), Pm, A))
+    keep.close()
+
+
 def test_frame_submit_pipelines_without_waiting_in_between(gpu):
     """Submissions are queued, not waited for: many frames in flight through the
     list-slot ring (deeper than the ring), several pooled frames in rotation, one

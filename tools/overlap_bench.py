@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""GPU box: do the scan converter's kernels and the element's DELTA compositor launch run side
+by side when they are queued on two streams?  n conversions of bench.py's outline on stream A,
+n DELTA launches (cfg2's states, as bench.py's delta_stream block) on stream B: each alone, both
+on ONE stream in turn (what the element does), and each on its own stream.
+    python tools/overlap_bench.py [n]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "flu-plugins-oss_amd"))
+import pyflutl as F  # noqa: E402
+import bench  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+b = np.load(os.path.join(ROOT, "bench_data", "outline_4k.npz"))
+edges, box = b["edges0"], tuple(int(v) for v in b["meta"][0][1:5])
+w, h = box[2] - box[0], box[3] - box[1]
+dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).cuda()
+ed = dev(np.ascontiguousarray(edges, np.int32))
+scratch = torch.zeros(F.scan_scratch_bytes(len(edges), w, h) + 256, dtype=torch.uint8, device="cuda")
+dst = torch.zeros(h * (w + 4), dtype=torch.uint8, device="cuda")
+
+W, H, states, atlas, _ = bench.load_states("cfg2_2160p_8regions_outline", 64, None)
+A_dev = dev(atlas)
+nf = 3
+twins = [torch.zeros(W * H * 4, dtype=torch.uint8, device="cuda") for _ in range(nf)]
+hosts = [torch.zeros(W * H * 4, dtype=torch.uint8).pin_memory() for _ in range(nf)]
+park = torch.zeros(W * H * 4, dtype=torch.uint8, device="cuda")
+changed = torch.zeros(1, dtype=torch.int64, device="cuda")
+per = []
+for (R, P) in states:
+    live = [r for r in R if r["y1"] > r["y0"]]
+    y0 = min(int(r["y0"]) for r in live)
+    y1 = max(int(r["y1"]) for r in live)
+    per.append((dev(R), len(R), dev(P), y0, y1, dev(F.row_order(W, H, R, P, y0, y1))))
+
+sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+
+
+def scan(stream):
+    F.launch_scan(stream.cuda_stream, ed, len(edges), box, 0, scratch, dst, w + 4, F.SCAN_CLEAN)
+
+
+def delta(stream, i):
+    rd, nr, pd, y0, y1, od = per[i % len(per)]
+    F.launch_frame_delta(stream.cuda_stream, W, H, twins[i % nf], hosts[i % nf], park, rd, nr, pd, A_dev,
+                         y0, y1, od, changed)
+
+
+def timed(fn):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e6
+
+
+x = torch.randn(4096, 4096, device="cuda")
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < 0.5:
+    y = x @ x
+torch.cuda.synchronize()
+for i in range(50):
+    scan(sa)
+    delta(sb, i)
+for rep in range(2):
+    a = timed(lambda: [scan(sa) for _ in range(n)])
+    d = timed(lambda: [delta(sb, i) for i in range(n)])
+    one = timed(lambda: [(scan(sa), delta(sa, i)) for i in range(n)])
+    two = timed(lambda: [(scan(sa), delta(sb, i)) for i in range(n)])
+    print(f"per pair, us: scan alone {a:.1f}, delta alone {d:.1f}, in turn on one stream {one:.1f}, "
+          f"on two streams {two:.1f}", flush=True)
