@@ -69,6 +69,18 @@ def timeline(out):
         print("  %-26s x%.2f per cue  mean %7.2f us   idle in front of it %6.2f us" % (
             k, cnt[k] / cues, dur[k] / cnt[k] / 1000, gap[k] / cnt[k] / 1000))
     print("  busy %.1f us + idle %.1f us per cue" % (sum(dur.values()) / cues / 1000, sum(gap.values()) / cues / 1000))
+    # two streams: how much of the time two operations run side by side
+    edges = sorted([(a, 1) for a, _, _ in ops] + [(b, -1) for _, b, _ in ops])
+    depth, last, any_busy, two_busy = 0, edges[0][0], 0, 0
+    for t, d in edges:
+        if depth >= 1:
+            any_busy += t - last
+        if depth >= 2:
+            two_busy += t - last
+        depth += d
+        last = t
+    print("  the device busy %.1f us per cue, of which two operations side by side %.1f us" % (
+        any_busy / cues / 1000, two_busy / cues / 1000))
 
 
 if __name__ == "__main__":
