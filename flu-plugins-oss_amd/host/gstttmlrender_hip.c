@@ -2999,7 +2999,10 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
   }
   /* outlines without a mask yet are rasterised on worker threads and waited for
    * by the finisher, unless the frame is needed complete right here */
-  flutl_recorder_set_defer (rec, !priv->sync_mode && !priv->full_d2h && !priv->video_pad &&
+  /* (a cue for the video side: its outlines go to the workers as well and are waited for
+   * before the cue is queued, below -- they come back as polygons for the device instead of
+   * being rasterised by Cairo on this thread) */
+  flutl_recorder_set_defer (rec, !priv->sync_mode && !priv->full_d2h &&
       (!priv->dump || priv->dump_defer));
   /* ... as polygons for the device to scan convert (not when the frame is dumped: a
    * scene pack holds the masks' bytes) */
@@ -3060,6 +3063,21 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
   }
   if (priv->video_pad) {
     /* fused over-video: this interval is a cue for the video side; no buffer */
+    if (!priv->dump) {
+      uint32_t n_patches = 0;
+      const FlutlPatch *patches = flutl_recorder_patches (rec, &n_patches);
+      if (n_patches)          /* (the cue's outlines, made by the workers meanwhile) */
+        flutl_recorder_resolve (rec, (flutl_region *) rg, n_rg, (flutl_prim *) pr, n_pr, patches,
+            n_patches);
+    }
+    if (priv->timing) {         /* (the cue's host time; FLUTL_TIMING's line counts cues here) */
+      gint64 t = g_get_monotonic_time ();
+      if (priv->n_timed++ == 0)
+        priv->t_first_return = t;
+      else
+        priv->t_record += t - t_start;
+      priv->t_last_return = t;
+    }
     video_cue_push (render, ts, duration, rg, n_rg, pr, n_pr);
     /* No buffer for the base class to push: what it does after a push is done here.
      * last_out_time is what clamps the intervals of events that come out of order (a
@@ -3342,10 +3360,13 @@ timing_report (GstTTMLRender *render)
   flutl_recorder_raster_stats (&by_cairo, &dev_fills);                         /* (process-wide) */
   pipeline_drain (render);
   if (priv->ctx) {
+    /* (fused over-video: the video thread uses the context as well) */
+    g_mutex_lock (&priv->ctx_lock);
     flutl_ctx_sync (priv->ctx);
     t_drained = g_get_monotonic_time ();
     delta = flutl_ctx_delta_bytes (priv->ctx) - priv->delta_reported;
     priv->delta_reported += delta;
+    g_mutex_unlock (&priv->ctx_lock);
   } else {
     t_drained = priv->t_last_return;
   }

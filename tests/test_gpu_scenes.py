@@ -366,12 +366,18 @@ def test_element_fused_over_video_at_full_size(gpu):
     import json
     meta = json.load(open(os.path.join(ROOT, "bench_data", "cfg2.video_sha256.json")))
     W, H, n = meta["width"], meta["height"], meta["frames"]
+    log = []
     vraw, oraw = gstenv.render_over_video(os.path.join(ROOT, "bench_data", meta["document"]),
-                                          W, H, n, meta["fps"], pattern=meta["pattern"])
+                                          W, H, n, meta["fps"], pattern=meta["pattern"],
+                                          extra_env={"FLUTL_TIMING": "1"}, log=log)
     size = W * H * 4
     assert len(oraw) == n * size and len(vraw) == n * size
     got = [hashlib.sha256(oraw[k * size:(k + 1) * size]).hexdigest() for k in range(n)]
     assert got == meta["sha256"], [k for k in range(n) if got[k] != meta["sha256"][k]]
+    # the cues' outlines came from the workers as polygons for the device: none by Cairo
+    import re
+    m = re.search(r"polygons=(\d+).* masks_by_cairo=(\d+)", log[0])
+    assert m and int(m.group(1)) > 0 and int(m.group(2)) == 0, log[0][-1500:]
 
 
 @pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),

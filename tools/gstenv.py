@@ -94,7 +94,7 @@ def dump_pack(ttml_path, width, height, pack_path, record_only=True, extra_env=N
 
 
 def render_over_video(ttml_path, width, height, n_frames, fps, pattern="smpte",
-                      extra_env=None):
+                      extra_env=None, log=None):
     """The element's fused over-video mode (FLUTL_VIDEO_PAD=1, request pad video_sink):
         videotestsrc ! BGRA caps ! r.video_sink   filesrc ! ttmlrender name=r ! filesink
     Returns (video frames as produced by videotestsrc alone, output frames), raw bytes."""
@@ -116,6 +116,8 @@ def render_over_video(ttml_path, width, height, n_frames, fps, pattern="smpte",
                            cwd=tempfile.gettempdir(), timeout=300)
         if r.returncode != 0:
             raise RuntimeError(f"gst-launch failed (rc {r.returncode}): {r.stdout}\n{r.stderr}")
+        if log is not None and with_subs:
+            log.append(r.stderr)
         outs.append(open(tmp.name, "rb").read())
         os.unlink(tmp.name)
     return outs[0], outs[1]
