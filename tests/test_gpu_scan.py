@@ -425,3 +425,75 @@ def test_a_staged_frames_list_goes_up_with_its_outlines_conversion(gpu):
         finally:
             fr.close()
     assert len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want))
+
+
+def test_whatever_reads_the_atlas_comes_behind_the_conversions_queued_before_it(gpu):
+    """The conversions run on a stream of their own.  Fifty of them queued back to back put
+    that stream a millisecond behind the host; a reader queued right away on the other
+    stream -- a frame submit, the synchronous render, the blend over a video frame -- must
+    still see the LAST entry complete; and after flutl_atlas_reset the bytes are used again:
+    a mask uploaded over them (on the compositor's stream) must not be overtaken by, nor
+    overtake, the conversions that wrote there before."""
+    import gpu_util
+    torch = gpu
+    i, kind, box, eo, edges, cov = next(p for p in _polygons() if p[1] == 2)
+    h, w = cov.shape
+    W, H = box[2] + 8, box[3] + 8
+    R = np.zeros(1, F.REGION_DTYPE)
+    R["x0"], R["y0"], R["x1"], R["y1"], R["first"], R["count"] = box[0], box[1], box[2], box[3], 0, 1
+    P = np.zeros(1, F.PRIM_DTYPE)
+    P["op"], P["rule"] = F.OP_MASK, F.RULE_LERP
+    P["cx0"], P["cy0"], P["cx1"], P["cy1"] = box[0], box[1], box[2], box[3]
+    P["color"] = 0xFF000000
+    P["b"], P["c"], P["d"] = w + 4, box[0], box[1]
+    padded = np.zeros((h, w + 4), np.uint8)
+    padded[:, :w] = cov
+    atlas = np.concatenate([np.zeros(F.ATLAS_SLACK + 4, np.uint8), padded.ravel(),
+                            np.zeros(F.ATLAS_SLACK, np.uint8)])
+    P2 = P.copy()
+    P2["a"] = F.ATLAS_SLACK + 4
+    want = gpu_util.hip_render(W, H, R, P2, atlas)
+    video = np.full((H, W), 0xFF204060, np.uint32)
+    import oracle_lib as O
+    want_over = O.over(want.reshape(-1), video.reshape(-1)).reshape(H, W)
+
+    def burst(ctx, n=50):
+        off = 0
+        for _ in range(n):
+            off = ctx.atlas_put_polygon(edges, box, eo)
+        return off
+
+    with F.Context(0) as ctx:
+        fr = ctx.frame(W, H)
+        try:
+            P["a"] = burst(ctx) + 4
+            fr.submit(R, P)
+            fr.wait()
+            assert np.array_equal(fr.host(), want), "frame submit overtook the conversions"
+            P["a"] = burst(ctx) + 4
+            assert np.array_equal(ctx.render_frame_to_host(W, H, R, P), want), "render overtook them"
+            P["a"] = burst(ctx) + 4
+            v = video.copy()
+            ctx.blend_over_host(W, H, R, P, v)
+            assert np.array_equal(v, want_over), "blend over video overtook them"
+            # the bytes used again: an upload over where conversions are still writing
+            burst(ctx)
+            ctx.atlas_reset()
+            inverse = padded.copy()
+            inverse[:, :w] = 255 - cov
+            off = ctx.atlas_put(np.concatenate([np.zeros(4, np.uint8), inverse.ravel()]))
+            P["a"] = off + 4
+            got = ctx.render_frame_to_host(W, H, R, P)
+            atlas_inv = np.concatenate([np.zeros(F.ATLAS_SLACK + 4, np.uint8), inverse.ravel(),
+                                        np.zeros(F.ATLAS_SLACK, np.uint8)])
+            assert np.array_equal(got, gpu_util.hip_render(W, H, R, P2, atlas_inv)), \
+                "an upload after the reset was overwritten by an earlier conversion"
+            # ... and a conversion over where an upload went, read by a submit
+            ctx.atlas_put(np.full(4 << 20, 0x77, np.uint8))
+            ctx.atlas_reset()
+            P["a"] = burst(ctx, 3) + 4
+            fr.submit(R, P)
+            fr.wait()
+            assert np.array_equal(fr.host(), want)
+        finally:
+            fr.close()
