@@ -899,8 +899,6 @@ extern "C" int flutl_atlas_put_blurred (flutl_ctx *c, uint32_t w, uint32_t h,
   if (!c || !offset_out || w == 0 || h == 0 || w > 32766 || h > 32766 || radius < 0 ||
       radius > FLUTL_BLUR_MAX_RADIUS || distx > 127 || disty > 127)
     return FLUTL_EINVAL;
-  if ((long long) w * h * (2ll * radius + 1) * (2ll * radius + 1) > FLUTL_BLUR_MAX_TAPS)
-    return FLUTL_ERANGE;
   int rc = flutl_list_validate (w, h, regions, n_regions, prims, n_prims,
       c->atlas_used + kAtlasSlack);
   if (rc)

@@ -1101,14 +1101,14 @@ constexpr int kBlurMaxRWide = FLUTL_BLUR_MAX_RADIUS;   // flutl_blur_wide_kernel
 
 __global__ __launch_bounds__ (256) void flutl_blur_kernel_dev (
     const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int w, int h,
-    int stride_px, const int32_t *__restrict__ kern, int radius)
+    int stride_px, const int32_t *__restrict__ kern, int radius, int tile_row0)
 {
   extern __shared__ __attribute__ ((aligned (16))) uint32_t smem[];
   const int size = 2 * radius + 1;
   const int hw = kBlurTW + 2 * radius, hh = kBlurTH + 2 * radius;
   uint32_t *s_src = smem;                       // hw * hh
   int32_t *s_k = reinterpret_cast<int32_t *> (smem + hw * hh);  // size*size
-  const int tx0 = blockIdx.x * kBlurTW, ty0 = blockIdx.y * kBlurTH;
+  const int tx0 = blockIdx.x * kBlurTW, ty0 = (tile_row0 + blockIdx.y) * kBlurTH;
   const int tid = threadIdx.x;
 
   for (int i = tid; i < size * size; i += 256)
@@ -1152,10 +1152,10 @@ __global__ __launch_bounds__ (256) void flutl_blur_kernel_dev (
 // the L1/L2.  Same arithmetic, same results; O((2r+1)^2) loads per pixel.
 __global__ __launch_bounds__ (256) void flutl_blur_wide_kernel_dev (
     const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int w, int h,
-    int stride_px, const int32_t *__restrict__ kern, int radius)
+    int stride_px, const int32_t *__restrict__ kern, int radius, int row0)
 {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int y = row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= w || y >= h)
     return;
   const int size = 2 * radius + 1;
@@ -1532,22 +1532,47 @@ extern "C" int flutl_launch_blur (void *stream, const void *src, void *dst,
   if (!src || !dst || !kernel_fixed || w == 0 || h == 0 || radius < 0 ||
       radius > kBlurMaxRWide || (stride_bytes & 3) || stride_bytes < (size_t) w * 4)
     return FLUTL_EINVAL;
-  if (radius > kBlurMaxR) {
-    hipLaunchKernelGGL (flutl_blur_wide_kernel_dev, dim3 ((w + 63) / 64, (h + 3) / 4),
-        dim3 (256), 0, static_cast<hipStream_t> (stream),
-        static_cast<const uint32_t *> (src), static_cast<uint32_t *> (dst), (int) w,
-        (int) h, (int) (stride_bytes / 4), kernel_fixed, radius);
-    return hipGetLastError () == hipSuccess ? FLUTL_OK : FLUTL_ENODEV;
-  }
+  // A launch per band of rows: the convolution is not separable in the reference's fixed
+  // point, (2r + 1)^2 taps per pixel it is -- a 4K surface under a 300 pixel radius is 3e12 of
+  // them --, and no single kernel should run for seconds.  Bands of at most 2e10 taps
+  // (FLUTL_BLUR_BAND_TAPS: the tests' way to have many bands on a small surface), queued one
+  // behind the other.
   const int size = 2 * radius + 1;
+  long long band_taps = 20000000000ll;
+  if (const char *e = getenv ("FLUTL_BLUR_BAND_TAPS"))
+    if (atoll (e) > 0)
+      band_taps = atoll (e);
+  const long long row_taps = (long long) w * size * size;
+  if (radius > kBlurMaxR) {
+    long long rows = band_taps / row_taps;
+    rows = rows > (long long) h ? (long long) h : rows;
+    rows = rows < 4 ? 4 : (rows + 3) & ~3ll;       // (whole workgroups of 4 rows)
+    for (uint32_t y0 = 0; y0 < h; y0 += (uint32_t) rows) {
+      const uint32_t n = h - y0 < (uint32_t) rows ? h - y0 : (uint32_t) rows;
+      hipLaunchKernelGGL (flutl_blur_wide_kernel_dev, dim3 ((w + 63) / 64, (n + 3) / 4),
+          dim3 (256), 0, static_cast<hipStream_t> (stream),
+          static_cast<const uint32_t *> (src), static_cast<uint32_t *> (dst), (int) w,
+          (int) h, (int) (stride_bytes / 4), kernel_fixed, radius, (int) y0);
+      if (hipGetLastError () != hipSuccess)
+        return FLUTL_ENODEV;
+    }
+    return FLUTL_OK;
+  }
   const size_t lds = ((size_t) (kBlurTW + 2 * radius) * (kBlurTH + 2 * radius) +
       (size_t) size * size) * 4;
-  dim3 grid ((w + kBlurTW - 1) / kBlurTW, (h + kBlurTH - 1) / kBlurTH);
-  hipLaunchKernelGGL (flutl_blur_kernel_dev, grid, dim3 (256), lds,
-      static_cast<hipStream_t> (stream), static_cast<const uint32_t *> (src),
-      static_cast<uint32_t *> (dst), (int) w, (int) h, (int) (stride_bytes / 4),
-      kernel_fixed, radius);
-  return hipGetLastError () == hipSuccess ? FLUTL_OK : FLUTL_ENODEV;
+  const uint32_t tiles_x = (w + kBlurTW - 1) / kBlurTW, tiles_y = (h + kBlurTH - 1) / kBlurTH;
+  long long band = band_taps / (row_taps * kBlurTH);
+  band = band < 1 ? 1 : (band > 65535 ? 65535 : band);
+  for (uint32_t t0 = 0; t0 < tiles_y; t0 += (uint32_t) band) {
+    const uint32_t n = tiles_y - t0 < (uint32_t) band ? tiles_y - t0 : (uint32_t) band;
+    hipLaunchKernelGGL (flutl_blur_kernel_dev, dim3 (tiles_x, n), dim3 (256), lds,
+        static_cast<hipStream_t> (stream), static_cast<const uint32_t *> (src),
+        static_cast<uint32_t *> (dst), (int) w, (int) h, (int) (stride_bytes / 4),
+        kernel_fixed, radius, (int) t0);
+    if (hipGetLastError () != hipSuccess)
+      return FLUTL_ENODEV;
+  }
+  return FLUTL_OK;
 }
 
 extern "C" int flutl_launch_resample (void *stream, const void *src, void *dst,

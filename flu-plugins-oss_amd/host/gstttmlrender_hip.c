@@ -2029,10 +2029,10 @@ blurred_outline (GstTTMLRender *render, HipRegion *r, PangoLayout *layout, guint
   rotated = fabs (m.xx) < 1e-9 && fabs (m.yy) < 1e-9 && m.xy == -1.0 && m.yx == 1.0;
   if ((!rotated && (m.xx != 1.0 || m.yy != 1.0 || m.xy != 0.0 || m.yx != 0.0)) ||
       radius > FLUTL_BLUR_MAX_RADIUS || radius < 0 || !(sigma > 0.0) || tw <= 0 || th <= 0 ||
-      tw > 32766 || th > 32766 || fabs (m.x0) > 30000.0 || fabs (m.y0) > 30000.0 ||
-      (gint64) tw * th * (2 * radius + 1) * (2 * radius + 1) > FLUTL_BLUR_MAX_TAPS) {
+      tw > 32766 || th > 32766 || fabs (m.x0) > 30000.0 || fabs (m.y0) > 30000.0) {
     /* (no CTM other than a translation or the quarter turn of the vertical writing
-     * modes ever reaches this point; the blur limits are the library's, flutl.h) */
+     * modes ever reaches this point; the radius' limit is the library's, flutl.h: twice
+     * the radius at which the reference's kernel no longer fits its thread's stack) */
     GST_FIXME_OBJECT (render, "blurred textOutline of region '%s': a blur of %g px over "
         "%dx%d px is beyond what is implemented; the buffer is dropped", r->id,
         r->outline.length[1].f, tw, th);

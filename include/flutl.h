@@ -303,12 +303,13 @@ size_t flutl_atlas_size (const flutl_ctx *ctx);
  * (flutl_launch_rotate_cw) -- after the resample, whose weights are then along
  * the surface's own axes, and `box` is in the turned (device) axes.
  * If host_copy is not NULL the entry's bytes are also copied there (for
- * scene-pack dumps).  radius <= FLUTL_BLUR_MAX_RADIUS, and w * h * (2 radius + 1)^2
- * taps <= FLUTL_BLUR_MAX_TAPS (FLUTL_ERANGE beyond: the convolution is not
- * separable in the reference's fixed point, so its cost is what it is -- the
- * reference's pixman needs minutes per frame there). */
+ * scene-pack dumps).  radius <= FLUTL_BLUR_MAX_RADIUS -- twice what the reference survives:
+ * gstttmlblur.c:38 keeps (2 radius + 1)^2 doubles on the stack (g_newa), 8 MB of it at a
+ * radius of 511.  No limit on the surface: the convolution is not separable in the
+ * reference's fixed point, so its cost is w * h * (2 radius + 1)^2 taps whatever one does
+ * (the reference's pixman needs minutes per frame for large ones); it is queued as launches
+ * of at most 2e10 taps each (flutl_launch_blur). */
 #define FLUTL_BLUR_MAX_RADIUS 1024
-#define FLUTL_BLUR_MAX_TAPS   400000000000ll
 int  flutl_atlas_put_blurred (flutl_ctx *ctx, uint32_t w, uint32_t h,
     const flutl_region *regions, uint32_t n_regions,
     const flutl_prim *prims, uint32_t n_prims,

@@ -261,6 +261,75 @@ def test_blur_matches_oracle_large(gpu):
         assert np.array_equal(got, O.blur(src, k, r))
 
 
+def test_blur_in_bands_of_rows_is_the_blur(gpu, monkeypatch):
+    """A blur is queued as launches over bands of rows of at most 2e10 taps each
+    (flutl_launch_blur), so that no surface is too large and no kernel runs for seconds.
+    FLUTL_BLUR_BAND_TAPS makes the bands small: the same surface in 2 to 40 bands, through
+    either kernel, must be the oracle's blur -- incl. bands that end inside a tile row."""
+    import torch
+    rng = np.random.default_rng(11)
+    h, w = 157, 203
+    src = rng.integers(0, 1 << 32, (h, w), dtype=np.uint64).astype(np.uint32)
+    for r, sigma in [(3, 1.5), (16, 8.0), (21, 10.5)]:
+        k = F.blur_kernel(r, sigma)
+        want = O.blur(src, k, r)
+        size = 2 * r + 1
+        for bands in (2, 7, 40):
+            monkeypatch.setenv("FLUTL_BLUR_BAND_TAPS", str(w * h * size * size // bands))
+            d = torch.full((h * w * 4,), 0x5A, dtype=torch.uint8, device="cuda")
+            F.launch_blur(torch.cuda.current_stream().cuda_stream, gpu.to_dev(src), d,
+                          w, h, gpu.to_dev(k), r)
+            torch.cuda.synchronize()
+            got = d.cpu().numpy().view(np.uint32).reshape(h, w)
+            assert np.array_equal(got, want), (r, bands)
+    monkeypatch.delenv("FLUTL_BLUR_BAND_TAPS")
+
+
+def test_a_blur_beyond_the_former_limit_of_taps(gpu):
+    """Rounds 1-3 refused w * h * (2r + 1)^2 > 4e11 taps.  A context's blurred atlas entry of
+    4.6e11 taps (2048 x 1400 under a radius of 200): accepted, made in two dozen launches,
+    and right where it can be told without convolving on the CPU -- the surface is one opaque
+    rectangle, so a pixel of the result is, per channel, (c * S + 0x8000) >> 16 with S the sum
+    of the kernel's weights whose taps fall inside the rectangle (pixman's weights are cut to
+    16.16 one by one: at sigma 100 their sum is well short of 1.0, and the reference's blur is
+    that much darker)."""
+    W, H, r = 2048, 1400, 200
+    x0, y0, x1, y1 = 100, 100, 1948, 1300
+    colour = 0xFF336699
+    R = np.zeros(1, F.REGION_DTYPE)
+    R["x0"], R["y0"], R["x1"], R["y1"], R["first"], R["count"] = 0, 0, W, H, 0, 1
+    P = np.zeros(1, F.PRIM_DTYPE)
+    P["op"], P["rule"] = F.OP_RECT, F.RULE_PIXMAN
+    P["cx0"], P["cy0"], P["cx1"], P["cy1"] = x0, y0, x1, y1
+    P["a"], P["b"], P["c"], P["d"] = x0 * 256, y0 * 256, x1 * 256, y1 * 256
+    P["color"] = colour
+    assert W * H * (2 * r + 1) ** 2 > 4e11
+    k = F.blur_kernel(r, r / 2.0).reshape(2 * r + 1, 2 * r + 1).astype(np.int64)
+    assert np.array_equal(k.ravel(), O.blur_kernel(r, r / 2.0))
+    with F.Context(0) as ctx:
+        off, host = ctx.atlas_put_blurred(W, H, R, P, r, r / 2.0)
+        assert off > 0
+
+    def expect(x, y):
+        # taps (j, i) read the surface at (x - r + i, y - r + j)
+        i0, i1 = max(0, x0 - (x - r)), min(2 * r + 1, x1 - (x - r))
+        j0, j1 = max(0, y0 - (y - r)), min(2 * r + 1, y1 - (y - r))
+        S = int(k[j0:j1, i0:i1].sum()) if i1 > i0 and j1 > j0 else 0
+        out = 0
+        for sh in (24, 16, 8, 0):
+            c = (colour >> sh) & 0xFF
+            out |= min(255, max(0, (c * S + 0x8000) >> 16)) << sh
+        return out
+
+    rng = np.random.default_rng(5)
+    points = [(0, 0), (W - 1, H - 1), (x0, y0), (x0 + r, y0 + r), (1024, 700), (x1 - 1, 700),
+              (0, 700), (1024, H - 1)] + \
+        [(int(rng.integers(0, W)), int(rng.integers(0, H))) for _ in range(200)]
+    for (x, y) in points:
+        assert int(host[y, x]) == expect(x, y), (x, y, hex(int(host[y, x])), hex(expect(x, y)))
+    assert expect(1024, 700) != 0 and expect(1024, 700) != colour
+
+
 @pytest.mark.parametrize("size", [(1920, 1080), (3840, 2160), (7680, 4320)])
 def test_full_size_properties(gpu, size):
     """At BASELINE sizes (oracle too slow to run densely): size-independent
