@@ -310,9 +310,11 @@ def test_promise_buffers_through_a_converting_element(gpu, tmp_path):
 @pytest.mark.parametrize("doc,knobs", [("cfg2", {}), ("typical_4k", {}),
                                        ("cfg2", {"FLUTL_QUEUE_ALWAYS": "1"}),
                                        ("typical_4k", {"FLUTL_SYNC": "1"}),
-                                       ("wide_8k", {}), ("wide_8k", {"FLUTL_SYNC": "1"})],
+                                       ("wide_8k", {}), ("wide_8k", {"FLUTL_SYNC": "1"}),
+                                       ("typical_4k", {"FLUTL_ATLAS_LIMIT_MB": "4"}),
+                                       ("typical_4k", {"FLUTL_ONE_STREAM": "1"})],
                          ids=["cfg2", "typical_4k", "cfg2-queued", "typical_4k-sync", "wide_8k",
-                              "wide_8k-sync"])
+                              "wide_8k-sync", "typical_4k-atlas-starting-over", "typical_4k-one-stream"])
 def test_element_at_full_size_is_the_reference_s(gpu, doc, knobs):
     """The documents bench.py's end-to-end figures are measured on, through the real
     pipeline at 3840x2160 (`filesrc ! ttmlrender ! caps ! fdsink`, frames read from the
@@ -321,7 +323,9 @@ def test_element_at_full_size_is_the_reference_s(gpu, doc, knobs):
     frames of cfg2 (regions played back in other colours, delta read-back into pooled
     frames) and 121 of typical_4k (an outline stroked on a worker thread per cue); and
     wide_8k at 7680x4320: lines of 180 px text whose outlines are 6 000 pixels wide, beyond
-    the scan converter's 4 096-pixel boxes (converted in column windows)."""
+    the scan converter's 4 096-pixel boxes (converted in column windows).  typical_4k also
+    with the atlas starting over every few cues (4 MB: its bytes are used again while
+    conversions and compositor launches are in flight on their two streams)."""
     import json
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import make_e2e_sha

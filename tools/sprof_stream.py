@@ -34,7 +34,11 @@ def main():
     top = sys.argv[2] if len(sys.argv) > 2 else "30"
     tmp = tempfile.gettempdir()
     doc = os.path.join(tmp, "typical_long.ttml")
-    document(cues, doc)
+    if os.environ.get("SPROF_DOC") == "cfg2":      # (the cfg2 kind of stream, `cues` states long)
+        import gen_config_ttml
+        open(doc, "w").write(gen_config_ttml.gen("cfg2", 2, n_states=cues))
+    else:
+        document(cues, doc)
     so = os.path.join(tmp, "sprof.so")
     subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", os.path.join(ROOT, "tools", "sprof.c"),
                            "-o", so, "-lpthread"])
