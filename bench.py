@@ -396,7 +396,7 @@ def e2e_block(W, H, cpu_baseline, gpu_warm=None, defer_cfg2_ref=False):
         if gpu_warm:
             gpu_warm()
         e2e_timing.measure_streams(ttml, W, H, 4)
-        runs = [e2e_timing.measure_streams(ttml, W, H, 4, log_path=log) for _ in range(2)]
+        runs = [e2e_timing.measure_streams(ttml, W, H, 4, log_path=log) for _ in range(3)]
         best = max(runs, key=lambda r: r["frames_per_s"])
         out["cfg2_x4_streams"] = dict(best, value=best["frames_per_s"], unit="frames/s",
                                       runs=[r["frames_per_s"] for r in runs])
@@ -407,7 +407,7 @@ def e2e_block(W, H, cpu_baseline, gpu_warm=None, defer_cfg2_ref=False):
             progress("2400 states")
             if gpu_warm:
                 gpu_warm()
-            one = [e2e_timing.measure(long_ttml, W, H, log_path=log) for _ in range(2)]
+            one = [e2e_timing.measure(long_ttml, W, H, log_path=log) for _ in range(3)]
             progress("2400 states x 4 streams")
             four = [e2e_timing.measure_streams(long_ttml, W, H, 4, log_path=log) for _ in range(2)]
         b1 = max(one, key=lambda r: r["frames_per_s"])
