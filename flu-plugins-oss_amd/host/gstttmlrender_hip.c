@@ -509,11 +509,13 @@ typedef struct
   gboolean pool_prefill_set;
   guint max_ahead;           /* FLUTL_MAX_AHEAD: buffers ahead of the device (0: by size) */
   guint n_pushed;            /* buffers handed to the finisher since the last reset */
-  gboolean queue_always;     /* FLUTL_QUEUE_ALWAYS=1: every frame goes through the finisher
-                              * (default: a frame with all its masks there is queued on the
-                              * device by the streaming thread itself when the finisher is
-                              * idle; measured on one box, cfg2: 6.1 / 7.8 k frames/s that
-                              * way, 6.5 / 6.8 k through the finisher -- no clear winner) */
+  gboolean queue_always;     /* every frame goes through the finisher (the default since
+                              * round 4; FLUTL_QUEUE_ALWAYS=0: a frame with all its masks
+                              * there is queued on the device by the streaming thread itself
+                              * when the finisher is idle, as in rounds 2 and 3 -- at 7 k
+                              * frames/s there was no clear winner; at 20-28 k the 13-16 us
+                              * of a submit's runtime calls are a third of that thread's
+                              * time per buffer: tools/r4_queue_ab.sh) */
   GThread *finisher;
   GAsyncQueue *jobs;
   GMutex flight_lock;
@@ -3938,7 +3940,7 @@ gst_ttmlrender_init (GstTTMLRender *render)
   priv->ttml_chain = GST_PAD_CHAINFUNC (render->base.sinkpad);
   gst_pad_set_chain_function (render->base.sinkpad, ttml_chain_in_video_mode);
   priv->sync_mode = g_getenv ("FLUTL_SYNC") != NULL;
-  priv->queue_always = g_getenv ("FLUTL_QUEUE_ALWAYS") != NULL;
+  priv->queue_always = !(g_getenv ("FLUTL_QUEUE_ALWAYS") && g_getenv ("FLUTL_QUEUE_ALWAYS")[0] == '0');
   priv->max_ahead = g_getenv ("FLUTL_MAX_AHEAD")
       ? (guint) CLAMP (atoi (g_getenv ("FLUTL_MAX_AHEAD")), 1, 4 * MAX_IN_FLIGHT) : 0;
   priv->pool_prefill_set = g_getenv ("FLUTL_POOL_PREFILL") != NULL;

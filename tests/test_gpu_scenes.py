@@ -258,7 +258,7 @@ def test_instances_of_one_process_take_the_nodes_devices_in_turn(gpu, tmp_path, 
                                    {"FLUTL_MAX_AHEAD": "1", "FLUTL_STROKE_THREADS": "1"},
                                    {"FLUTL_FULL_D2H": "1"}, {"FLUTL_POOL_PREFILL": "0"},
                                    {"FLUTL_NO_SPAN_PLANS": "1", "FLUTL_NO_RUN_MERGE": "1"},
-                                   {"FLUTL_QUEUE_ALWAYS": "1", "FLUTL_NO_LAYOUT_CACHE": "1"},
+                                   {"FLUTL_QUEUE_ALWAYS": "0", "FLUTL_NO_LAYOUT_CACHE": "1"},
                                    {"FLUTL_NO_RECOLOUR": "1"}, {"FLUTL_HOST_STROKES": "1"},
                                    {"FLUTL_NO_COMPOSED_PATHS": "1"},
                                    {"FLUTL_CHECK_PATHS": "1", "FLUTL_MAX_AHEAD": "16"},
@@ -266,7 +266,7 @@ def test_instances_of_one_process_take_the_nodes_devices_in_turn(gpu, tmp_path, 
                                    {"FLUTL_NO_EDGE_BLOCKS": "1"}, {"FLUTL_ONE_STREAM": "1"},
                                    {"FLUTL_NO_FRAME_ARENA": "1"}],
                          ids=["sync", "no-region-cache", "ahead1", "full-d2h", "no-prefill",
-                              "no-plans-no-merge", "queue-always", "no-recolour", "host-strokes",
+                              "no-plans-no-merge", "direct-when-idle", "no-recolour", "host-strokes",
                               "paths-by-cairo", "paths-checked-ahead16", "writable", "scan-fused",
                               "no-edge-blocks", "one-stream", "no-frame-arena"])
 def test_element_modes_all_reproduce_the_reference(gpu, knobs):
@@ -308,12 +308,12 @@ def test_promise_buffers_through_a_converting_element(gpu, tmp_path):
 @pytest.mark.skipif(not gstenv.available(gstenv.HIP_PLUGIN_DIR),
                     reason="fluttml-hip plugin / GStreamer runtime not present")
 @pytest.mark.parametrize("doc,knobs", [("cfg2", {}), ("typical_4k", {}),
-                                       ("cfg2", {"FLUTL_QUEUE_ALWAYS": "1"}),
+                                       ("cfg2", {"FLUTL_QUEUE_ALWAYS": "0"}),
                                        ("typical_4k", {"FLUTL_SYNC": "1"}),
                                        ("wide_8k", {}), ("wide_8k", {"FLUTL_SYNC": "1"}),
                                        ("typical_4k", {"FLUTL_ATLAS_LIMIT_MB": "4"}),
                                        ("typical_4k", {"FLUTL_ONE_STREAM": "1"})],
-                         ids=["cfg2", "typical_4k", "cfg2-queued", "typical_4k-sync", "wide_8k",
+                         ids=["cfg2", "typical_4k", "cfg2-direct-when-idle", "typical_4k-sync", "wide_8k",
                               "wide_8k-sync", "typical_4k-atlas-starting-over", "typical_4k-one-stream"])
 def test_element_at_full_size_is_the_reference_s(gpu, doc, knobs):
     """The documents bench.py's end-to-end figures are measured on, through the real
