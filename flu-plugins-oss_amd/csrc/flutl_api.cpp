@@ -51,6 +51,7 @@ struct flutl_list {
 // page-locked memory is a true asynchronous DMA) and in HBM.
 struct list_slot {
   void *host;
+  void *host_dev;      // the device's address of `host`
   void *dev;
   size_t cap;
   hipEvent_t done;     // recorded after the last kernel that reads `dev`
@@ -122,6 +123,7 @@ struct flutl_ctx {
   hipStream_t scan_stream;
   hipEvent_t scan_ev, main_ev;
   bool scan_pending;
+  bool list_copy;               // FLUTL_LIST_COPY=1 (see flutl_frame_submit_staged)
   // FLUTL_API_TIMING=1: where flutl_frame_submit's time goes on the calling thread (ns)
   bool api_timing;
   uint64_t t_sub[6], n_sub;
@@ -361,6 +363,10 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
   c->scan_ev = c->main_ev = nullptr;
   c->scan_pending = false;
   {
+    const char *lc = getenv ("FLUTL_LIST_COPY");
+    c->list_copy = lc && *lc && *lc != '0';
+  }
+  {
     const char *one = getenv ("FLUTL_ONE_STREAM");
     if (!(one && *one && *one != '0')) {
       if (!hip_ok (hipStreamCreateWithFlags (&c->scan_stream, hipStreamNonBlocking)) ||
@@ -384,7 +390,7 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
   c->listbuf = nullptr;
   c->listbuf_cap = 0;
   for (auto &sl : c->slots)
-    sl = list_slot { nullptr, nullptr, 0, nullptr, false };
+    sl = list_slot { nullptr, nullptr, nullptr, 0, nullptr, false };
   c->next_slot = 0;
   c->stage = nullptr;
   c->stage_cap = c->stage_used = 0;
@@ -1572,7 +1578,7 @@ extern "C" int flutl_frame_stage (flutl_ctx *c, flutl_frame *f,
       (void) hipHostFree (sl.host);
     if (sl.dev)
       (void) hipFree (sl.dev);
-    sl.host = sl.dev = nullptr;
+    sl.host = sl.host_dev = sl.dev = nullptr;
     sl.cap = 0;
     size_t cap = (size_t) 1 << 16;
     while (cap < rb + pb + ob + 32)
@@ -1580,6 +1586,8 @@ extern "C" int flutl_frame_stage (flutl_ctx *c, flutl_frame *f,
     if (!hip_ok (hipHostMalloc (&sl.host, cap, hipHostMallocDefault)) ||
         !hip_ok (hipMalloc (&sl.dev, cap)))
       return FLUTL_ENOMEM;
+    if (!hip_ok (hipHostGetDevicePointer (&sl.host_dev, sl.host, 0)))
+      sl.host_dev = nullptr;
     sl.cap = cap;
   }
   if (!sl.done && !hip_ok (hipEventCreateWithFlags (&sl.done, hipEventDisableTiming)))
@@ -1661,16 +1669,25 @@ extern "C" int flutl_frame_submit_staged (flutl_ctx *c, flutl_frame *f)
     c->frame_cap = need;
   }
   bool ok = atlas_join (c);
-  // (the list: up with a scan conversion's launch since it was staged, or by a copy now)
+  // The list: up with a scan conversion's launch since it was staged; else the launch reads
+  // it where it lies, in the slot's page-locked half -- a few KB that the first waves fetch
+  // over PCIe and the others find in the L2: 3.2 us on the launch (tools/list_in_host_bench.py:
+  // 22.4 -> 25.6 us) instead of a copy operation of 4.2 us, the gap behind it and 3-6 us of
+  // hipMemcpyAsync on this thread.  The slot is not written again before its event has been
+  // seen.  FLUTL_LIST_COPY=1: copied, as before.
+  const uint8_t *lbase = static_cast<const uint8_t *> (sl.dev);
   if (c->staged.copy_pending) {
-    ok = hip_ok (hipMemcpyAsync (sl.dev, sl.host, c->staged.copy_bytes, hipMemcpyHostToDevice, c->stream));
+    if (sl.host_dev && !c->list_copy)
+      lbase = static_cast<const uint8_t *> (sl.host_dev);
+    else
+      ok = hip_ok (hipMemcpyAsync (sl.dev, sl.host, c->staged.copy_bytes, hipMemcpyHostToDevice, c->stream));
     c->staged.copy_pending = false;
   }
   if (!ok)
     return FLUTL_ENODEV;
   SUB_MARK (3);
-  const flutl_region *rd = static_cast<const flutl_region *> (sl.dev);
-  const flutl_prim *pd = reinterpret_cast<const flutl_prim *> (static_cast<uint8_t *> (sl.dev) + rb);
+  const flutl_region *rd = reinterpret_cast<const flutl_region *> (lbase);
+  const flutl_prim *pd = reinterpret_cast<const flutl_prim *> (lbase + rb);
   if (!c->delta_segments) {
     if (!hip_ok (hipMalloc (reinterpret_cast<void **> (&c->delta_segments), sizeof (uint64_t))) ||
         !hip_ok (hipMemsetAsync (c->delta_segments, 0, sizeof (uint64_t), c->stream)))
@@ -1681,7 +1698,7 @@ extern "C" int flutl_frame_submit_staged (flutl_ctx *c, flutl_frame *f)
   if (rc == FLUTL_OK && n_order)
     rc = flutl_launch_frame_delta (c->stream, width, height, f->twin, f->host_dev, c->frame,
         (size_t) width * 4, rd, c->staged.n_regions, pd, c->atlas, c->staged.y0, c->staged.y1,
-        reinterpret_cast<const uint16_t *> (static_cast<uint8_t *> (sl.dev) + rb + pb),
+        reinterpret_cast<const uint16_t *> (lbase + rb + pb),
         c->delta_segments);
   SUB_MARK (4);
   ok = rc == FLUTL_OK && hip_ok (hipEventRecord (sl.done, c->stream)) &&

@@ -264,11 +264,11 @@ def test_instances_of_one_process_take_the_nodes_devices_in_turn(gpu, tmp_path, 
                                    {"FLUTL_CHECK_PATHS": "1", "FLUTL_MAX_AHEAD": "16"},
                                    {"FLUTL_WRITABLE": "1"}, {"FLUTL_SCAN_FUSED": "1"},
                                    {"FLUTL_NO_EDGE_BLOCKS": "1"}, {"FLUTL_ONE_STREAM": "1"},
-                                   {"FLUTL_NO_FRAME_ARENA": "1"}],
+                                   {"FLUTL_NO_FRAME_ARENA": "1"}, {"FLUTL_LIST_COPY": "1"}],
                          ids=["sync", "no-region-cache", "ahead1", "full-d2h", "no-prefill",
                               "no-plans-no-merge", "direct-when-idle", "no-recolour", "host-strokes",
                               "paths-by-cairo", "paths-checked-ahead16", "writable", "scan-fused",
-                              "no-edge-blocks", "one-stream", "no-frame-arena"])
+                              "no-edge-blocks", "one-stream", "no-frame-arena", "list-copied"])
 def test_element_modes_all_reproduce_the_reference(gpu, knobs):
     """The element's pipeline knobs change how a buffer is produced, never what it
     holds: an outlined, animated scene and a moving outline under each of them."""
