@@ -65,6 +65,9 @@ constexpr uint32_t kEdgeEpochPolygons = 4;       // an event behind every so man
 
 struct FrameArena;
 
+// contexts alive per device in this process (see flutl_frame_stage: the lanes)
+static std::atomic<int> g_contexts[16];
+
 struct flutl_ctx {
   int device;
   hipStream_t stream;
@@ -112,18 +115,39 @@ struct flutl_ctx {
     int slot;
     size_t rb, pb, ob, copy_bytes;
     uint32_t n_regions, n_prims, n_order, y0, y1, now[4];
+    int lane;
   } staged;
   std::vector<FrameArena *> frame_arenas;
   // The outlines' scan conversions are queued on a stream of their own: they hang on nothing
   // the compositor does -- an atlas entry is written once, into bytes nothing has read yet --
   // so cue k + 1's conversion runs beside cue k's compositor launch, whose stores wait for
-  // PCIe (tools/overlap_bench.py: 48.7 us per pair in turn, 34.8 side by side).  scan_pending:
-  // entries queued there that `stream` has not been made to wait for yet (atlas_join).
+  // PCIe (tools/overlap_bench.py: 48.7 us per pair in turn, 34.8 side by side).  scan_gen:
+  // entries queued there; what each compositor lane has been made to wait for: atlas_join.
   // FLUTL_ONE_STREAM=1: everything on `stream`, as before round 4.
   hipStream_t scan_stream;
-  hipEvent_t scan_ev, main_ev;
-  bool scan_pending;
+  hipEvent_t scan_ev;
+  uint32_t scan_gen;            // atlas entries queued on the scan stream (one count per entry)
+  uint32_t scan_ev_gen;         // ... what scan_ev stands behind
+  uint32_t scan_joined[2];      // ... what each compositor lane has been made to wait for
   bool list_copy;               // FLUTL_LIST_COPY=1 (see flutl_frame_submit_staged)
+  // Frames are submitted to two streams in turn ("lanes"; lane 0 is `stream`, where everything
+  // else of the context is queued): a DELTA launch spends a third of its time waiting for its
+  // stores to cross PCIe, the next frame's launch composites meanwhile
+  // (tools/delta_two_streams_bench.py: 23.4 -> 15.1 us per launch).  What orders the lanes:
+  // a frame's own event when it changes lanes (flutl_frame.lane), an event behind lane 0's
+  // atlas uploads before a launch on lane 1 reads them (upload_gen), the scan stream's event
+  // per lane (scan_joined); the atlas starting over or growing drains all of them.  Each lane
+  // has a park buffer of its own.  FLUTL_ONE_LANE=1: lane 0 only.
+  hipStream_t stream2;
+  hipEvent_t lane_ev;
+  void *frame2;
+  size_t frame2_cap;
+  uint32_t n_staged;            // frames staged on alternating lanes so far: the next one's lane is its low bit
+  uint32_t upload_gen, upload_seen2;
+  uint32_t staged_scan_gen, staged_upload_gen;  // scan_gen / upload_gen when the last frame was staged
+  bool lanes_allowed;           // (not FLUTL_ONE_LANE)
+  uint32_t alone_run;           // frames staged in a row while this was the device's only context here
+  uint32_t lanes_after;         // ... of which so many before the second lane is used
   // FLUTL_API_TIMING=1: where flutl_frame_submit's time goes on the calling thread (ns)
   bool api_timing;
   uint64_t t_sub[6], n_sub;
@@ -165,6 +189,7 @@ struct flutl_frame {
   uint32_t width, height;
   FrameArena *arena;   // where host and twin come from (NULL: allocations of the frame's own)
   uint32_t arena_block;
+  int lane;            // the compositor lane of the context its last operation was queued on
   void *host;          // page-locked, device mapped
   void *host_dev;      // its device address
   void *twin;          // device
@@ -360,8 +385,33 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
     return FLUTL_ENODEV;
   }
   c->scan_stream = nullptr;
-  c->scan_ev = c->main_ev = nullptr;
-  c->scan_pending = false;
+  c->scan_ev = nullptr;
+  c->scan_gen = c->scan_ev_gen = c->scan_joined[0] = c->scan_joined[1] = 0;
+  c->stream2 = nullptr;
+  c->lane_ev = nullptr;
+  c->frame2 = nullptr;
+  c->frame2_cap = 0;
+  c->n_staged = 0;
+  c->upload_gen = c->upload_seen2 = 0;
+  c->staged_scan_gen = c->staged_upload_gen = 0;
+  {
+    const char *one = getenv ("FLUTL_ONE_LANE");
+    c->lanes_allowed = !(one && *one && *one != '0');
+    c->alone_run = 0;
+    // (FLUTL_LANES_AFTER=n: after n frames instead of 8; the tests' way to lanes at once)
+    const char *after = getenv ("FLUTL_LANES_AFTER");
+    c->lanes_after = after && *after ? (uint32_t) atoi (after) : 8u;
+    if (c->lanes_allowed) {
+      if (!hip_ok (hipStreamCreateWithFlags (&c->stream2, hipStreamNonBlocking)) ||
+          !hip_ok (hipEventCreateWithFlags (&c->lane_ev, hipEventDisableTiming))) {
+        if (c->stream2)
+          (void) hipStreamDestroy (c->stream2);
+        c->stream2 = nullptr;
+        c->lane_ev = nullptr;
+        c->lanes_allowed = false;
+      }
+    }
+  }
   {
     const char *lc = getenv ("FLUTL_LIST_COPY");
     c->list_copy = lc && *lc && *lc != '0';
@@ -370,12 +420,15 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
     const char *one = getenv ("FLUTL_ONE_STREAM");
     if (!(one && *one && *one != '0')) {
       if (!hip_ok (hipStreamCreateWithFlags (&c->scan_stream, hipStreamNonBlocking)) ||
-          !hip_ok (hipEventCreateWithFlags (&c->scan_ev, hipEventDisableTiming)) ||
-          !hip_ok (hipEventCreateWithFlags (&c->main_ev, hipEventDisableTiming))) {
+          !hip_ok (hipEventCreateWithFlags (&c->scan_ev, hipEventDisableTiming))) {
         if (c->scan_ev)
           (void) hipEventDestroy (c->scan_ev);
         if (c->scan_stream)
           (void) hipStreamDestroy (c->scan_stream);
+        if (c->stream2) {
+          (void) hipEventDestroy (c->lane_ev);
+          (void) hipStreamDestroy (c->stream2);
+        }
         (void) hipStreamDestroy (c->stream);
         delete c;
         return FLUTL_ENODEV;
@@ -459,6 +512,7 @@ extern "C" int flutl_ctx_create (int device, flutl_ctx **out)
           box, 0, base, base + own + 256, 16, 0 | 16, nullptr);
   }
   (void) hipStreamSynchronize (c->stream);
+  g_contexts[device & 15].fetch_add (1, std::memory_order_relaxed);
   *out = c;
   return FLUTL_OK;
 }
@@ -469,37 +523,56 @@ static inline hipStream_t scan_stream_of (flutl_ctx *c)
   return c->scan_stream ? c->scan_stream : c->stream;
 }
 
-// `stream` behind every atlas entry queued on the scan stream so far: before anything on
-// `stream` that reads the atlas (or writes where an entry was, or frees what a conversion uses)
-static bool atlas_join (flutl_ctx *c)
+static inline hipStream_t lane_stream (flutl_ctx *c, int lane)
 {
-  if (!c->scan_stream || !c->scan_pending)
+  return lane && c->stream2 ? c->stream2 : c->stream;
+}
+
+// A compositor lane behind every atlas entry queued on the scan stream so far: before anything
+// on it that reads the atlas (or writes where an entry was, or frees what a conversion uses)
+static bool atlas_join_lane (flutl_ctx *c, int lane)
+{
+  if (!c->scan_stream || c->scan_joined[lane] == c->scan_gen)
     return true;
-  if (!hip_ok (hipEventRecord (c->scan_ev, c->scan_stream)) ||
-      !hip_ok (hipStreamWaitEvent (c->stream, c->scan_ev, 0)))
+  if (c->scan_ev_gen != c->scan_gen) {
+    if (!hip_ok (hipEventRecord (c->scan_ev, c->scan_stream))) {
+      const bool ok = hip_ok (hipStreamSynchronize (c->scan_stream));
+      c->scan_joined[0] = c->scan_joined[1] = c->scan_ev_gen = c->scan_gen;
+      return ok;
+    }
+    c->scan_ev_gen = c->scan_gen;
+  }
+  if (!hip_ok (hipStreamWaitEvent (lane_stream (c, lane), c->scan_ev, 0)))
     return hip_ok (hipStreamSynchronize (c->scan_stream));
-  c->scan_pending = false;
+  c->scan_joined[lane] = c->scan_gen;
   return true;
 }
 
-// ... and the scan stream behind everything queued on `stream` so far: before bytes of the
-// atlas are used again (flutl_atlas_reset)
-static bool scan_stream_follows (flutl_ctx *c)
+static bool atlas_join (flutl_ctx *c) { return atlas_join_lane (c, 0); }
+
+// lane 1 behind the atlas uploads queued on lane 0 so far (flutl_atlas_put, _put_blurred)
+static bool uploads_join_lane (flutl_ctx *c, int lane)
 {
-  if (!c->scan_stream)
+  if (lane == 0 || !c->stream2 || c->upload_seen2 == c->upload_gen)
     return true;
-  if (!hip_ok (hipEventRecord (c->main_ev, c->stream)) ||
-      !hip_ok (hipStreamWaitEvent (c->scan_stream, c->main_ev, 0)))
+  if (!hip_ok (hipEventRecord (c->lane_ev, c->stream)) ||
+      !hip_ok (hipStreamWaitEvent (c->stream2, c->lane_ev, 0)))
     return hip_ok (hipStreamSynchronize (c->stream));
+  c->upload_seen2 = c->upload_gen;
   return true;
 }
 
+// every stream of the context drained
 static bool sync_streams (flutl_ctx *c)
 {
   bool ok = true;
   if (c->scan_stream) {
     ok = hip_ok (hipStreamSynchronize (c->scan_stream));
-    c->scan_pending = false;
+    c->scan_joined[0] = c->scan_joined[1] = c->scan_ev_gen = c->scan_gen;
+  }
+  if (c->stream2) {
+    ok = hip_ok (hipStreamSynchronize (c->stream2)) && ok;
+    c->upload_seen2 = c->upload_gen;
   }
   return hip_ok (hipStreamSynchronize (c->stream)) && ok;
 }
@@ -515,10 +588,13 @@ extern "C" void flutl_ctx_destroy (flutl_ctx *c)
         c->t_sub[3] / 1e3 / c->n_sub, c->t_sub[4] / 1e3 / c->n_sub, c->t_sub[5] / 1e3 / c->n_sub);
   (void) hipSetDevice (c->device);
   (void) sync_streams (c);
+  g_contexts[c->device & 15].fetch_sub (1, std::memory_order_relaxed);
   if (c->atlas)
     (void) hipFree (c->atlas);
   if (c->frame)
     (void) hipFree (c->frame);
+  if (c->frame2)
+    (void) hipFree (c->frame2);
   if (c->listbuf)
     (void) hipFree (c->listbuf);
   for (auto &sl : c->slots) {
@@ -547,8 +623,11 @@ extern "C" void flutl_ctx_destroy (flutl_ctx *c)
     frame_arena_unref (a);
   if (c->scan_stream) {
     (void) hipEventDestroy (c->scan_ev);
-    (void) hipEventDestroy (c->main_ev);
     (void) hipStreamDestroy (c->scan_stream);
+  }
+  if (c->stream2) {
+    (void) hipEventDestroy (c->lane_ev);
+    (void) hipStreamDestroy (c->stream2);
   }
   (void) hipStreamDestroy (c->stream);
   delete c;
@@ -599,11 +678,8 @@ static int atlas_reserve (flutl_ctx *c, size_t need)
   uint8_t *n = nullptr;
   if (!hip_ok (hipMalloc (reinterpret_cast<void **> (&n), cap)))
     return FLUTL_ENOMEM;
-  // (conversions in flight write the old buffer)
-  if (c->scan_stream) {
-    (void) hipStreamSynchronize (c->scan_stream);
-    c->scan_pending = false;
-  }
+  // (conversions in flight write the old buffer, launches on either lane read it)
+  (void) sync_streams (c);
   if (!hip_ok (hipMemsetAsync (n, 0, cap, c->stream))) {
     (void) hipFree (n);
     return FLUTL_ENODEV;
@@ -659,6 +735,7 @@ extern "C" int flutl_atlas_put (flutl_ctx *c, const void *src, size_t bytes,
     c->stage_used = 0;
   }
   c->atlas_used = end;
+  c->upload_gen++;
   *offset_out = (uint32_t) off;
   return FLUTL_OK;
 }
@@ -840,7 +917,7 @@ extern "C" int flutl_atlas_put_polygon (flutl_ctx *c, const int32_t *edges, uint
   }
   // the entry: the coverage, and the zero bytes around and between its rows (mode 8); the
   // converter's status words are the first of its scratch and stay zero between calls (16)
-  c->scan_pending = true;
+  c->scan_gen++;
   if (n_edges == 0) {
     if (!hip_ok (hipMemsetAsync (c->atlas + off, 0, bytes, ms)))
       return FLUTL_ENODEV;
@@ -999,11 +1076,11 @@ extern "C" void flutl_atlas_reset (flutl_ctx *c)
 {
   if (!c)
     return;
-  // (the bytes are used again: whatever is written there next, on either stream, comes behind
-  // everything queued so far on both)
+  // (the bytes are used again: whatever is written there next, on whichever stream, comes
+  // behind everything queued so far on all of them -- drained: this is once per document, or
+  // per 256 MB of masks)
   (void) hipSetDevice (c->device);
-  (void) atlas_join (c);
-  (void) scan_stream_follows (c);
+  (void) sync_streams (c);
   c->atlas_used = kAtlasSlack;
 }
 
@@ -1423,6 +1500,7 @@ extern "C" int flutl_frame_create_quiet (flutl_ctx *c, uint32_t width, uint32_t 
   f->pending = false;
   f->error = 0;
   f->written = false;
+  f->lane = 0;
   f->ext[0] = f->ext[1] = f->ext[2] = f->ext[3] = 0;
   bool ok = true, clean = false;
   f->arena = frame_arena_take (c, bytes, &f->arena_block, &clean);
@@ -1515,6 +1593,8 @@ extern "C" uint64_t flutl_ctx_delta_bytes (flutl_ctx *c)
   if (!c || !c->delta_segments)
     return 0;
   (void) hipSetDevice (c->device);
+  if (c->stream2)               // (launches on the other lane count into it too)
+    (void) hipStreamSynchronize (c->stream2);
   if (!hip_ok (hipMemcpyAsync (&n, c->delta_segments, sizeof n, hipMemcpyDeviceToHost, c->stream)) ||
       !hip_ok (hipStreamSynchronize (c->stream)))
     return 0;
@@ -1596,12 +1676,33 @@ extern "C" int flutl_frame_stage (flutl_ctx *c, flutl_frame *f,
     memcpy (sl.host, regions, (size_t) n_regions * sizeof (flutl_region));
   if (n_prims)
     memcpy (static_cast<uint8_t *> (sl.host) + rb, prims, (size_t) n_prims * sizeof (flutl_prim));
+  // the frame's lane: the two in turn -- while nothing new goes into the atlas (a frame that
+  // brings masks or outlines waits for them on lane 0 anyway, and would pay a join per lane:
+  // measured 4 % slower on a stream of new outlined text) and while this is the only context
+  // on its device in the process (every context has three streams, the runtime a handful of
+  // hardware queues per process: four elements with two lanes each were no faster, in one run
+  // of two 15 % slower, than with one); behind whatever the frame's last use queued on the other lane (its clearing when it
+  // was made, its last submission)
+  const bool quiet_atlas = c->staged_scan_gen == c->scan_gen && c->staged_upload_gen == c->upload_gen;
+  c->staged_scan_gen = c->scan_gen;
+  c->staged_upload_gen = c->upload_gen;
+  // (... for a few frames: the contexts of one pipeline's elements are made within
+  // milliseconds of each other)
+  const bool alone = g_contexts[c->device & 15].load (std::memory_order_relaxed) <= 1;
+  c->alone_run = alone ? c->alone_run + 1 : 0;
+  const int lane = c->stream2 && quiet_atlas && c->alone_run >= c->lanes_after ? (int) (c->n_staged++ & 1u) : 0;
+  hipStream_t ls = lane_stream (c, lane);
+  if (f->lane != lane) {
+    if (!hip_ok (hipStreamWaitEvent (ls, f->done, 0)))
+      return FLUTL_ENODEV;
+    f->lane = lane;
+  }
   // a frame its consumer wrote into: the twin is brought up to the host block (the whole
   // frame up, in stream order) and every row is composited, so that the comparison below
   // puts each pixel right again in both
   if (f->written.exchange (false, std::memory_order_acq_rel)) {
     if (!hip_ok (hipMemcpyAsync (f->twin, f->host, (size_t) width * 4 * height, hipMemcpyHostToDevice,
-            c->stream)))
+            ls)))
       return FLUTL_ENODEV;
     f->ext[0] = f->ext[1] = 0;
     f->ext[2] = width;
@@ -1623,6 +1724,7 @@ extern "C" int flutl_frame_stage (flutl_ctx *c, flutl_frame *f,
       y0, y1, reinterpret_cast<uint16_t *> (static_cast<uint8_t *> (sl.host) + rb + pb));
   SUB_MARK (2);
   c->staged.frame = f;
+  c->staged.lane = lane;
   c->staged.slot = slot;
   c->staged.rb = rb;
   c->staged.pb = pb;
@@ -1656,19 +1758,23 @@ extern "C" int flutl_frame_submit_staged (flutl_ctx *c, flutl_frame *f)
       c->staged.n_prims, c->atlas_used + kAtlasSlack);
   if (rc)
     return rc;
-  // scratch frame of the context (here: where translucent groups park pixels)
+  // scratch frame of the lane (here: where translucent groups park pixels)
+  const int lane = c->staged.lane;
+  hipStream_t ls = lane_stream (c, lane);
+  void *&park = lane ? c->frame2 : c->frame;
+  size_t &park_cap = lane ? c->frame2_cap : c->frame_cap;
   const size_t need = (size_t) width * 4 * height;
-  if (need > c->frame_cap) {
-    (void) hipStreamSynchronize (c->stream);
-    if (c->frame)
-      (void) hipFree (c->frame);
-    c->frame = nullptr;
-    c->frame_cap = 0;
-    if (!hip_ok (hipMalloc (&c->frame, need)))
+  if (need > park_cap) {
+    (void) hipStreamSynchronize (ls);
+    if (park)
+      (void) hipFree (park);
+    park = nullptr;
+    park_cap = 0;
+    if (!hip_ok (hipMalloc (&park, need)))
       return FLUTL_ENOMEM;
-    c->frame_cap = need;
+    park_cap = need;
   }
-  bool ok = atlas_join (c);
+  bool ok = atlas_join_lane (c, lane) && uploads_join_lane (c, lane);
   // The list: up with a scan conversion's launch since it was staged; else the launch reads
   // it where it lies, in the slot's page-locked half -- a few KB that the first waves fetch
   // over PCIe and the others find in the L2: 3.2 us on the launch (tools/list_in_host_bench.py:
@@ -1680,7 +1786,7 @@ extern "C" int flutl_frame_submit_staged (flutl_ctx *c, flutl_frame *f)
     if (sl.host_dev && !c->list_copy)
       lbase = static_cast<const uint8_t *> (sl.host_dev);
     else
-      ok = hip_ok (hipMemcpyAsync (sl.dev, sl.host, c->staged.copy_bytes, hipMemcpyHostToDevice, c->stream));
+      ok = hip_ok (hipMemcpyAsync (sl.dev, sl.host, c->staged.copy_bytes, hipMemcpyHostToDevice, ls));
     c->staged.copy_pending = false;
   }
   if (!ok)
@@ -1689,20 +1795,22 @@ extern "C" int flutl_frame_submit_staged (flutl_ctx *c, flutl_frame *f)
   const flutl_region *rd = reinterpret_cast<const flutl_region *> (lbase);
   const flutl_prim *pd = reinterpret_cast<const flutl_prim *> (lbase + rb);
   if (!c->delta_segments) {
+    // (once per context, and waited for: launches on either lane count into it)
     if (!hip_ok (hipMalloc (reinterpret_cast<void **> (&c->delta_segments), sizeof (uint64_t))) ||
-        !hip_ok (hipMemsetAsync (c->delta_segments, 0, sizeof (uint64_t), c->stream)))
+        !hip_ok (hipMemsetAsync (c->delta_segments, 0, sizeof (uint64_t), c->stream)) ||
+        !hip_ok (hipStreamSynchronize (c->stream)))
       rc = FLUTL_ENOMEM;
   }
   // one launch: composite those rows, compare with the twin, write what differs
   // into the twin and the host block (flutl_launch_frame_delta)
   if (rc == FLUTL_OK && n_order)
-    rc = flutl_launch_frame_delta (c->stream, width, height, f->twin, f->host_dev, c->frame,
+    rc = flutl_launch_frame_delta (ls, width, height, f->twin, f->host_dev, park,
         (size_t) width * 4, rd, c->staged.n_regions, pd, c->atlas, c->staged.y0, c->staged.y1,
         reinterpret_cast<const uint16_t *> (lbase + rb + pb),
         c->delta_segments);
   SUB_MARK (4);
-  ok = rc == FLUTL_OK && hip_ok (hipEventRecord (sl.done, c->stream)) &&
-      hip_ok (hipEventRecord (f->done, c->stream));
+  ok = rc == FLUTL_OK && hip_ok (hipEventRecord (sl.done, ls)) &&
+      hip_ok (hipEventRecord (f->done, ls));
   SUB_MARK (5);
   if (c->api_timing)
     c->n_sub++;
@@ -1710,7 +1818,7 @@ extern "C" int flutl_frame_submit_staged (flutl_ctx *c, flutl_frame *f)
   f->pending = true;
   if (!ok) {
     // whatever was queued: the frame's content is unknown from here on
-    (void) hipStreamSynchronize (c->stream);
+    (void) hipStreamSynchronize (ls);
     f->error = rc ? rc : FLUTL_ENODEV;
     return f->error;
   }

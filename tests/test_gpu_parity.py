@@ -593,6 +593,75 @@ def test_frame_submit_pipelines_without_waiting_in_between(gpu):
                 f.close()
 
 
+def test_frames_change_lanes_and_masks_arrive_just_in_time(gpu, monkeypatch):
+    """Submissions go to two compositor streams in turn while the atlas is quiet.  Five frames
+    in rotation change lanes; every third submission brings a mask (flutl_atlas_put, queued on
+    lane 0) that it and later ones -- on either lane -- composite over what an earlier
+    submission left in the same frame; a group parks frame pixels in the lane's scratch frame.
+    After 60 submissions without a wait in between every frame must hold the oracle's
+    frame of ITS last list; and again after waits at odd places."""
+    W, H = 640, 200
+    rng = np.random.default_rng(17)
+    monkeypatch.setenv("FLUTL_LANES_AFTER", "0")      # (a context takes to its second lane after 8 frames)
+    with F.Context(0) as ctx:
+        frames = [ctx.frame(W, H) for _ in range(5)]
+        atlas = [np.zeros(F.ATLAS_SLACK, np.uint8)]
+        last = {}
+        try:
+            masks = []
+            for i in range(60):
+                # a new mask every third submission (a submission that brings one stays on lane
+                # 0; the ones after it alternate and read masks lane 0 uploaded)
+                if i % 3 == 0:
+                    mw, mh = int(rng.integers(40, 200)), int(rng.integers(10, 60))
+                    m = np.zeros((mh, mw + 4), np.uint8)
+                    m[:, :mw] = rng.integers(0, 256, (mh, mw))
+                    blob = np.concatenate([np.zeros(4, np.uint8), m.ravel()])
+                    off = ctx.atlas_put(blob)
+                    pad = (-len(np.concatenate(atlas))) % 16
+                    assert off == len(np.concatenate(atlas)) + pad
+                    atlas += [np.zeros(pad, np.uint8), blob]
+                    masks.append((off, mw, mh))
+                off, mw, mh = masks[-1] if i % 3 != 2 else masks[int(rng.integers(0, len(masks)))]
+                x0, y0 = int(rng.integers(0, W - mw)), int(rng.integers(20, H - mh - 20))
+                R = np.zeros(1, F.REGION_DTYPE)
+                R["x0"], R["y0"], R["x1"], R["y1"], R["first"], R["count"] = 0, y0 - 20, W, y0 + mh + 20, 0, 4
+                P = np.zeros(4, F.PRIM_DTYPE)
+                P["cx0"], P["cy0"], P["cx1"], P["cy1"] = 0, y0 - 20, W, y0 + mh + 20
+                P["op"] = [F.OP_GROUP_BEGIN, F.OP_RECT, F.OP_MASK, F.OP_GROUP_END]
+                P["rule"] = [0, F.RULE_PIXMAN, F.RULE_LERP, 0]
+                P["color"][1] = 0x80402010
+                P["a"][1], P["b"][1], P["c"][1], P["d"][1] = 0, (y0 - 20) * 256, W * 256, (y0 + mh + 20) * 256
+                P["color"][2] = 0xFF000000 | int(rng.integers(0, 1 << 24))
+                P["cx0"][2], P["cy0"][2], P["cx1"][2], P["cy1"][2] = x0, y0, x0 + mw, y0 + mh
+                P["a"][2], P["b"][2], P["c"][2], P["d"][2] = off + 4, mw + 4, x0, y0
+                f = i % 5
+                frames[f].submit(R, _with_opacity(P, int(rng.integers(80, 256))))
+                last[f] = (R, _with_opacity.last)
+                if i in (13, 31, 32, 47):
+                    frames[f].wait()
+                    A = np.concatenate(atlas + [np.zeros(F.ATLAS_SLACK, np.uint8)])
+                    assert np.array_equal(frames[f].host(), O.render(W, H, R, _with_opacity.last, A)), i
+            A = np.concatenate(atlas + [np.zeros(F.ATLAS_SLACK, np.uint8)])
+            for f, fr in enumerate(frames):
+                fr.wait()
+                R, P = last[f]
+                exp = O.render(W, H, R, P, A)
+                assert np.array_equal(fr.host(), exp), f
+                assert np.array_equal(_twin_of(fr), exp), f
+        finally:
+            for fr in frames:
+                fr.close()
+
+
+def _with_opacity(P, alpha):
+    """GROUP_END carries the group's 8-bit alpha in `param` (include/flutl.h)"""
+    Q = P.copy()
+    Q["param"][3] = alpha
+    _with_opacity.last = Q
+    return Q
+
+
 @pytest.mark.parametrize("size,rows", [((320, 180), (37, 101)), ((333, 77), (0, 5)),
                                        ((640, 360), (350, 360)), ((640, 360), (16, 32))])
 def test_row_window_launch_writes_only_its_supertile_rows(gpu, size, rows):

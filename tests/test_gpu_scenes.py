@@ -264,11 +264,12 @@ def test_instances_of_one_process_take_the_nodes_devices_in_turn(gpu, tmp_path, 
                                    {"FLUTL_CHECK_PATHS": "1", "FLUTL_MAX_AHEAD": "16"},
                                    {"FLUTL_WRITABLE": "1"}, {"FLUTL_SCAN_FUSED": "1"},
                                    {"FLUTL_NO_EDGE_BLOCKS": "1"}, {"FLUTL_ONE_STREAM": "1"},
-                                   {"FLUTL_NO_FRAME_ARENA": "1"}, {"FLUTL_LIST_COPY": "1"}],
+                                   {"FLUTL_NO_FRAME_ARENA": "1"}, {"FLUTL_LIST_COPY": "1"},
+                                   {"FLUTL_ONE_LANE": "1"}],
                          ids=["sync", "no-region-cache", "ahead1", "full-d2h", "no-prefill",
                               "no-plans-no-merge", "direct-when-idle", "no-recolour", "host-strokes",
                               "paths-by-cairo", "paths-checked-ahead16", "writable", "scan-fused",
-                              "no-edge-blocks", "one-stream", "no-frame-arena", "list-copied"])
+                              "no-edge-blocks", "one-stream", "no-frame-arena", "list-copied", "one-lane"])
 def test_element_modes_all_reproduce_the_reference(gpu, knobs):
     """The element's pipeline knobs change how a buffer is produced, never what it
     holds: an outlined, animated scene and a moving outline under each of them."""
@@ -312,9 +313,12 @@ def test_promise_buffers_through_a_converting_element(gpu, tmp_path):
                                        ("typical_4k", {"FLUTL_SYNC": "1"}),
                                        ("wide_8k", {}), ("wide_8k", {"FLUTL_SYNC": "1"}),
                                        ("typical_4k", {"FLUTL_ATLAS_LIMIT_MB": "4"}),
-                                       ("typical_4k", {"FLUTL_ONE_STREAM": "1"})],
+                                       ("typical_4k", {"FLUTL_ONE_STREAM": "1"}),
+                                       ("cfg2", {"FLUTL_LANES_AFTER": "8"}),
+                                       ("cfg2", {"FLUTL_ONE_LANE": "1"})],
                          ids=["cfg2", "typical_4k", "cfg2-direct-when-idle", "typical_4k-sync", "wide_8k",
-                              "wide_8k-sync", "typical_4k-atlas-starting-over", "typical_4k-one-stream"])
+                              "wide_8k-sync", "typical_4k-atlas-starting-over", "typical_4k-one-stream",
+                              "cfg2-lanes-as-shipped", "cfg2-one-lane"])
 def test_element_at_full_size_is_the_reference_s(gpu, doc, knobs):
     """The documents bench.py's end-to-end figures are measured on, through the real
     pipeline at 3840x2160 (`filesrc ! ttmlrender ! caps ! fdsink`, frames read from the

@@ -63,8 +63,13 @@ while time.perf_counter() - t0 < 0.5:
     y = x @ x
 torch.cuda.synchronize()
 ref = None
-for kind in ("device", "host non-coherent", "host coherent", "device"):
-    per = build(kind)
+dev_hosts = [torch.zeros(W * H * 4, dtype=torch.uint8, device="cuda") for _ in range(nf)]
+pinned_hosts = hosts
+for kind in ("device", "host non-coherent", "host coherent", "device", "device, frames' host blocks in HBM"):
+    per = build("device" if kind.startswith("device") else kind)
+    hosts = dev_hosts if "HBM" in kind else pinned_hosts
+    for t in twins:
+        t.zero_()
 
     def launch(i):
         rd, nr, pd, y0, y1, od = per[i % len(per)]
