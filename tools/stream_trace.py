@@ -18,7 +18,11 @@ import sprof_stream  # noqa: E402
 def main():
     cues = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
     doc = os.path.join(tempfile.gettempdir(), "typical_long.ttml")
-    sprof_stream.document(cues, doc)
+    if os.environ.get("SPROF_DOC") == "cfg2":      # (the cfg2 kind of stream, `cues` states long)
+        import gen_config_ttml
+        open(doc, "w").write(gen_config_ttml.gen("cfg2", 2, n_states=cues))
+    else:
+        sprof_stream.document(cues, doc)
     out = os.path.join(ROOT, "gpurun_out", "stream_trace")
     os.makedirs(out, exist_ok=True)
     env = gstenv.env_for(gstenv.HIP_PLUGIN_DIR, {"FLUTL_TIMING": "1", "TMPDIR": "/tmp"})
