@@ -491,7 +491,7 @@ typedef struct
   GHashTable *layouts;       /* layout cache: key string -> PangoLayout, per document */
   gboolean no_layout_cache;  /* FLUTL_NO_LAYOUT_CACHE=1 */
   GHashTable *plans;         /* SpanPlan * (a set): what span_to_region does, by its inputs */
-  GByteArray *plan_key;
+  struct KeyBuf *plan_key;
   gboolean no_span_plans;    /* FLUTL_NO_SPAN_PLANS=1 */
   GPtrArray *region_cache;   /* RegionEntry *: recorded regions by what determines them */
   gboolean no_region_cache;  /* FLUTL_NO_REGION_CACHE=1 */
@@ -635,6 +635,8 @@ typedef struct
   GString *par_key;          /* the par_add_attr calls so far, as bytes (layout cache key) */
   gboolean par_unkeyable;    /* ... or attributes that are not plain data (shapes) */
   gint par_plain_len;
+  GList *pending_attrs;      /* a region put in for its background (background_region) whose
+                              * configuring waits for a span to do it: its attribute stack */
 } HipRegion;
 
 #define COMP(c, shift) ((((c) >> (shift)) & 255) / 255.0)
@@ -839,7 +841,7 @@ par_add_attr (HipRegion *r, PangoAttribute *attr)
    * that copies every attribute) */
   gint32 rec[6] = { 0, (gint32) attr->start_index, (gint32) attr->end_index, 0, 0, 0 };
   if (!r->par_key)
-    r->par_key = g_string_new (NULL);
+    r->par_key = g_string_sized_new (8 * sizeof rec);
   if (attr->klass->type == PANGO_ATTR_FOREGROUND || attr->klass->type == PANGO_ATTR_BACKGROUND) {
     const PangoColor *c = &((PangoAttrColor *) attr)->color;
     rec[0] = attr->klass->type == PANGO_ATTR_FOREGROUND ? 1 : 2;
@@ -1000,8 +1002,10 @@ span_to_region_slow (GstTTMLRender *render, GList **regions, GstTTMLSpan *span)
   if (link) {
     r = link->data;
     /* reference :647-654: only the first contributor configures the region */
-    if (!r->layouts && !r->par)
+    if (!r->layouts && !r->par) {
       region_configure (render, r, &merged);
+      r->pending_attrs = NULL;
+    }
   } else {
     r = g_new0 (HipRegion, 1);
     r->id = g_strdup (rid);
@@ -1122,21 +1126,46 @@ span_plan_free (gpointer data)
   g_free (p);
 }
 
+/* Hash of a cache key (some 600 bytes for a span plan, eight per buffer): four independent
+ * multiply chains over 32 bytes at a time -- one chain waited 5 cycles per word for itself. */
+static guint
+bytes_hash (const guint8 *p, gsize n)
+{
+  guint64 h0 = 0xcbf29ce484222325ull, h1 = 0x9e3779b97f4a7c15ull, h2 = 0xc2b2ae3d27d4eb4full,
+      h3 = 0x165667b19e3779f9ull, h;
+  gsize i = 0;
+  for (; i + 32 <= n; i += 32) {
+    guint64 w[4];
+    memcpy (w, p + i, 32);
+    h0 = (h0 ^ w[0]) * 0x100000001b3ull;
+    h1 = (h1 ^ w[1]) * 0x100000001b3ull;
+    h2 = (h2 ^ w[2]) * 0x100000001b3ull;
+    h3 = (h3 ^ w[3]) * 0x100000001b3ull;
+    h0 ^= h0 >> 29;
+    h1 ^= h1 >> 31;
+    h2 ^= h2 >> 27;
+    h3 ^= h3 >> 33;
+  }
+  h = (h0 ^ (h1 << 1 | h1 >> 63)) * 0x100000001b3ull;
+  h = (h ^ h2) * 0x100000001b3ull;
+  h = (h ^ h3) * 0x100000001b3ull;
+  for (; i + 8 <= n; i += 8) {
+    guint64 w;
+    memcpy (&w, p + i, 8);
+    h = (h ^ w) * 0x100000001b3ull;
+    h ^= h >> 29;
+  }
+  for (; i < n; i++)
+    h = (h ^ p[i]) * 0x100000001b3ull;
+  h ^= n;
+  return (guint) (h ^ (h >> 32));
+}
+
 static guint
 span_plan_hash (gconstpointer v)
 {
   const SpanPlan *p = v;
-  guint64 h = 0xcbf29ce484222325ull;
-  gsize i = 0;
-  for (; i + 8 <= p->key_len; i += 8) {
-    guint64 w;
-    memcpy (&w, p->key + i, 8);
-    h = (h ^ w) * 0x100000001b3ull;
-    h ^= h >> 29;
-  }
-  for (; i < p->key_len; i++)
-    h = (h ^ p->key[i]) * 0x100000001b3ull;
-  return (guint) (h ^ (h >> 32));
+  return bytes_hash (p->key, p->key_len);
 }
 
 static gboolean
@@ -1146,40 +1175,66 @@ span_plan_equal (gconstpointer a, gconstpointer b)
   return x->key_len == y->key_len && memcmp (x->key, y->key, x->key_len) == 0;
 }
 
-static void
-key_put (GByteArray *k, gconstpointer p, guint n)
+/* (a plain growing buffer written with inlined copies: some 80 fields per span and eight
+ * spans per buffer went through g_byte_array_append, a tenth of gen_buffer on a stream of
+ * cached regions) */
+typedef struct KeyBuf
 {
-  g_byte_array_append (k, p, n);
+  guint8 *data;
+  gsize len, cap;
+} KeyBuf;
+
+static inline guint8 *
+key_room (KeyBuf *k, gsize n)
+{
+  if (G_UNLIKELY (k->len + n > k->cap)) {
+    k->cap = (k->len + n) * 2 + 256;
+    k->data = g_realloc (k->data, k->cap);
+  }
+  k->len += n;
+  return k->data + k->len - n;
 }
 
-static void
-key_put_string (GByteArray *k, const gchar *str)
+static inline void
+key_put (KeyBuf *k, gconstpointer p, gsize n)
 {
-  guint32 n = str ? (guint32) strlen (str) + 1 : 0;
-  key_put (k, &n, 4);
+  memcpy (key_room (k, n), p, n);
+}
+
+static inline void
+key_put_u32 (KeyBuf *k, guint32 v)
+{
+  memcpy (key_room (k, 4), &v, 4);
+}
+
+static inline void
+key_put_string (KeyBuf *k, const gchar *str)
+{
+  const guint32 n = str ? (guint32) strlen (str) + 1 : 0;
+  key_put_u32 (k, n);
   if (n)
     key_put (k, str, n);
 }
 
 /* the bytes of an attribute list that determine what it means */
 static void
-key_put_attrs (GByteArray *k, GList *attrs)
+key_put_attrs (KeyBuf *k, GList *attrs)
 {
   guint32 n = 0;
   GList *l;
-  for (l = attrs; l; l = l->next)
-    n++;
-  key_put (k, &n, 4);
+  guint8 *count = key_room (k, 4);
+  const gsize count_at = (gsize) (count - k->data);
   for (l = attrs; l; l = l->next) {
     const GstTTMLAttribute *a = l->data;
-    guint32 type = (guint32) a->type;
-    key_put (k, &type, 4);
+    n++;
+    key_put_u32 (k, (guint32) a->type);
     key_put_string (k, a->value.string);
     /* (the anonymous union after `string`: attributes are made zero-filled and
      * copied whole, so equal values are equal bytes) */
     key_put (k, (const guint8 *) &a->value + sizeof (gchar *),
         sizeof a->value - sizeof (gchar *));
   }
+  memcpy (k->data + count_at, &n, 4);     /* (the buffer may have moved) */
 }
 
 static SpanPlan *
@@ -1291,16 +1346,20 @@ span_plan_apply (const SpanPlan *p, GList **regions, GstTTMLSpan *span)
     r->outline = q->outline;
     r->overflow_visible = q->overflow_visible;
     r->writing_mode = q->writing_mode;
+    r->pending_attrs = NULL;
   }
   if (!link)
     *regions = g_list_insert_sorted (*regions, r, region_cmp_z);
 
   if (span->length) {
+    /* (the paragraph's buffer at its final size: grown by doubling from nothing it was
+     * half a dozen reallocs per region and buffer) */
+    const gsize hl = strlen (p->head), tl = strlen (p->tail);
     if (!r->par)
-      r->par = g_string_new (NULL);
-    g_string_append (r->par, p->head);
+      r->par = g_string_sized_new (hl + span->length + tl + 64);
+    g_string_append_len (r->par, p->head, hl);
     g_string_append_len (r->par, span->chars, span->length);
-    g_string_append (r->par, p->tail);
+    g_string_append_len (r->par, p->tail, tl);
   }
   if (!r->par_vals && !r->par_style.attributes) {
     r->par_vals = TRUE;
@@ -1350,7 +1409,7 @@ span_to_region (GstTTMLRender *render, GList **regions, GstTTMLSpan *span)
   GstTTMLAttribute *a;
   GList *region_attrs = NULL;
   gboolean region_known = FALSE;
-  GByteArray *k;
+  KeyBuf *k;
   SpanPlan probe, *p;
   gint32 ctx[6];
 
@@ -1365,9 +1424,9 @@ span_to_region (GstTTMLRender *render, GList **regions, GstTTMLSpan *span)
         a->value.string, NULL, (gpointer *) &region_attrs);
   /* the plan's key: everything the slow path reads */
   if (!priv->plan_key)
-    priv->plan_key = g_byte_array_new ();
+    priv->plan_key = g_new0 (KeyBuf, 1);
   k = priv->plan_key;
-  g_byte_array_set_size (k, 0);
+  k->len = 0;
   ctx[0] = base->state.frame_width;
   ctx[1] = base->state.frame_height;
   ctx[2] = base->state.cell_resolution_x;
@@ -1413,9 +1472,16 @@ background_region (gpointer key, gpointer value, gpointer user_data)
   if (a && a->value.show_background != GST_TTML_SHOW_BACKGROUND_ALWAYS)
     return;
   if (!g_list_find_custom (*regions, key, region_cmp_id)) {
+    /* Its place in the paint order now (the z index), the other dozen attributes when no
+     * span turns out to configure the region (gen_buffer, after the spans): the first span
+     * that reaches a region configures it over again anyway (:647-654), from its own merged
+     * style -- on a stream of eight regions with text, eight region_configure calls per
+     * buffer for nothing. */
     HipRegion *r = g_new0 (HipRegion, 1);
     r->id = g_strdup (key);
-    region_configure (render, r, &style);
+    a = gst_ttml_style_get_attr (&style, GST_TTML_ATTR_ZINDEX);
+    r->zindex = a ? a->value.i : 0;
+    r->pending_attrs = value;
     *regions = g_list_insert_sorted (*regions, r, region_cmp_z);
   }
 }
@@ -1553,17 +1619,7 @@ static guint
 layout_key_hash (gconstpointer v)
 {
   const GString *k = v;
-  guint64 h = 0xcbf29ce484222325ull;
-  gsize i = 0;
-  for (; i + 8 <= k->len; i += 8) {
-    guint64 w;
-    memcpy (&w, k->str + i, 8);
-    h = (h ^ w) * 0x100000001b3ull;
-    h ^= h >> 29;
-  }
-  for (; i < k->len; i++)
-    h = (h ^ (guint8) k->str[i]) * 0x100000001b3ull;
-  return (guint) (h ^ (h >> 32));
+  return bytes_hash ((const guint8 *) k->str, k->len);
 }
 
 static gboolean
@@ -1627,7 +1683,8 @@ region_flush_paragraph (GstTTMLRender *render, HipRegion *r)
       break;
   }
   if (!priv->no_layout_cache) {
-    key = g_string_new (NULL);
+    /* (at its final size, more or less: see span_plan_apply) */
+    key = g_string_sized_new ((r->par ? r->par->len : 0) + (r->par_key ? r->par_key->len : 0) + 192);
     if (!layout_cache_key (key, render->pango_context, r, w, h,
             wrap == GST_TTML_WRAP_OPTION_YES, align, spacing)) {
       g_string_free (key, TRUE);
@@ -3022,6 +3079,16 @@ gst_ttmlrender_gen_buffer (GstTTMLBase *base, GstClockTime ts, GstClockTime dura
   }
   for (l = base->active_spans; l; l = l->next)
     span_to_region (render, &regions, l->data);
+  for (l = regions; l; l = l->next) {
+    /* background regions no span has configured */
+    HipRegion *r = l->data;
+    if (r->pending_attrs) {
+      GstTTMLStyle style;
+      style.attributes = r->pending_attrs;
+      r->pending_attrs = NULL;
+      region_configure (render, r, &style);
+    }
+  }
   if (priv->timing && priv->n_timed)
     priv->t_build += g_get_monotonic_time () - t_start;
   for (l = regions; l; l = l->next) {
@@ -3488,7 +3555,8 @@ gst_ttmlrender_dispose (GObject *object)
     priv->plans = NULL;
   }
   if (priv->plan_key) {
-    g_byte_array_unref (priv->plan_key);
+    g_free (priv->plan_key->data);
+    g_free (priv->plan_key);
     priv->plan_key = NULL;
   }
   if (priv->jobs) {
