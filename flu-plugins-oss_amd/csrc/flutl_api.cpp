@@ -336,7 +336,12 @@ extern "C" uint32_t flutl_row_order (uint32_t width, uint32_t height,
   if (!order_out || row0 >= row1 || row1 > height || height > 32767)
     return 0;
   const uint32_t base = row0 / 16u, n = (row1 + 15u) / 16u - base;
-  std::vector<uint32_t> weight (n, 0u);
+  // (on the stack, sorted without a temporary buffer: this runs once per frame on the thread
+  // that feeds the device -- a vector and std::stable_sort's buffer were two allocations and
+  // 3 us of its 24 per frame)
+  uint64_t key[2048];           // height <= 32767: at most 2048 supertile rows
+  for (uint32_t k = 0; k < n; k++)
+    key[k] = 0;
   for (uint32_t r = 0; r < n_regions; r++) {
     const flutl_region &rg = regions[r];
     for (uint32_t i = rg.first; i < rg.first + rg.count && i < n_prims; i++) {
@@ -346,17 +351,19 @@ extern "C" uint32_t flutl_row_order (uint32_t width, uint32_t height,
       // tiles of 64 px the primitive crosses in a row, times what a tile of it costs
       const uint32_t tiles = (uint32_t) (p.cx1 - 1) / 64u - (uint32_t) p.cx0 / 64u + 1u;
       const uint32_t cost = p.op == FLUTL_OP_MASK ? 8u : p.op == FLUTL_OP_RECT ? 1u : 6u;
-      const uint32_t a = (uint32_t) p.cy0 / 16u, b = (uint32_t) (p.cy1 - 1) / 16u;
-      for (uint32_t row = a; row <= b; row++)
-        if (row >= base && row < base + n)
-          weight[row - base] += tiles * cost;
+      uint32_t a = (uint32_t) p.cy0 / 16u, b = (uint32_t) (p.cy1 - 1) / 16u;
+      a = a < base ? base : a;
+      b = b >= base + n ? base + n - 1 : b;
+      for (uint32_t row = a; row <= b && row >= base; row++)
+        key[row - base] += tiles * cost;
     }
   }
+  // heaviest first, equal rows top to bottom: one ascending sort of (~weight, row)
   for (uint32_t k = 0; k < n; k++)
-    order_out[k] = (uint16_t) k;
-  // (stable: equal rows stay top to bottom)
-  std::stable_sort (order_out, order_out + n,
-      [&] (uint16_t x, uint16_t y) { return weight[x] > weight[y]; });
+    key[k] = ((uint64_t) (0xffffffffu - (uint32_t) (key[k] > 0xffffffffull ? 0xffffffffull : key[k])) << 16) | k;
+  std::sort (key, key + n);
+  for (uint32_t k = 0; k < n; k++)
+    order_out[k] = (uint16_t) (key[k] & 0xffffu);
   (void) width;
   return n;
 }
