@@ -2574,7 +2574,12 @@ stroke_pool_get (void)
     const char *e = g_getenv ("FLUTL_STROKE_THREADS");
     int n = e ? atoi (e) : (int) g_get_num_processors () - 1;
     n = n < 1 ? 1 : (n > 32 ? 32 : n);
-    stroke_pool = g_thread_pool_new (stroke_job_run, NULL, n, FALSE, NULL);
+    /* (exclusive: its threads are made now and stay.  A shared pool keeps at most two
+     * idle threads of the process around -- GLib's max_unused_threads -- and on a stream that
+     * needs five workers every now and then it made and ended threads all the time: a
+     * pthread_create on the streaming thread per push, its mmap, mprotect and clone a fifth
+     * of that thread's time in a region of new outlined text, tools/sprof.c) */
+    stroke_pool = g_thread_pool_new (stroke_job_run, NULL, n, TRUE, NULL);
   }
   g_mutex_unlock (&stroke_pool_lock);
   return stroke_pool;
