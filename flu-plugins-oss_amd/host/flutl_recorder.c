@@ -69,7 +69,9 @@ typedef struct
   double hscale;
   double x, y, w, h;
   int npoly;                 /* ... or, if set, a closed polygon of npoly points (x, y, w, h: its box) */
-  double poly[24];
+  double *poly;              /* (its own allocation: the ops of a cue's outline are copied and
+                              * sorted as a whole, and 192 bytes of points in every one of them --
+                              * used by one glyph in a million -- more than doubled their size) */
   cairo_matrix_t m;
 } PathOp;
 
@@ -1700,6 +1702,7 @@ path_ops_clear (FlutlRecorder *rec)
       g_object_unref (rec->ops[i].font);
     if (rec->ops[i].sfont)
       cairo_scaled_font_destroy (rec->ops[i].sfont);
+    free (rec->ops[i].poly);
   }
   rec->n_ops = 0;
 }
@@ -1771,6 +1774,9 @@ flutl_recorder_path_polygon (FlutlRecorder *rec, const double *pts, int n)
   PathOp *op = path_op_push (rec);
   double x0 = pts[0], y0 = pts[1], x1 = pts[0], y1 = pts[1];
   op->npoly = n;
+  op->poly = malloc ((size_t) n * 2 * sizeof (double));
+  if (!op->poly)
+    abort ();
   memcpy (op->poly, pts, (size_t) n * 2 * sizeof (double));
   for (int i = 1; i < n; i++) {
     x0 = MIN (x0, pts[2 * i]);
