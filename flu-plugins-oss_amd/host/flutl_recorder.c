@@ -193,6 +193,8 @@ struct FlutlRecorder
   int color_opaque, color_clear;
   uint16_t color_tag;           /* who set the colour (element's numbering; 0: not said) */
   const cairo_matrix_t *ctm_inverse;   /* the reference's inverse CTM, if the caller keeps it */
+  int ctm_given;                /* the next glyph's CTM is `ctm`, not the context's (flutl_recorder_set_ctm) */
+  cairo_matrix_t ctm;
   uint16_t *prim_tags;          /* per primitive, parallel to prims */
 
   uint32_t unsupported;
@@ -1168,7 +1170,10 @@ show_scaled_glyph (FlutlRecorder *rec, cairo_scaled_font_t *sf, uint32_t glyph, 
     double cy)
 {
   cairo_matrix_t m;
-  cairo_get_matrix (rec->cr, &m);
+  if (rec->ctm_given)
+    m = rec->ctm;
+  else
+    cairo_get_matrix (rec->cr, &m);
   if (m.xx == 1.0 && m.yy == 1.0 && m.xy == 0.0 && m.yx == 0.0) {
     cx += m.x0;
     cy += m.y0;
@@ -1716,8 +1721,22 @@ path_op_push (FlutlRecorder *rec)
   }
   PathOp *op = &rec->ops[rec->n_ops++];
   memset (op, 0, sizeof *op);
-  cairo_get_matrix (rec->cr, &op->m);
+  if (rec->ctm_given)
+    op->m = rec->ctm;
+  else
+    cairo_get_matrix (rec->cr, &op->m);
   return op;
+}
+
+/* The CTM of the next glyph shown or added to the path, given instead of set on the tracking
+ * context and read back (a cairo_set_matrix inverts and checks the matrix; per glyph and pass
+ * it was a tenth of a region of new text).  NULL: the context's again. */
+void
+flutl_recorder_set_ctm (FlutlRecorder *rec, const cairo_matrix_t *m)
+{
+  rec->ctm_given = m != NULL;
+  if (m)
+    rec->ctm = *m;
 }
 
 void

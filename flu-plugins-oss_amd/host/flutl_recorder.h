@@ -63,6 +63,9 @@ void flutl_recorder_get_color (FlutlRecorder *rec, double rgba[4]);
 uint32_t flutl_recorder_pixel_of (double r, double g, double b, double a);
 void flutl_recorder_set_color_tag (FlutlRecorder *rec, uint16_t tag);
 void flutl_recorder_set_ctm_inverse (FlutlRecorder *rec, const cairo_matrix_t *inverse);
+/* the CTM of the next show_glyph / path_glyph of a KNOWN glyph, given instead of set on the
+ * tracking context (NULL: the context's again) */
+void flutl_recorder_set_ctm (FlutlRecorder *rec, const cairo_matrix_t *m);
 uint16_t flutl_recorder_get_color_tag (FlutlRecorder *rec);
 const uint16_t *flutl_recorder_prim_tags (FlutlRecorder *rec);
 

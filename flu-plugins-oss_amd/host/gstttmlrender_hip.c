@@ -1991,12 +1991,18 @@ walk_layout (GstTTMLRender *render, FlutlRecorder *rec, PangoLayout *layout,
           /* reference: the glyph offsets are applied here AND again by Pango */
           CTM_TRANSLATE (gi->geometry.x_offset / (double) PANGO_SCALE,
               gi->geometry.y_offset / (double) PANGO_SCALE);
-          CTM_SYNC ();
+          /* (a glyph of the font: its CTM handed over; Pango's boxes and arrows for a glyph
+           * no font has are drawn with calls on the context, which then needs it) */
+          if (gi->glyph & PANGO_GLYPH_UNKNOWN_FLAG)
+            CTM_SYNC ();
+          else
+            flutl_recorder_set_ctm (rec, &m);
           if (fill) {
             flutl_recorder_show_glyph (rec, run->item->analysis.font, gi);
           } else {
             flutl_recorder_path_glyph (rec, run->item->analysis.font, gi);
           }
+          flutl_recorder_set_ctm (rec, NULL);
           m = stack[2];
           minv = stack_inv[2];
           CTM_TRANSLATE (gi->geometry.width / (double) PANGO_SCALE, 0);
