@@ -2590,6 +2590,30 @@ stroke_job_run (gpointer data, gpointer user_data)
 static GThreadPool *stroke_pool;
 static GMutex stroke_pool_lock;
 
+/* The processors this process may keep busy: the machine's, or what its control group's CPU
+ * bandwidth allows where that is less (a container given 16 of a 256-processor host's: 255
+ * workers' worth of threads there would only take turns being throttled). */
+static int
+cpu_budget (void)
+{
+  int n = (int) g_get_num_processors ();
+  FILE *f = fopen ("/sys/fs/cgroup/cpu.max", "r");
+  if (f) {
+    long long quota = 0, period = 0;
+    char first[32] = "";
+    if (fscanf (f, "%31s %lld", first, &period) == 2 && strcmp (first, "max") != 0 && period > 0) {
+      quota = atoll (first);
+      if (quota > 0) {
+        const int by_quota = (int) ((quota + period - 1) / period);
+        if (by_quota >= 1 && by_quota < n)
+          n = by_quota;
+      }
+    }
+    fclose (f);
+  }
+  return n;
+}
+
 
 static GThreadPool *
 stroke_pool_get (void)
@@ -2597,7 +2621,7 @@ stroke_pool_get (void)
   g_mutex_lock (&stroke_pool_lock);
   if (!stroke_pool) {
     const char *e = g_getenv ("FLUTL_STROKE_THREADS");
-    int n = e ? atoi (e) : (int) g_get_num_processors () - 1;
+    int n = e ? atoi (e) : cpu_budget () - 1;
     n = n < 1 ? 1 : (n > 32 ? 32 : n);
     /* (exclusive: its threads are made now and stay.  A shared pool keeps at most two
      * idle threads of the process around -- GLib's max_unused_threads -- and on a stream that
