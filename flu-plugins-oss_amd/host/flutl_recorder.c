@@ -2610,6 +2610,21 @@ cpu_budget (void)
       }
     }
     fclose (f);
+  } else {
+    /* (control groups v1) */
+    long long quota = -1, period = 0;
+    FILE *q = fopen ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r");
+    FILE *p = fopen ("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+    if (q && p && fscanf (q, "%lld", &quota) == 1 && fscanf (p, "%lld", &period) == 1 &&
+        quota > 0 && period > 0) {
+      const int by_quota = (int) ((quota + period - 1) / period);
+      if (by_quota >= 1 && by_quota < n)
+        n = by_quota;
+    }
+    if (q)
+      fclose (q);
+    if (p)
+      fclose (p);
   }
   return n;
 }
