@@ -149,6 +149,11 @@ struct FlutlRecorder
   uint32_t n_ops, cap_ops;
   StrokeEntry *strokes;
   uint32_t n_strokes, cap_strokes;
+  /* by hash, open addressing: entry index + 1, 0 empty (a stream of new outlined text has
+   * some 470 entries before its caches start over, and every new outline looked through all
+   * of them: 2.6 us of each cue, a twentieth of its recording) */
+  uint32_t *stroke_index;
+  uint32_t stroke_index_cap;
   /* the keys of `strokes` name scaled fonts by address: every such font is
    * referenced here for as long as the cache lives, so that an address cannot
    * come back as a different font */
@@ -618,6 +623,8 @@ drop_caches (FlutlRecorder *rec)
     }
   }
   rec->n_strokes = 0;
+  if (rec->stroke_index)
+    memset (rec->stroke_index, 0, rec->stroke_index_cap * sizeof *rec->stroke_index);
   if (rec->outlines)            /* (keyed by the addresses of the fonts released next) */
     g_hash_table_remove_all (rec->outlines);
   for (uint32_t i = 0; i < rec->n_key_fonts; i++)
@@ -666,6 +673,7 @@ flutl_recorder_free (FlutlRecorder *rec)
   path_ops_clear (rec);
   free (rec->ops);
   free (rec->strokes);
+  free (rec->stroke_index);
   if (rec->outlines)
     g_hash_table_destroy (rec->outlines);
   free (rec->key_fonts);
@@ -3326,8 +3334,12 @@ ops_find_mask (FlutlRecorder *rec, int fill, int *dx, int *dy, int *is_new)
   size_t key_len = stroke_key (rec, lw, base_x + ox, base_y + oy, &key);
   uint64_t h = hash_bytes (key, key_len);
   *is_new = 0;
-  for (uint32_t i = 0; i < rec->n_strokes; i++) {
-    StrokeEntry *e = &rec->strokes[i];
+  /* (entries of one hash are met in the order they were made, as the list was walked) */
+  for (uint32_t pos = (uint32_t) h; rec->stroke_index_cap; pos++) {
+    const uint32_t v = rec->stroke_index[pos & (rec->stroke_index_cap - 1)];
+    if (!v)
+      break;
+    StrokeEntry *e = &rec->strokes[v - 1];
     if (e->hash == h && e->key_len == key_len && memcmp (e->key, key, key_len) == 0) {
       const int tx = base_x - e->base_x, ty = base_y - e->base_y;
       /* A mask made clear of its limits is the stroke at any integer
@@ -3362,6 +3374,29 @@ ops_find_mask (FlutlRecorder *rec, int fill, int *dx, int *dy, int *is_new)
   e->base_y = base_y;
   *dx = *dy = 0;
   *is_new = 1;
+  /* into the index: grown to at least twice the entries, everything put in again */
+  if (rec->n_strokes * 2 > rec->stroke_index_cap) {
+    uint32_t cap = rec->stroke_index_cap ? rec->stroke_index_cap * 2 : 256;
+    while (cap < rec->n_strokes * 2)
+      cap *= 2;
+    free (rec->stroke_index);
+    rec->stroke_index = calloc (cap, sizeof *rec->stroke_index);
+    if (!rec->stroke_index)
+      abort ();
+    rec->stroke_index_cap = cap;
+    for (uint32_t i = 0; i + 1 < rec->n_strokes; i++) {
+      uint32_t pos = (uint32_t) rec->strokes[i].hash;
+      while (rec->stroke_index[pos & (cap - 1)])
+        pos++;
+      rec->stroke_index[pos & (cap - 1)] = i + 1;
+    }
+  }
+  {
+    uint32_t pos = (uint32_t) h;
+    while (rec->stroke_index[pos & (rec->stroke_index_cap - 1)])
+      pos++;
+    rec->stroke_index[pos & (rec->stroke_index_cap - 1)] = rec->n_strokes;
+  }
   return e;
 }
 
