@@ -175,6 +175,8 @@ struct FlutlRecorder
   int in_run_flush, no_run_merge;
   struct RunEntry *runs;
   uint32_t n_runs, cap_runs;
+  uint32_t *run_index;          /* by hash, as stroke_index (up to 4096 runs were walked per line of new text) */
+  uint32_t run_index_cap;
   uint32_t runs_merged, runs_clashed;     /* statistics */
 
   /* deferred strokes (root recorder only): what the streaming thread and the
@@ -633,6 +635,8 @@ drop_caches (FlutlRecorder *rec)
   for (uint32_t i = 0; i < rec->n_runs; i++)
     free (rec->runs[i].key);
   rec->n_runs = 0;
+  if (rec->run_index)
+    memset (rec->run_index, 0, rec->run_index_cap * sizeof *rec->run_index);
   rec->n_run = 0;
   rec->atlas_size = ATLAS_SLACK;
   if (rec->atlas && madvise (rec->atlas, rec->atlas_cap, MADV_DONTNEED) != 0)
@@ -680,6 +684,7 @@ flutl_recorder_free (FlutlRecorder *rec)
   free (rec->patches);
   free (rec->run);
   free (rec->runs);
+  free (rec->run_index);
   g_rec_mutex_clear (&rec->lock);
   free (rec);
 }
@@ -1297,12 +1302,16 @@ run_flush (FlutlRecorder *rec)
   const uint64_t h = hash_bytes ((const uint8_t *) key, key_len);
   g_rec_mutex_lock (&rec->lock);      /* (the atlas is shared with the resolving thread) */
   RunEntry *e = NULL;
-  for (uint32_t i = 0; i < rec->n_runs; i++)
-    if (rec->runs[i].hash == h && rec->runs[i].key_len == key_len &&
-        memcmp (rec->runs[i].key, key, key_len) == 0) {
-      e = &rec->runs[i];
+  for (uint32_t pos = (uint32_t) h; rec->run_index_cap; pos++) {
+    const uint32_t v = rec->run_index[pos & (rec->run_index_cap - 1)];
+    if (!v)
+      break;
+    if (rec->runs[v - 1].hash == h && rec->runs[v - 1].key_len == key_len &&
+        memcmp (rec->runs[v - 1].key, key, key_len) == 0) {
+      e = &rec->runs[v - 1];
       break;
     }
+  }
   if (!e) {                     /* first sighting: remember it, emit as before */
     /* (a live stream without outlines never fills the atlas, so nothing else ever
      * clears this table: bound it -- a run forgotten is a run seen for the first
@@ -1311,6 +1320,8 @@ run_flush (FlutlRecorder *rec)
       for (uint32_t i = 0; i < rec->n_runs; i++)
         free (rec->runs[i].key);
       rec->n_runs = 0;
+      if (rec->run_index)
+        memset (rec->run_index, 0, rec->run_index_cap * sizeof *rec->run_index);
     }
     if (rec->n_runs == rec->cap_runs) {
       rec->cap_runs = rec->cap_runs ? rec->cap_runs * 2 : 32;
@@ -1323,6 +1334,18 @@ run_flush (FlutlRecorder *rec)
     e->key_len = key_len;
     key = NULL;
     rec->region_provisional = 1;
+    if (!rec->run_index) {      /* (8192 places for at most 4096 runs: never more than half full) */
+      rec->run_index_cap = 8192;
+      rec->run_index = calloc (rec->run_index_cap, sizeof *rec->run_index);
+      if (!rec->run_index)
+        abort ();
+    }
+    {
+      uint32_t pos = (uint32_t) h;
+      while (rec->run_index[pos & (rec->run_index_cap - 1)])
+        pos++;
+      rec->run_index[pos & (rec->run_index_cap - 1)] = rec->n_runs;
+    }
   } else if (e->state == 0) {   /* second sighting: one mask, if coverages never meet */
     const int W = x1 - x0, H = y1 - y0;
     uint8_t *m = calloc ((size_t) W, (size_t) H);
